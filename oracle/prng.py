@@ -1,0 +1,140 @@
+"""JAX threefry2x32 PRNG restated in numpy (oracle; test infrastructure only).
+
+The reference draws every random number through ``jax.random`` (jax 0.6.0,
+``uv.lock:993``) with the default ``threefry2x32`` implementation and
+``jax_threefry_partitionable=True``.  JAX itself is absent from the reference
+tree, so this file restates the published algorithm (Random123 Threefry-2x32,
+20 rounds) and JAX's derivations of ``split`` / ``random_bits`` / ``uniform`` /
+``gumbel`` / ``categorical`` / ``randint`` / ``permutation`` from it.
+
+Reference call sites: rec_magpo.py:135,202,373,439-450,642,660,699;
+networks/utils/sable/decode.py:141-142; coordsum/env.py:56-57;
+wrappers/auto_reset_wrapper.py:74; wrappers/episode_metrics.py:62.
+
+Pinned by the Random123 known-answer vectors (tests/test_oracle_prng.py);
+the JAX-specific derivations are restated from memory of jax/_src/prng.py and
+jax/_src/random.py and are PARITY UNPINNED until checked on a machine with JAX.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+_U32 = np.uint32
+_ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
+_PARITY = _U32(0x1BD11BDA)
+
+
+def _rotl(x: np.ndarray, r: int) -> np.ndarray:
+    return (x << _U32(r)) | (x >> _U32(32 - r))
+
+
+def threefry2x32(k0, k1, c0, c1):
+    """Threefry-2x32-20 block function; all arguments broadcastable uint32 arrays."""
+    with np.errstate(over="ignore"):
+        k0 = np.asarray(k0, dtype=_U32)
+        k1 = np.asarray(k1, dtype=_U32)
+        x0 = np.asarray(c0, dtype=_U32).copy()
+        x1 = np.asarray(c1, dtype=_U32).copy()
+        k0, k1, x0, x1 = np.broadcast_arrays(k0, k1, x0, x1)
+        x0 = x0.copy()
+        x1 = x1.copy()
+        ks = (k0, k1, k0 ^ k1 ^ _PARITY)
+        x0 = x0 + ks[0]
+        x1 = x1 + ks[1]
+        for i in range(5):
+            for r in _ROT[i % 2]:
+                x0 = x0 + x1
+                x1 = _rotl(x1, r)
+                x1 = x1 ^ x0
+            x0 = x0 + ks[(i + 1) % 3]
+            x1 = x1 + ks[(i + 2) % 3] + _U32(i + 1)
+    return x0, x1
+
+
+def prng_key(seed: int) -> np.ndarray:
+    """jax.random.PRNGKey(seed) for 0 <= seed < 2**64: [hi32, lo32]."""
+    seed = int(seed)
+    return np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=_U32)
+
+
+def _iota_2x32(n: int):
+    idx = np.arange(n, dtype=np.uint64)
+    return (idx >> np.uint64(32)).astype(_U32), (idx & np.uint64(0xFFFFFFFF)).astype(_U32)
+
+
+def split(key: np.ndarray, num: int = 2) -> np.ndarray:
+    """jax.random.split (partitionable / 'fold-like'): row i = threefry(key, (0, i)).
+
+    ``key`` may be a single key (2,) -> (num, 2), or a batch (..., 2) -> (..., num, 2).
+    """
+    key = np.asarray(key, dtype=_U32)
+    hi, lo = _iota_2x32(num)
+    k0 = key[..., 0][..., None]
+    k1 = key[..., 1][..., None]
+    x0, x1 = threefry2x32(k0, k1, hi, lo)
+    return np.stack([x0, x1], axis=-1)
+
+
+def random_bits(key: np.ndarray, n: int) -> np.ndarray:
+    """32-bit ``_random_bits(key, 32, shape)`` flattened: element i = x0 ^ x1 of
+    threefry(key, (hi(i), lo(i))).  Batched keys (..., 2) -> (..., n)."""
+    key = np.asarray(key, dtype=_U32)
+    hi, lo = _iota_2x32(n)
+    k0 = key[..., 0][..., None]
+    k1 = key[..., 1][..., None]
+    x0, x1 = threefry2x32(k0, k1, hi, lo)
+    return x0 ^ x1
+
+
+def bits_to_uniform(bits: np.ndarray, minval: float = 0.0, maxval: float = 1.0) -> np.ndarray:
+    """jax.random._uniform for float32 given the raw 32 bits."""
+    fbits = (bits >> _U32(9)) | _U32(0x3F800000)
+    floats = fbits.view(np.float32) - np.float32(1.0)
+    lo = np.float32(minval)
+    hi = np.float32(maxval)
+    return np.maximum(lo, floats * (hi - lo) + lo).astype(np.float32)
+
+
+def bits_to_gumbel(bits: np.ndarray) -> np.ndarray:
+    """jax.random.gumbel (mode 'low'): -log(-log(uniform(tiny, 1)))."""
+    u = bits_to_uniform(bits, np.finfo(np.float32).tiny, 1.0)
+    return (-np.log(-np.log(u))).astype(np.float32)
+
+
+def categorical(key: np.ndarray, logits: np.ndarray) -> np.ndarray:
+    """jax.random.categorical(key, logits, axis=-1) with the gumbel tensor laid out
+    row-major over ``logits.shape`` (what distrax's ``sample`` with n=1 produces for a
+    (B,1,K) logits batch: shape (1,B,1,K); decode.py:141-142)."""
+    logits = np.asarray(logits, dtype=np.float32)
+    g = bits_to_gumbel(random_bits(key, logits.size)).reshape(logits.shape)
+    return np.argmax(g + logits, axis=-1).astype(np.int32)
+
+
+def randint(key: np.ndarray, n: int, minval: int, maxval: int) -> np.ndarray:
+    """jax.random.randint(key, (n,), minval, maxval) for int32. Batched keys allowed."""
+    ks = split(key, 2)
+    hi_bits = random_bits(ks[..., 0, :], n)
+    lo_bits = random_bits(ks[..., 1, :], n)
+    span = _U32(maxval - minval) if maxval > minval else _U32(1)
+    with np.errstate(over="ignore"):
+        mult = _U32(1 << 16) % span
+        mult = _U32((np.uint64(mult) * np.uint64(mult)) & np.uint64(0xFFFFFFFF)) % span
+        off = (hi_bits % span) * mult + (lo_bits % span)
+        off = off % span
+    return (np.int64(minval) + off.astype(np.int64)).astype(np.int32)
+
+
+def permutation(key: np.ndarray, n: int) -> np.ndarray:
+    """jax.random.permutation(key, n): repeated stable sort by random 32-bit keys."""
+    x = np.arange(n, dtype=np.int32)
+    num_rounds = int(math.ceil(3 * math.log(max(1, n)) / math.log(2**32 - 1)))
+    key = np.asarray(key, dtype=_U32)
+    for _ in range(num_rounds):
+        ks = split(key, 2)
+        key, sub = ks[0], ks[1]
+        sort_keys = random_bits(sub, n)
+        order = np.argsort(sort_keys, kind="stable")
+        x = x[order]
+    return x
