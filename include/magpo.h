@@ -1,0 +1,143 @@
+/* magpo.h -- C ABI of libmagpo_hip.so: the MI355X (gfx950) kernels behind the MAGPO Anakin learner.
+ *
+ * The reference (liyheng/MAGPO) has no FFI: its hot path is one jitted XLA program behind the Python
+ * callable `learn: LearnerFn[GPOLearnerState]` (mava/systems/gpo/anakin/rec_magpo.py:91-530, :635-636).
+ * This header is the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md); every entry
+ * point names the reference computation it replaces.
+ *
+ * Conventions
+ *   - plain C types only; all pointers are DEVICE pointers unless the name ends in _host;
+ *   - fp32 row-major; `ld*` / `*_stride` are element strides; `hipStream_t` is passed as void*;
+ *   - stream-ordered and asynchronous; no allocation, no host synchronisation, no global state;
+ *   - return 0 on success, <0 on error (-1 invalid argument, -2 launch failure); the message is
+ *     available from magpo_last_error() (thread-local).
+ *   - "slab" outputs are per-workgroup partial sums [grid][width] that the caller reduces with
+ *     magpo_reduce_slabs (fixed order => bit-stable results).
+ */
+#ifndef MAGPO_H
+#define MAGPO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* magpo_stream_t; /* hipStream_t */
+
+const char* magpo_last_error(void);
+int magpo_abi_version(void);
+
+/* ---- K12 PRNG: jax.random threefry2x32 (rec_magpo.py:135,202,439,642,660,699; decode.py:141) ---- */
+int magpo_threefry_split(const uint32_t* key, uint32_t* out, long num, magpo_stream_t stream);
+int magpo_threefry_random_bits(const uint32_t* key, uint32_t* out, long num, magpo_stream_t stream);
+int magpo_key_split_host(const uint32_t* key_host, int num, uint32_t* out_host);
+int magpo_random_bits_host(const uint32_t* key_host, int num, uint32_t* out_host);
+
+/* ---- K1 CoordSum env + wrappers (coordsum/env.py:55-139, wrappers/{matrax,observation,auto_reset_wrapper,episode_metrics}.py) ---- */
+int magpo_coordsum_reset(int* step_count, int* target, int* record, uint32_t* key, uint32_t* metrics_key,
+                         float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A, int K, int TLIM,
+                         int maxval, const uint32_t* env_keys, float* obs, int* obs_step, magpo_stream_t stream);
+int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key, uint32_t* metrics_key,
+                        float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A, int K, int TLIM,
+                        int maxval, const int* actions, int act_stride, float* reward, unsigned char* done,
+                        float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
+                        int auto_reset, magpo_stream_t stream);
+
+/* ---- dense layers on fp32 MFMA (flax nn.Dense / retention projections) ---- */
+int magpo_linear(const float* X, int ldx, const float* Wt, const float* bias, float* Y, int ldy, float* Ypre,
+                 long R, int KIN, int NOUT, int act, magpo_stream_t stream);
+long magpo_wgrad_workspace_floats(int KIN, int NOUT, int G);
+int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, long R, int KIN, int krows, int NOUT, float* dW,
+                float* db, float* workspace, int G, float scale, int accumulate, magpo_stream_t stream);
+int magpo_reduce_slabs(const float* slab, float* out, int G, long P, long stride, float scale, int accumulate,
+                       magpo_stream_t stream);
+int magpo_transpose_pad(const float* W, float* Wt, int K, int N, int Npad, magpo_stream_t stream);
+int magpo_small_linear(const float* X, int ldx, int F, const float* W, const float* b, float* Y, int ldy, int N,
+                       long R, int relu, magpo_stream_t stream);
+
+/* ---- token-local Sable rows (sable_network.py:62-71,93-137,188-217,255-319; retention.py:289-294) ---- */
+int magpo_row_grid(long R);
+int magpo_pe_table(float* pe, int npos, int E, magpo_stream_t stream);
+int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const float* s_obs, const float* W,
+                    const int* idx, int idx_stride, const float* s_ln, const float* pe, const int* pos,
+                    int pos_stride, int npos, float* z, int ldz, float* xn, int ldxn, float* kin, int ldkin,
+                    long R, magpo_stream_t stream);
+int magpo_embed_bwd(int mode, const float* z, int ldz, const float* d0, int ldd0, const float* d1, int ldd1,
+                    const float* d2, int ldd2, const float* s_ln, float* dz, int lddz, float* slab_sln,
+                    const float* obs, int ldo, int F, const float* s_obs, const float* W, float* slab_sobs,
+                    long R, magpo_stream_t stream);
+int magpo_small_operand(int mode, const float* obs, int ldo, int F, const float* s_obs, const int* idx,
+                        int idx_stride, float* out, long R, magpo_stream_t stream);
+int magpo_retpost_fwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
+                      float* u, int ldu, long R, magpo_stream_t stream);
+int magpo_retpost_bwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
+                      const float* du, int lddu, float* dr, int lddr, float* dgp, int lddg, float* slab_gamma,
+                      float* slab_beta, long R, magpo_stream_t stream);
+int magpo_resnorm_fwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
+                      const float* pe, const int* pos, int pos_stride, int npos, float* out, int ldout,
+                      float* outpe, int ldoutpe, long R, magpo_stream_t stream);
+int magpo_resnorm_bwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
+                      const float* d0, int ldd0, const float* d1, int ldd1, const float* d2, int ldd2,
+                      float* dsum, int lddsum, float* slab_s1, float* slab_s2, long R, magpo_stream_t stream);
+int magpo_headmid_fwd(const float* hpre, int ldh, const float* s, float* hn, int ldhn, const float* w,
+                      const float* b, float* value, int value_stride, long R, magpo_stream_t stream);
+int magpo_headmid_bwd(const float* hpre, int ldh, const float* s, const float* dhn, int lddhn, const float* w,
+                      const float* dvalue, int dvalue_stride, float* dhpre, int lddh, float* slab_s,
+                      float* slab_w, float* slab_b, long R, magpo_stream_t stream);
+int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, magpo_stream_t stream);
+
+/* ---- K2/K7 retention (retention.py:66-115 chunkwise + recurrent, :117-213 decay matrix / xi) ---- */
+int magpo_retention_num_chunks(int T, int A);
+int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                              float* r, long ldr, const float* s0, const int* seq_env,
+                              const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
+                              int masked, float kappa, magpo_stream_t stream);
+int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                              const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
+                              long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
+                              int masked, float kappa, magpo_stream_t stream);
+int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                              long env_stride_rows, float* r, long ldr, int nenv, int ntok, float decay,
+                              magpo_stream_t stream);
+int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned char* done, int nenv,
+                                 magpo_stream_t stream);
+
+/* ---- K3/K8 GRU actor (base.py:121-184; flax GRUCell) ---- */
+int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
+                       const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
+                       magpo_stream_t stream);
+int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned char* reset, const float* dhs,
+                       const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
+                       magpo_stream_t stream);
+
+/* ---- K2 sampling, K5 GAE, K6 shuffle/layout, K9 losses (decode.py:128-149; multistep.py:24-68; rec_magpo.py:222-370,439-462) ---- */
+int magpo_sample_categorical(const float* logits, long ld, const unsigned char* mask, long mask_stride,
+                             uint32_t k0, uint32_t k1, int* action, long act_stride, float* logp,
+                             long logp_stride, int* next_idx, long next_stride, float* lp_all, long lp_ld, int N,
+                             int K, magpo_stream_t stream);
+int magpo_gae(const float* reward, const float* value, const unsigned char* done, const float* last_val,
+              const unsigned char* last_done, float* adv, float* targets, int T, int N, int A, float gamma,
+              float lam, magpo_stream_t stream);
+int magpo_gather_minibatch(const float* obs, const int* action, const int* stepcount, const unsigned char* done,
+                           const unsigned char* mask, const float* value, const float* logp, const float* adv,
+                           const float* targets, const int* env_idx, const int* agent_perm, float* o_obs,
+                           int* o_action, int* o_prev, int* o_pos, unsigned char* o_done, unsigned char* o_mask,
+                           float* o_value, float* o_logp, float* o_adv, float* o_targets, int* o_h0idx, int T,
+                           int N, int A, int F, int K, int mb, magpo_stream_t stream);
+int magpo_adv_moments(const float* x, long n, double* workspace, float* out, magpo_stream_t stream);
+int magpo_loss_fwd_bwd(const float* g_logits, long ldg, const float* a_logits, long lda, const unsigned char* mask,
+                       const int* action, const float* old_logp, const float* old_value, const float* value,
+                       const float* adv, const float* targets, const float* adv_stats, float* dg_logits,
+                       long lddg, float* da_logits, long lddda, float* dvalue, double* workspace, float* loss_out,
+                       long R, int K, float clip_eps, float clip_gpo, float ent_coef, float vf_coef, float alpha,
+                       magpo_stream_t stream);
+int magpo_copy_rows(const float* src, long lds_, float* dst, long ldd, long R, int W, magpo_stream_t stream);
+
+/* ---- K10 optimiser: optax clip_by_global_norm + adam(eps=1e-5) (rec_magpo.py:581-589, :412-420) ---- */
+int magpo_clip_adam(float* params, const float* grads, float* mu, float* nu, long n, float grad_scale,
+                    float max_norm, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                    double* workspace, float* gnorm, magpo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGPO_H */

@@ -1,0 +1,48 @@
+"""Build libmagpo_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(os.path.dirname(HERE), "build")
+OUT = os.path.join(HERE, "libmagpo_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+
+
+def _newer(src, dst):
+    return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp"))
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(BUILD, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
+            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(OUT):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

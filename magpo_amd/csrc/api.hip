@@ -1,0 +1,19 @@
+// Error plumbing shared by every C-ABI entry point (include/magpo.h).
+#include "common.hpp"
+#include <string>
+
+namespace magpo {
+static thread_local std::string g_last_error;
+void set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return MAGPO_ELAUNCH;
+  }
+  return MAGPO_OK;
+}
+}  // namespace magpo
+
+extern "C" const char* magpo_last_error() { return magpo::g_last_error.c_str(); }
+extern "C" int magpo_abi_version() { return 1; }

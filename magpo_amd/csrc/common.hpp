@@ -1,0 +1,90 @@
+// Shared device helpers for the MAGPO gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MAGPO_OK 0
+#define MAGPO_EINVAL (-1)
+#define MAGPO_ELAUNCH (-2)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace magpo {
+
+void set_error(const char* msg);
+int check_launch(const char* what);
+
+// Row pitch (floats) of a 64-column LDS tile: +4 keeps 16-B alignment and makes the
+// row-per-lane ds_read_b128 pattern conflict-free (bank = 4*row + c mod 64).
+constexpr int LDP = 4;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reduce over groups of 16 consecutive lanes
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+  // jax.nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float c = 0.7978845608028654f;
+  float u = c * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float c = 0.7978845608028654f;
+  float x2 = x * x;
+  float u = c * (x + 0.044715f * x * x2);
+  float t = tanhf(u);
+  float du = c * (1.0f + 3.0f * 0.044715f * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float swish_grad(float x) {
+  float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// ---- Threefry-2x32-20 (Random123), the JAX default PRNG block function ----------------------
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                                      uint32_t& o0, uint32_t& o1) {
+  const uint32_t ks0 = k0, ks1 = k1, ks2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  uint32_t x0 = c0 + ks0, x1 = c1 + ks1;
+#define TF_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)  x0 += ks1; x1 += ks2 + 1u;
+  TF_R(17) TF_R(29) TF_R(16) TF_R(24) x0 += ks2; x1 += ks0 + 2u;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)  x0 += ks0; x1 += ks1 + 3u;
+  TF_R(17) TF_R(29) TF_R(16) TF_R(24) x0 += ks1; x1 += ks2 + 4u;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)  x0 += ks2; x1 += ks0 + 5u;
+#undef TF_R
+  o0 = x0; o1 = x1;
+}
+// 32 random bits for flat element index idx (< 2^32) under key (k0,k1): x0 ^ x1.
+__host__ __device__ __forceinline__ uint32_t random_bits32(uint32_t k0, uint32_t k1, uint32_t idx) {
+  uint32_t a, b;
+  threefry2x32(k0, k1, 0u, idx, a, b);
+  return a ^ b;
+}
+// jax.random.gumbel (mode "low") from raw bits: -log(-log(max(tiny, u))), u = bitcast((b>>9)|0x3f800000)-1
+__device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
+  float f = __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f;
+  const float tiny = 1.17549435e-38f;
+  // floats * (1 - tiny) + tiny with (1 - tiny) == 1 in fp32, then max(tiny, .)
+  float u = fmaxf(tiny, f + tiny);
+  return -logf(-logf(u));
+}
+
+}  // namespace magpo

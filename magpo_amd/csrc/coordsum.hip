@@ -1,0 +1,190 @@
+// CoordSum environment + Mava wrapper stack as one HIP kernel per call (gfx950).
+//
+// Replaces, for a batch of envs, the reference's vmap(env.step) over
+//   RecordEpisodeMetrics (wrappers/episode_metrics.py:60-112) -> AutoResetWrapper
+//   (wrappers/auto_reset_wrapper.py:60-101) -> AgentIDWrapper (wrappers/observation.py:42-54)
+//   -> CoordSumWrapper (wrappers/matrax.py:117-142) -> CoordSum (coordsum/env.py:55-139).
+// Integer work, HBM-bound: one wave per env so the 4*T_lim-byte record row is read coalesced; the
+// per-action histogram is K wave ballots; JAX's clamped out-of-range gather / dynamic_update_slice
+// (record row min(target, K-1)) is reproduced explicitly.  Auto-reset branches per env
+// (the reference evaluates reset for every env every step under vmap(cond)).
+#include "common.hpp"
+
+namespace magpo {
+
+struct CoordSumState {
+  int* step_count;       // [N]
+  int* target;           // [N][TLIM+1]
+  int* record;           // [N][K][TLIM]
+  uint32_t* key;         // [N][2]   CoordSum State.key
+  uint32_t* metrics_key; // [N][2]   RecordEpisodeMetricsState.key (kept, never consumed)
+  float* run_ret; int* run_len; float* ep_ret; int* ep_len;  // [N] episode metric counters
+};
+struct CoordSumCfg { int N, A, K, TLIM, maxval; };
+
+// jax.random.randint(key, (n,), 0, span) element i (see oracle/prng.py:randint)
+__device__ __forceinline__ int randint_elem(uint32_t ka0, uint32_t ka1, uint32_t kb0, uint32_t kb1, uint32_t i, uint32_t span) {
+  const uint32_t hi = random_bits32(ka0, ka1, i), lo = random_bits32(kb0, kb1, i);
+  uint32_t mult = 65536u % span;
+  mult = (mult * mult) % span;
+  return (int)(((hi % span) * mult + (lo % span)) % span);
+}
+
+// CoordSum.reset for one env by one wave: fills target / record / step_count / key; returns target[0] on lane 0.
+__device__ __forceinline__ int core_reset(const CoordSumState& s, const CoordSumCfg& c, long n, uint32_t k0, uint32_t k1, int lane) {
+  uint32_t nk0, nk1, t0, t1;
+  threefry2x32(k0, k1, 0u, 0u, nk0, nk1);   // key
+  threefry2x32(k0, k1, 0u, 1u, t0, t1);     // target_key
+  uint32_t a0, a1, b0, b1;
+  threefry2x32(t0, t1, 0u, 0u, a0, a1);     // randint: k1, k2 = split(target_key)
+  threefry2x32(t0, t1, 0u, 1u, b0, b1);
+  const uint32_t span = c.maxval > 0 ? (uint32_t)c.maxval : 1u;
+  int first = 0;
+  for (int i = lane; i <= c.TLIM; i += 64) {
+    int v = randint_elem(a0, a1, b0, b1, (uint32_t)i, span);
+    s.target[n * (c.TLIM + 1) + i] = v;
+    if (i == 0) first = v;
+  }
+  int* rec = s.record + n * (long)c.K * c.TLIM;
+  for (int i = lane; i < c.K * c.TLIM; i += 64) rec[i] = -1;
+  if (lane == 0) {
+    s.step_count[n] = 0;
+    s.key[2 * n] = nk0;
+    s.key[2 * n + 1] = nk1;
+  }
+  return __shfl(first, 0, 64);
+}
+
+__device__ __forceinline__ void write_obs(float* __restrict__ obs, int* __restrict__ obs_step, long n, const CoordSumCfg& c,
+                                          int target_val, int step, int lane) {
+  const int F = c.A + 1;
+  float* o = obs + n * (long)c.A * F;
+  for (int i = lane; i < c.A * F; i += 64) {
+    int a = i / F, f = i - a * F;
+    o[i] = f < c.A ? (f == a ? 1.f : 0.f) : (float)target_val;
+  }
+  if (lane == 0) obs_step[n] = step;
+}
+
+__global__ __launch_bounds__(256) void k_coordsum_reset(CoordSumState s, CoordSumCfg c, const uint32_t* __restrict__ env_keys,
+                                                        float* __restrict__ obs, int* __restrict__ obs_step) {
+  const int lane = threadIdx.x & 63;
+  const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= c.N) return;
+  const uint32_t e0 = env_keys[2 * n], e1 = env_keys[2 * n + 1];
+  uint32_t m0, m1, r0, r1;
+  threefry2x32(e0, e1, 0u, 0u, m0, m1);  // key, reset_key = split(key)   (episode_metrics.py:62)
+  threefry2x32(e0, e1, 0u, 1u, r0, r1);
+  const int tv = core_reset(s, c, n, r0, r1, lane);
+  if (lane == 0) {
+    s.metrics_key[2 * n] = m0; s.metrics_key[2 * n + 1] = m1;
+    s.run_ret[n] = 0.f; s.run_len[n] = 0; s.ep_ret[n] = 0.f; s.ep_len[n] = 0;
+  }
+  write_obs(obs, obs_step, n, c, tv, 0, lane);
+}
+
+struct StepOut {
+  float* reward;          // [N][A]
+  unsigned char* done;    // [N]   timestep.last()
+  float* obs;             // [N][A][A+1]  next observation (reset obs after auto-reset)
+  int* obs_step;          // [N]          observation.step_count
+  float* m_ep_ret; int* m_ep_len; unsigned char* m_term;  // [N] extras["episode_metrics"]
+};
+
+__global__ __launch_bounds__(256) void k_coordsum_step(CoordSumState s, CoordSumCfg c, const int* __restrict__ actions,
+                                                       int act_stride, StepOut o, int auto_reset) {
+  const int lane = threadIdx.x & 63;
+  const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= c.N) return;
+  const int t = s.step_count[n];
+  const int* tgt = s.target + n * (c.TLIM + 1);
+  const int g = tgt[min(t, c.TLIM)];
+  int av = 0;
+  for (int a = lane; a < c.A; a += 64) av += actions[n * act_stride + a];
+  const int asum = (int)wave_sum((float)av);  // exact: |sum| < 2^24
+  const int a0 = actions[n * act_stride];
+  const int row = min(g, c.K - 1);
+  int* rec = s.record + (n * c.K + row) * (long)c.TLIM;
+  // histogram of the valid entries of the row: lane b owns bin b
+  int cnt = 0;
+  for (int base = 0; base < c.TLIM; base += 64) {
+    const int i = base + lane;
+    const int v = i < c.TLIM ? rec[i] : -1;
+    for (int b = 0; b < c.K; ++b) {
+      const unsigned long long m = __ballot(v == b);
+      if (lane == b) cnt += __popcll(m);
+    }
+  }
+  // argmax with first-max tie-break (bins >= K are empty; an empty row gives guess 0)
+  int keyv = lane < c.K ? cnt * 64 + (63 - lane) : -1;
+  for (int off = 32; off > 0; off >>= 1) keyv = max(keyv, __shfl_xor(keyv, off, 64));
+  const int guess = 63 - (keyv & 63);
+  const bool sum_match = asum == g;
+  const float reward = sum_match ? (guess == a0 ? 1.0f : 2.0f) : 0.0f;
+  if (lane == 0) rec[min(t, c.TLIM - 1)] = a0;
+  const int steps = t + 1;
+  const bool done = steps >= c.TLIM;
+  int obs_target = tgt[min(steps, c.TLIM)];
+  int obs_step = steps;
+  if (lane == 0) s.step_count[n] = steps;
+  if (done && auto_reset) {
+    uint32_t k0 = s.key[2 * n], k1 = s.key[2 * n + 1], nk0, nk1;
+    threefry2x32(k0, k1, 0u, 0u, nk0, nk1);  // key, _ = split(state.key)   (auto_reset_wrapper.py:74)
+    obs_target = core_reset(s, c, n, nk0, nk1, lane);
+    obs_step = 0;
+  }
+  for (int a = lane; a < c.A; a += 64) o.reward[n * c.A + a] = reward;
+  write_obs(o.obs, o.obs_step, n, c, obs_target, obs_step, lane);
+  if (lane == 0) {
+    o.done[n] = done ? 1 : 0;
+    // episode_metrics.py:79-112 (mean over agents of identical rewards == reward)
+    const float new_ret = s.run_ret[n] + reward;
+    const int new_len = s.run_len[n] + 1;
+    const float ep_ret = done ? new_ret : s.ep_ret[n];
+    const int ep_len = done ? new_len : s.ep_len[n];
+    s.run_ret[n] = done ? 0.f : new_ret;
+    s.run_len[n] = done ? 0 : new_len;
+    s.ep_ret[n] = ep_ret;
+    s.ep_len[n] = ep_len;
+    o.m_ep_ret[n] = ep_ret;
+    o.m_ep_len[n] = ep_len;
+    o.m_term[n] = done ? 1 : 0;
+  }
+}
+
+}  // namespace magpo
+
+using namespace magpo;
+
+static int check_cfg(int N, int A, int K, int TLIM) {
+  if (N < 0 || A < 1 || K < 1 || K > 64 || TLIM < 1 || K > TLIM) {
+    set_error("coordsum: need A >= 1, 1 <= K <= 64, K <= time_limit");
+    return MAGPO_EINVAL;
+  }
+  return MAGPO_OK;
+}
+
+extern "C" int magpo_coordsum_reset(int* step_count, int* target, int* record, uint32_t* key, uint32_t* metrics_key,
+                                    float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A, int K, int TLIM,
+                                    int maxval, const uint32_t* env_keys, float* obs, int* obs_step, hipStream_t st) {
+  if (int e = check_cfg(N, A, K, TLIM)) return e;
+  if (N == 0) return MAGPO_OK;
+  CoordSumState s{step_count, target, record, key, metrics_key, run_ret, run_len, ep_ret, ep_len};
+  CoordSumCfg c{N, A, K, TLIM, maxval};
+  hipLaunchKernelGGL(k_coordsum_reset, dim3((N + 3) / 4), dim3(256), 0, st, s, c, env_keys, obs, obs_step);
+  return check_launch("magpo_coordsum_reset");
+}
+
+extern "C" int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key, uint32_t* metrics_key,
+                                   float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A, int K, int TLIM,
+                                   int maxval, const int* actions, int act_stride, float* reward, unsigned char* done,
+                                   float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
+                                   int auto_reset, hipStream_t st) {
+  if (int e = check_cfg(N, A, K, TLIM)) return e;
+  if (N == 0) return MAGPO_OK;
+  CoordSumState s{step_count, target, record, key, metrics_key, run_ret, run_len, ep_ret, ep_len};
+  CoordSumCfg c{N, A, K, TLIM, maxval};
+  StepOut o{reward, done, obs, obs_step, m_ep_ret, m_ep_len, m_term};
+  hipLaunchKernelGGL(k_coordsum_step, dim3((N + 3) / 4), dim3(256), 0, st, s, c, actions, act_stride, o, auto_reset);
+  return check_launch("magpo_coordsum_step");
+}

@@ -1,0 +1,241 @@
+// Row-batched dense layers on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+//   k_linear<KIN> : Y[R,NOUT] = act(X[R,KIN] @ W + b), W given transposed ("Wt[NOUT_pad][KIN]").
+//                   The same kernel computes dX = dY @ W^T by passing W in its natural [in][out]
+//                   layout as "Wt" (replaces XLA's dot_general for flax nn.Dense and the Sable
+//                   projections: sable_network.py:93-109,258-284, retention.py:73-75,294, base.py:175-181).
+//   k_wgrad<NB>   : dW[KIN,NOUT] partial sums = X^T dY per workgroup slab (+ column sums of dY for
+//                   the bias), reduced in fixed order by k_reduce_slabs (bit-stable reruns).
+//
+// Tile: 64 rows per workgroup (4 waves as 2x2 quadrants of 32x32 accumulators).  X rows are staged
+// once in LDS ([64][KIN+4] floats, ds_read_b128 per lane conflict-free); B fragments come
+// straight from L2 into VGPRs (each lane owns one output column and 32 contiguous k's).
+#include "common.hpp"
+
+namespace magpo {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SWISH = 3 };
+
+template <int KIN>
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int ldx,
+                                                const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                float* __restrict__ Y, int ldy, float* __restrict__ Ypre,
+                                                int R, int NOUT, int act) {
+  constexpr int LD = KIN + LDP;
+  extern __shared__ __align__(16) float xs[];  // [64][LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, h = lane >> 5;
+  const long row0 = (long)blockIdx.x * 64;
+
+  // stage X tile
+  constexpr int F4 = KIN / 4;
+  for (int i = tid; i < 64 * F4; i += 256) {
+    int r = i / F4, c4 = i - r * F4;
+    long gr = row0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gr < R) v = *reinterpret_cast<const float4*>(X + gr * (long)ldx + 4 * c4);
+    *reinterpret_cast<float4*>(&xs[r * LD + 4 * c4]) = v;
+  }
+  __syncthreads();
+
+  const float* arow = &xs[(32 * wr + lr) * LD + 32 * h];
+  const int nblk = (NOUT + 63) >> 6;
+  for (int nb = 0; nb < nblk; ++nb) {
+    const int n = nb * 64 + 32 * wc + lr;
+    if (nb * 64 + 32 * wc >= NOUT) continue;  // wave-uniform
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* wrow = Wt + (long)n * KIN + 32 * h;  // Wt is padded to a multiple of 32 rows
+#pragma unroll 1
+    for (int kc = 0; kc < KIN / 64; ++kc) {
+      float4 b[8], a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const float4*>(wrow + kc * 64 + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4*>(arow + kc * 64 + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+      }
+    }
+    if (n < NOUT) {
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        long gr = row0 + 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (gr < R) {
+          float v = acc[i] + bv;
+          if (Ypre) Ypre[gr * (long)ldy + n] = v;
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_GELU) v = gelu_tanh(v);
+          else if (act == ACT_SWISH) v = swishf_(v);
+          Y[gr * (long)ldy + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// dW slab: grid (G, ceil(NOUT / (64 NB)), KIN / 64)
+template <int NB>
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
+                                               int R, int KIN, int NOUT, float* __restrict__ slab,
+                                               float* __restrict__ bias_slab) {
+  constexpr int LDX = 64 + LDP, LDY = 64 * NB + LDP;
+  __shared__ __align__(16) float xs[64 * LDX];
+  __shared__ __align__(16) float ys[64 * LDY];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, h = lane >> 5;
+  const int g = blockIdx.x, G = gridDim.x;
+  const int c0 = blockIdx.y * 64 * NB, kb = blockIdx.z;
+  const int ntiles = (R + 63) >> 6;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = bias_slab != nullptr && kb == 0;
+
+  for (int tile = g; tile < ntiles; tile += G) {
+    const long row0 = (long)tile * 64;
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      int r = i >> 4, c4 = i & 15;
+      long gr = row0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < R) v = *reinterpret_cast<const float4*>(X + gr * (long)ldx + kb * 64 + 4 * c4);
+      *reinterpret_cast<float4*>(&xs[r * LDX + 4 * c4]) = v;
+    }
+    for (int i = tid; i < 64 * 16 * NB; i += 256) {
+      int r = i / (16 * NB), c4 = i - r * (16 * NB);
+      long gr = row0 + r;
+      int col = c0 + 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < R) {
+        const float* p = dY + gr * (long)ldy + col;
+        if (col + 3 < NOUT) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (col + 0 < NOUT) v.x = p[0];
+          if (col + 1 < NOUT) v.y = p[1];
+          if (col + 2 < NOUT) v.z = p[2];
+        }
+      }
+      *reinterpret_cast<float4*>(&ys[r * LDY + 4 * c4]) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {
+      const int tok = 32 * h + s;
+      const float a = xs[tok * LDX + 32 * wr + lr];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float bb = ys[tok * LDY + 64 * b + 32 * wc + lr];
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[b], 0, 0, 0);
+      }
+    }
+    if (do_bias && tid < 64 * NB) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) s += ys[r * LDY + tid];
+      bsum += s;
+    }
+  }
+  float* out = slab + (long)g * KIN * NOUT;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int n = c0 + 64 * b + 32 * wc + lr;
+    if (n < NOUT) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int kr = kb * 64 + 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        out[(long)kr * NOUT + n] = acc[b][i];
+      }
+    }
+  }
+  if (do_bias && tid < 64 * NB && c0 + tid < NOUT) bias_slab[(long)g * NOUT + c0 + tid] = bsum;
+}
+
+// out[p] = scale * sum_g slab[g][p]  (fixed order => bit-stable)
+__global__ void k_reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, int G, long P, long stride,
+                               float scale, int accumulate) {
+  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += slab[(long)g * stride + p];
+  s *= scale;
+  out[p] = accumulate ? out[p] + s : s;
+}
+
+// Wt[Npad][K] = W[K][N]^T, rows N..Npad-1 zero.
+__global__ void k_transpose_pad(const float* __restrict__ W, float* __restrict__ Wt, int K, int N, int Npad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad * K) return;
+  int n = i / K, k = i - n * K;
+  Wt[i] = n < N ? W[(long)k * N + n] : 0.f;
+}
+
+}  // namespace magpo
+
+using namespace magpo;
+
+extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const float* bias, float* Y, int ldy, float* Ypre,
+                            long R, int KIN, int NOUT, int act, hipStream_t stream) {
+  if (R <= 0) return MAGPO_OK;
+  if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
+  dim3 grid((unsigned)((R + 63) / 64)), block(256);
+  size_t lds = (size_t)64 * (KIN + LDP) * sizeof(float);
+#define LAUNCH(K_)                                                                                              \
+  if (lds > 65536) {                                                                                            \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear<K_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+  }                                                                                                             \
+  hipLaunchKernelGGL(k_linear<K_>, grid, block, lds, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act)
+  switch (KIN) {
+    case 64: LAUNCH(64); break;
+    case 128: LAUNCH(128); break;
+    case 192: LAUNCH(192); break;
+    case 256: LAUNCH(256); break;
+    case 384: LAUNCH(384); break;
+    default: set_error("magpo_linear: unsupported KIN"); return MAGPO_EINVAL;
+  }
+#undef LAUNCH
+  return check_launch("magpo_linear");
+}
+
+extern "C" long magpo_wgrad_workspace_floats(int KIN, int NOUT, int G) { return (long)G * ((long)KIN * NOUT + NOUT); }
+
+// dW[KIN][NOUT] (+ optional db[NOUT]) = scale * X^T dY ; workspace >= magpo_wgrad_workspace_floats floats.
+// Only the first `krows` rows of dW are written (krows < KIN for zero-padded small operands).
+extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, long R, int KIN, int krows, int NOUT, float* dW,
+                           float* db, float* workspace, int G, float scale, int accumulate, hipStream_t stream) {
+  if ((ldx & 3) || (ldy & 3) || KIN % 64) { set_error("magpo_wgrad: bad strides / KIN"); return MAGPO_EINVAL; }
+  float* slab = workspace;
+  float* bslab = db ? workspace + (long)G * KIN * NOUT : nullptr;
+  int nb = NOUT >= 128 ? 2 : 1;
+  dim3 grid(G, (NOUT + 64 * nb - 1) / (64 * nb), KIN / 64), block(256);
+  if (nb == 2) hipLaunchKernelGGL(k_wgrad<2>, grid, block, 0, stream, X, ldx, dY, ldy, (int)R, KIN, NOUT, slab, bslab);
+  else hipLaunchKernelGGL(k_wgrad<1>, grid, block, 0, stream, X, ldx, dY, ldy, (int)R, KIN, NOUT, slab, bslab);
+  long P = (long)krows * NOUT;
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
+  if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 255) / 256), dim3(256), 0, stream, bslab, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
+  return check_launch("magpo_wgrad");
+}
+
+extern "C" int magpo_reduce_slabs(const float* slab, float* out, int G, long P, long stride, float scale, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, slab, out, G, P, stride, scale, accumulate);
+  return check_launch("magpo_reduce_slabs");
+}
+
+extern "C" int magpo_transpose_pad(const float* W, float* Wt, int K, int N, int Npad, hipStream_t stream) {
+  int total = Npad * K;
+  hipLaunchKernelGGL(k_transpose_pad, dim3((total + 255) / 256), dim3(256), 0, stream, W, Wt, K, N, Npad);
+  return check_launch("magpo_transpose_pad");
+}

@@ -1,0 +1,449 @@
+// Sable retention on fp32 MFMA for gfx950.
+//
+// Reference semantics: SimpleRetention (mava/networks/retention.py:66-115): chunkwise
+//   ret = ((Q K^T) * D) V + (Q S0) * xi     with the done-aware decay matrix D (:117-187) and xi (:189-213),
+// recurrent  S <- S + k^T v ; ret = q S  with  S <- kappa S  applied once per timestep by the caller
+// (sable_network.py:457) and S <- 0 at episode ends (rec_magpo.py:164-169).
+//
+// Both forms are the same linear recurrence  S_t = d_t S_{t-1} + sum_a k_{t,a}^T v_{t,a},
+// d_t = kappa * (1 - done_t).  The reference evaluates one C x C chunk (C = T*A tokens); this kernel
+// evaluates the identical sum chunk by chunk (64-token tiles) carrying the 64x64 state on chip, which
+// needs 2.5x fewer FLOPs than the causal half of the C x C form and never materialises D:
+//   intra-chunk  P = (Q K^T) * w ,  w(i,j) = kappa^(t_i - t_j) [same episode segment] [causal]
+//   inter-chunk  O += beta_i (q_i S_c) ,  S_{c+1} = gamma_c S_c + sum_j eta_j k_j^T v_j
+// One workgroup (4 waves, 2x2 quadrants of 32x32 accumulators) per sequence.  LDS tiles are
+// [64][68] floats: row-per-lane operands are read with ds_read_b128, column-per-lane with ds_read_b32.
+#include "common.hpp"
+
+namespace magpo {
+
+constexpr int TL = 64 + LDP;  // tile pitch
+
+struct ChunkMeta {      // per-chunk decay bookkeeping in LDS
+  float kpow[66];       // kappa^p
+  int cnt[64];          // per token: # dones among chunk timesteps [0..lt]
+  int lt[64];           // per token: chunk-local timestep (invalid tokens: -1)
+  float beta[64];       // incoming-state weight per token
+  float eta[64];        // outgoing-state weight per token
+  float gamma;          // state carry factor
+};
+
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, long ld, int nvalid) {
+  // 64 rows x 64 floats, rows >= nvalid zero-filled
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+    int r = i >> 4, c4 = i & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
+    *reinterpret_cast<float4*>(&dst[r * TL + 4 * c4]) = v;
+  }
+}
+__device__ __forceinline__ void load_state(float* __restrict__ dst, const float* __restrict__ src) {
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+    int r = i >> 4, c4 = i & 15;
+    float4 v = src ? *reinterpret_cast<const float4*>(src + r * 64 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&dst[r * TL + 4 * c4]) = v;
+  }
+}
+__device__ __forceinline__ void store_state(float* __restrict__ dst, const float* __restrict__ src) {
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+    int r = i >> 4, c4 = i & 15;
+    *reinterpret_cast<float4*>(dst + r * 64 + 4 * c4) = *reinterpret_cast<const float4*>(&src[r * TL + 4 * c4]);
+  }
+}
+
+// fragment of 32 k-values for a row-per-lane operand: T[row][32h .. 32h+31]
+struct Frag { float4 v[8]; };
+__device__ __forceinline__ Frag load_rowfrag(const float* __restrict__ tile, int row, int h) {
+  Frag f;
+  const float* p = tile + row * TL + 32 * h;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) f.v[u] = *reinterpret_cast<const float4*>(p + 4 * u);
+  return f;
+}
+__device__ __forceinline__ float frag_at(const Frag& f, int s) {
+  const float4& q = f.v[s >> 2];
+  return (s & 3) == 0 ? q.x : ((s & 3) == 1 ? q.y : ((s & 3) == 2 ? q.z : q.w));
+}
+
+// acc += A B with A row-per-lane frag, B row-per-lane frag (B[k][n] = Tb[n][k])
+__device__ __forceinline__ void mma_rr(f32x16& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].x, b.v[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].y, b.v[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].z, b.v[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].w, b.v[u].w, acc, 0, 0, 0);
+  }
+}
+// acc += A B with A row-per-lane frag, B column-per-lane from tile Tb[k][col]
+__device__ __forceinline__ void mma_rc(f32x16& acc, const Frag& a, const float* __restrict__ tb, int col, int h) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float* p = tb + (32 * h + 4 * u) * TL + col;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].x, p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].y, p[TL], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].z, p[2 * TL], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u].w, p[3 * TL], acc, 0, 0, 0);
+  }
+}
+// acc += A^T B: A[i][kk] = Ta[kk][arow_col] * scale[kk] (scale optional), B[kk][n] = Tb[kk][col]
+__device__ __forceinline__ void mma_cc(f32x16& acc, const float* __restrict__ ta, int acol, const float* __restrict__ tb,
+                                       int bcol, int h, const float* __restrict__ scale) {
+#pragma unroll 8
+  for (int s = 0; s < 32; ++s) {
+    const int kk = 32 * h + s;
+    float a = ta[kk * TL + acol];
+    if (scale) a *= scale[kk];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, tb[kk * TL + bcol], acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void acc_zero(f32x16& a) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = 0.f;
+}
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// Build the per-chunk metadata.  dones: this sequence's per-timestep flags; t0 first timestep of
+// the chunk; ltc number of valid timesteps; A agents.
+__device__ __forceinline__ void build_meta(ChunkMeta& m, const unsigned char* __restrict__ dones, int t0, int ltc, int A,
+                                           float kappa) {
+  const int tid = threadIdx.x;
+  if (tid < 66) m.kpow[tid] = powf(kappa, (float)tid);
+  if (tid < 64) {
+    int lt = tid / A;
+    if (lt < ltc) {
+      int c = 0;
+      for (int s = 0; s <= lt; ++s) c += dones[t0 + s] ? 1 : 0;
+      m.lt[tid] = lt;
+      m.cnt[tid] = c;
+    } else {
+      m.lt[tid] = -1;
+      m.cnt[tid] = -1;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int lt = m.lt[tid];
+    int ctot = m.cnt[(ltc - 1) * A];
+    float b = 0.f, e = 0.f;
+    if (lt >= 0) {
+      b = (m.cnt[tid] == 0) ? m.kpow[lt + 1] : 0.f;
+      e = (m.cnt[tid] == ctot) ? m.kpow[ltc - 1 - lt] : 0.f;
+    }
+    m.beta[tid] = b;
+    m.eta[tid] = e;
+    if (tid == 0) m.gamma = (ctot == 0) ? m.kpow[ltc] : 0.f;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float decay_w(const ChunkMeta& m, int i, int j, int masked) {
+  const int li = m.lt[i], lj = m.lt[j];
+  if (li < 0 || lj < 0 || li < lj || m.cnt[i] != m.cnt[j]) return 0.f;
+  if (masked && j > i) return 0.f;
+  return m.kpow[li - lj];
+}
+
+struct RetArgs {
+  const float* q; const float* k; const float* v; long ldq, ldk, ldv;   // row strides (floats)
+  float* r; long ldr;
+  const float* s0;            // [*][64][64] initial states, indexed by seq_env (or seq)
+  const int* seq_env;         // nullable
+  const unsigned char* dones; // [nseq][T]
+  float* states;              // [nseq][nch][64][64] chunk-entry states (nullable in fwd)
+  float* s_final;             // [nseq][64][64] state after the last chunk (nullable)
+  int T, A, masked; float kappa;
+};
+
+__global__ __launch_bounds__(256) void k_ret_chunk_fwd(RetArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* Qs = smem;             // later P
+  float* Ks = Qs + 64 * TL;
+  float* Vs = Ks + 64 * TL;
+  float* Ss = Vs + 64 * TL;
+  ChunkMeta& meta = *reinterpret_cast<ChunkMeta*>(Ss + 64 * TL);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, h = lane >> 5;
+  const int seq = blockIdx.x;
+  const int Lt = 64 / a.A, L = Lt * a.A;
+  const int nch = (a.T + Lt - 1) / Lt;
+  const long row_base = (long)seq * a.T * a.A;
+  const float* s0 = a.s0 ? a.s0 + (long)(a.seq_env ? a.seq_env[seq] : seq) * 4096 : nullptr;
+  load_state(Ss, s0);
+  for (int c = 0; c < nch; ++c) {
+    const int t0 = c * Lt;
+    const int ltc = min(Lt, a.T - t0);
+    const int nvalid = ltc * a.A;
+    const long r0 = row_base + (long)c * L;
+    __syncthreads();  // previous chunk finished with Qs/Ks/Vs, Ss updated
+    load_tile(Qs, a.q + r0 * a.ldq, a.ldq, nvalid);
+    load_tile(Ks, a.k + r0 * a.ldk, a.ldk, nvalid);
+    load_tile(Vs, a.v + r0 * a.ldv, a.ldv, nvalid);
+    build_meta(meta, a.dones + (long)seq * a.T, t0, ltc, a.A, a.kappa);  // contains __syncthreads
+    if (a.states) store_state(a.states + ((long)seq * nch + c) * 4096, Ss);
+
+    f32x16 sc, o;
+    acc_zero(sc);
+    acc_zero(o);
+    {
+      Frag qa = load_rowfrag(Qs, 32 * wr + lr, h);
+      Frag kb = load_rowfrag(Ks, 32 * wc + lr, h);
+      mma_rr(sc, qa, kb);                      // Q K^T
+      mma_rc(o, qa, Ss, 32 * wc + lr, h);      // Q S
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ri = 32 * wr + acc_row(i, h);
+      o[i] *= meta.beta[ri];
+      sc[i] *= decay_w(meta, ri, 32 * wc + lr, a.masked);
+    }
+    __syncthreads();  // everyone done reading Qs
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Qs[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr] = sc[i];
+    __syncthreads();
+    {
+      Frag pa = load_rowfrag(Qs, 32 * wr + lr, h);
+      mma_rc(o, pa, Vs, 32 * wc + lr, h);      // P V
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ri = 32 * wr + acc_row(i, h);
+      if (ri < nvalid) a.r[(r0 + ri) * a.ldr + 32 * wc + lr] = o[i];
+    }
+    // state update  S <- gamma S + (eta K)^T V
+    f32x16 sn;
+    const float gm = meta.gamma;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sn[i] = gm * Ss[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr];
+    mma_cc(sn, Ks, 32 * wr + lr, Vs, 32 * wc + lr, h, meta.eta);
+    __syncthreads();  // all reads of Ss done
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ss[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr] = sn[i];
+  }
+  if (a.s_final) {
+    __syncthreads();
+    store_state(a.s_final + (long)seq * 4096, Ss);
+  }
+}
+
+struct RetBwdArgs {
+  const float* q; const float* k; const float* v; long ldq, ldk, ldv;
+  const float* dr; long lddr;
+  float* dq; float* dk; float* dv; long lddq, lddk, lddv;
+  const unsigned char* dones;
+  const float* states;  // [nseq][nch][64][64] from the forward
+  int T, A, masked; float kappa;
+};
+
+__global__ __launch_bounds__(256) void k_ret_chunk_bwd(RetBwdArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* Qs = smem;
+  float* Ks = Qs + 64 * TL;
+  float* Vs = Ks + 64 * TL;
+  float* Ds = Vs + 64 * TL;   // dO
+  float* Ss = Ds + 64 * TL;   // chunk-entry state S_c
+  float* Gs = Ss + 64 * TL;   // dL/dS_{c+1}
+  float* Ps = Gs + 64 * TL;
+  float* dPs = Ps + 64 * TL;
+  ChunkMeta& meta = *reinterpret_cast<ChunkMeta*>(dPs + 64 * TL);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, h = lane >> 5;
+  const int seq = blockIdx.x;
+  const int Lt = 64 / a.A, L = Lt * a.A;
+  const int nch = (a.T + Lt - 1) / Lt;
+  const long row_base = (long)seq * a.T * a.A;
+  load_state(Gs, nullptr);
+  for (int c = nch - 1; c >= 0; --c) {
+    const int t0 = c * Lt;
+    const int ltc = min(Lt, a.T - t0);
+    const int nvalid = ltc * a.A;
+    const long r0 = row_base + (long)c * L;
+    __syncthreads();
+    load_tile(Qs, a.q + r0 * a.ldq, a.ldq, nvalid);
+    load_tile(Ks, a.k + r0 * a.ldk, a.ldk, nvalid);
+    load_tile(Vs, a.v + r0 * a.ldv, a.ldv, nvalid);
+    load_tile(Ds, a.dr + r0 * a.lddr, a.lddr, nvalid);
+    load_state(Ss, a.states + ((long)seq * nch + c) * 4096);
+    build_meta(meta, a.dones + (long)seq * a.T, t0, ltc, a.A, a.kappa);
+
+    // P = (Q K^T) * w ; dP = (dO V^T) * w
+    Frag doa = load_rowfrag(Ds, 32 * wr + lr, h);
+    {
+      f32x16 p, dp;
+      acc_zero(p);
+      acc_zero(dp);
+      Frag qa = load_rowfrag(Qs, 32 * wr + lr, h);
+      Frag kb = load_rowfrag(Ks, 32 * wc + lr, h);
+      mma_rr(p, qa, kb);
+      Frag vb = load_rowfrag(Vs, 32 * wc + lr, h);
+      mma_rr(dp, doa, vb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ri = 32 * wr + acc_row(i, h);
+        const float w = decay_w(meta, ri, 32 * wc + lr, a.masked);
+        Ps[ri * TL + 32 * wc + lr] = p[i] * w;
+        dPs[ri * TL + 32 * wc + lr] = dp[i] * w;
+      }
+    }
+    __syncthreads();
+    // dQ = dP K + beta * (dO S_c^T)
+    {
+      f32x16 acc1, acc2;
+      acc_zero(acc1);
+      acc_zero(acc2);
+      Frag dpa = load_rowfrag(dPs, 32 * wr + lr, h);
+      mma_rc(acc1, dpa, Ks, 32 * wc + lr, h);
+      Frag sb = load_rowfrag(Ss, 32 * wc + lr, h);
+      mma_rr(acc2, doa, sb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ri = 32 * wr + acc_row(i, h);
+        if (ri < nvalid) a.dq[(r0 + ri) * a.lddq + 32 * wc + lr] = acc1[i] + meta.beta[ri] * acc2[i];
+      }
+    }
+    // dK = dP^T Q + eta * (V G^T)
+    {
+      f32x16 acc1, acc2;
+      acc_zero(acc1);
+      acc_zero(acc2);
+      mma_cc(acc1, dPs, 32 * wr + lr, Qs, 32 * wc + lr, h, nullptr);
+      Frag va = load_rowfrag(Vs, 32 * wr + lr, h);
+      Frag gb = load_rowfrag(Gs, 32 * wc + lr, h);
+      mma_rr(acc2, va, gb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ri = 32 * wr + acc_row(i, h);
+        if (ri < nvalid) a.dk[(r0 + ri) * a.lddk + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
+      }
+    }
+    // dV = P^T dO + eta * (K G)
+    {
+      f32x16 acc1, acc2;
+      acc_zero(acc1);
+      acc_zero(acc2);
+      mma_cc(acc1, Ps, 32 * wr + lr, Ds, 32 * wc + lr, h, nullptr);
+      Frag ka = load_rowfrag(Ks, 32 * wr + lr, h);
+      mma_rc(acc2, ka, Gs, 32 * wc + lr, h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ri = 32 * wr + acc_row(i, h);
+        if (ri < nvalid) a.dv[(r0 + ri) * a.lddv + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
+      }
+    }
+    // G <- gamma G + (beta Q)^T dO
+    {
+      f32x16 gn;
+      const float gm = meta.gamma;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gn[i] = gm * Gs[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr];
+      mma_cc(gn, Qs, 32 * wr + lr, Ds, 32 * wc + lr, h, meta.beta);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Gs[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr] = gn[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Recurrent form for acting (retention.py:102-115): one workgroup per env.
+//   S <- decay * S + sum_{a<ntok} k_a^T v_a ;  ret_a = q_a S        (all ntok tokens see the full update)
+__global__ __launch_bounds__(256) void k_ret_recurrent(float* __restrict__ S, const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, long ldq, long ldk, long ldv, long env_stride_rows,
+                                                       float* __restrict__ r, long ldr, int ntok, float decay) {
+  __shared__ float qs[16][64], ks[16][64], vs[16][64];
+  __shared__ float part[4][16][64];
+  const int tid = threadIdx.x, j = tid & 63, rg = tid >> 6;
+  const long env = blockIdx.x;
+  const long row0 = env * env_stride_rows;
+  for (int i = tid; i < ntok * 64; i += 256) {
+    int a = i >> 6, c = i & 63;
+    qs[a][c] = q[(row0 + a) * ldq + c];
+    ks[a][c] = k[(row0 + a) * ldk + c];
+    vs[a][c] = v[(row0 + a) * ldv + c];
+  }
+  __syncthreads();
+  float* Se = S + env * 4096;
+  float s[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float x = decay * Se[(16 * rg + i) * 64 + j];
+    for (int a = 0; a < ntok; ++a) x += ks[a][16 * rg + i] * vs[a][j];
+    s[i] = x;
+    Se[(16 * rg + i) * 64 + j] = x;
+  }
+  for (int a = 0; a < ntok; ++a) {
+    float p = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p += qs[a][16 * rg + i] * s[i];
+    part[rg][a][j] = p;
+  }
+  __syncthreads();
+  for (int i = tid; i < ntok * 64; i += 256) {
+    int a = i >> 6, c = i & 63;
+    r[(row0 + a) * ldr + c] = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
+  }
+}
+
+// zero the three retention states of envs whose episode just ended (rec_magpo.py:164-169)
+__global__ void k_zero_states(float* __restrict__ s0, float* __restrict__ s1, float* __restrict__ s2,
+                              const unsigned char* __restrict__ done) {
+  if (!done[blockIdx.x]) return;
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+    reinterpret_cast<float4*>(s0 + (long)blockIdx.x * 4096)[i] = z;
+    reinterpret_cast<float4*>(s1 + (long)blockIdx.x * 4096)[i] = z;
+    reinterpret_cast<float4*>(s2 + (long)blockIdx.x * 4096)[i] = z;
+  }
+}
+
+}  // namespace magpo
+
+using namespace magpo;
+
+static int check_ret_shape(int T, int A, long ldq, long ldk, long ldv) {
+  if (A < 1 || A > 64 || T < 1) { set_error("retention: need 1 <= A <= 64, T >= 1"); return MAGPO_EINVAL; }
+  if ((ldq & 3) || (ldk & 3) || (ldv & 3)) { set_error("retention: row strides must be multiples of 4 floats"); return MAGPO_EINVAL; }
+  return MAGPO_OK;
+}
+
+extern "C" int magpo_retention_num_chunks(int T, int A) { int Lt = 64 / A; return (T + Lt - 1) / Lt; }
+
+extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                         float* r, long ldr, const float* s0, const int* seq_env,
+                                         const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
+                                         int masked, float kappa, hipStream_t st) {
+  if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
+  RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa};
+  size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(ChunkMeta);
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(k_ret_chunk_fwd, dim3(nseq), dim3(256), lds, st, a);
+  return check_launch("magpo_retention_chunk_fwd");
+}
+
+extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                         const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
+                                         long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
+                                         int masked, float kappa, hipStream_t st) {
+  if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
+  RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa};
+  size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(ChunkMeta);
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(k_ret_chunk_bwd, dim3(nseq), dim3(256), lds, st, a);
+  return check_launch("magpo_retention_chunk_bwd");
+}
+
+extern "C" int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                         long env_stride_rows, float* r, long ldr, int nenv, int ntok, float decay,
+                                         hipStream_t st) {
+  if (ntok < 1 || ntok > 16) { set_error("retention_recurrent: 1 <= ntok <= 16"); return MAGPO_EINVAL; }
+  hipLaunchKernelGGL(k_ret_recurrent, dim3(nenv), dim3(256), 0, st, S, q, k, v, ldq, ldk, ldv, env_stride_rows, r, ldr, ntok, decay);
+  return check_launch("magpo_retention_recurrent");
+}
+
+extern "C" int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned char* done, int nenv,
+                                            hipStream_t st) {
+  hipLaunchKernelGGL(k_zero_states, dim3(nenv), dim3(256), 0, st, s0, s1, s2, done);
+  return check_launch("magpo_zero_states_where_done");
+}

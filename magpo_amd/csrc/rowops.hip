@@ -1,0 +1,509 @@
+// Row-wise (token-local) pieces of the Sable guider between the dense layers and the retention
+// kernels: embeddings, RMSNorm / GroupNorm, GELU / swish gates, residual adds, positional encoding,
+// forward and hand-derived backward.  HBM-bound: 16 lanes x float4 per 64-wide row (4 rows per
+// wave-instruction, 1 KiB coalesced), row statistics by 16-lane xor-shuffles, parameter gradients
+// accumulated per lane and written as per-workgroup slabs (reduced in fixed order afterwards).
+//
+// Reference maths: sable_network.py:62-71,93-109,121-137,188-217,255-284,296-319 (blocks, heads),
+// retention.py:289-295 (GroupNorm + swish gate), positional_encoding.py:24-60, torsos.py:79-99
+// (SwiGLU is identically zero at its zero init and is not evaluated; the host verifies that).
+#include "common.hpp"
+
+namespace magpo {
+
+constexpr float NORM_EPS = 1e-6f;
+constexpr int ROWS_PER_BLOCK = 16;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// mean over a 64-wide row held as float4 by 16 consecutive lanes
+__device__ __forceinline__ float rowmean64(float4 v) { return sum16(f4sum(v)) * (1.0f / 64.0f); }
+
+struct RmsFwd { float4 y; float4 xhat; float rstd; };
+__device__ __forceinline__ RmsFwd rms_fwd(float4 x, float4 s) {
+  RmsFwd o;
+  o.rstd = rsqrtf(rowmean64(f4mul(x, x)) + NORM_EPS);
+  o.xhat = f4scale(x, o.rstd);
+  o.y = f4mul(o.xhat, s);
+  return o;
+}
+// returns dx; accumulates ds
+__device__ __forceinline__ float4 rms_bwd(float4 dy, const RmsFwd& f, float4 s, float4& ds) {
+  float4 g = f4mul(dy, s);
+  float dot = rowmean64(f4mul(g, f.xhat));
+  ds = f4add(ds, f4mul(dy, f.xhat));
+  return f4scale(make_float4(g.x - f.xhat.x * dot, g.y - f.xhat.y * dot, g.z - f.xhat.z * dot, g.w - f.xhat.w * dot), f.rstd);
+}
+
+// Sum a per-lane float4 accumulator over all rows handled by the workgroup and store 64 floats.
+__device__ __forceinline__ void block_store_colsum(float4 acc, float* __restrict__ out64, float* lds /*[4][64]*/) {
+  acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+  acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+  acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+  acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane < 16) st4(&lds[wave * 64 + 4 * lane], acc);
+  __syncthreads();
+  if (threadIdx.x < 64) out64[threadIdx.x] = (lds[threadIdx.x] + lds[64 + threadIdx.x]) + (lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pe_table[pos][2i] = sin(pos * div_i), [2i+1] = cos(pos * div_i), div_i = exp(2i * -ln(1e4)/E)
+__global__ void k_pe_table(float* __restrict__ pe, int npos, int E) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npos * E) return;
+  int pos = i / E, c = i - pos * E;
+  float div = expf((float)(c & ~1) * (-logf(10000.0f) / (float)E));
+  float x = (float)pos * div;
+  pe[i] = (c & 1) ? cosf(x) : sinf(x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding rows: z -> x0 = gelu(z) -> xn = rmsnorm(x0) * s_ln -> kin = xn + pe[pos]
+//   mode 0 (observation encoder): z = (rmsnorm_F(obs) * s_obs) @ W_obs          (sable_network.py:93-101,126,132)
+//   mode 1 (action encoder):      z = W_act[idx]  (one-hot input, no bias)      (sable_network.py:258-267,306-307)
+struct EmbedArgs {
+  const float* obs; int ldo; int F; const float* s_obs; const float* W;  // W: [F][64] or [K+1][64]
+  const int* idx; int idx_stride;
+  const float* s_ln; const float* pe; const int* pos; int pos_stride; int npos;
+  float* z; float* xn; float* kin; int ldz, ldxn, ldkin;
+  long R;
+};
+
+__global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 sln = ld4(a.s_ln + c4);
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < a.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < a.R;
+    float4 z = f4zero();
+    if (ok) {
+      if (mode == 0) {
+        const float* o = a.obs + row * a.ldo;
+        float ms = 0.f;
+        for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
+        const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
+        for (int f = 0; f < a.F; ++f) {
+          const float of = o[f] * rstd * a.s_obs[f];
+          const float4 w = ld4(a.W + f * 64 + c4);
+          z.x += of * w.x; z.y += of * w.y; z.z += of * w.z; z.w += of * w.w;
+        }
+      } else {
+        z = ld4(a.W + (long)a.idx[row * a.idx_stride] * 64 + c4);
+      }
+    }
+    float4 x0 = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
+    RmsFwd n = rms_fwd(x0, sln);
+    if (ok) {
+      int p = a.pos[row * a.pos_stride];
+      p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
+      const float4 pe = ld4(a.pe + (long)p * 64 + c4);
+      if (a.z) st4(a.z + row * a.ldz + c4, z);
+      st4(a.xn + row * a.ldxn + c4, n.y);
+      st4(a.kin + row * a.ldkin + c4, f4add(n.y, pe));
+    }
+  }
+}
+
+// Backward of the embedding rows: d(xn) = d0 + d1 (+ d2) -> dz; slabs: ds_ln[64] (+ ds_obs[F] for mode 0)
+struct EmbedBwdArgs {
+  const float* z; int ldz;
+  const float* d0; const float* d1; const float* d2; int ldd0, ldd1, ldd2;
+  const float* s_ln;
+  float* dz; int lddz;
+  float* slab_sln;   // [grid][64]
+  // mode 0 extras
+  const float* obs; int ldo; int F; const float* s_obs; const float* W; float* slab_sobs;  // [grid][32]
+  long R;
+};
+
+__global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a, int mode) {
+  __shared__ float lds[4 * 64];
+  __shared__ float sobs_acc[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 sln = ld4(a.s_ln + c4);
+  float4 dsln = f4zero();
+  float dsobs[32];
+  if (mode == 0) {
+#pragma unroll
+    for (int f = 0; f < 32; ++f) dsobs[f] = 0.f;
+  }
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < a.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < a.R;
+    float4 z = f4zero(), d = f4zero();
+    if (ok) {
+      z = ld4(a.z + row * a.ldz + c4);
+      d = ld4(a.d0 + row * a.ldd0 + c4);
+      if (a.d1) d = f4add(d, ld4(a.d1 + row * a.ldd1 + c4));
+      if (a.d2) d = f4add(d, ld4(a.d2 + row * a.ldd2 + c4));
+    }
+    float4 x0 = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
+    RmsFwd n = rms_fwd(x0, sln);
+    float4 dx0 = rms_bwd(d, n, sln, dsln);
+    float4 dz = make_float4(dx0.x * gelu_tanh_grad(z.x), dx0.y * gelu_tanh_grad(z.y), dx0.z * gelu_tanh_grad(z.z),
+                            dx0.w * gelu_tanh_grad(z.w));
+    if (ok) st4(a.dz + row * a.lddz + c4, dz);
+    if (mode == 0) {
+      // d(s_obs)[f] += (dz . W[f,:]) * obs[f] * rstd   (the obs themselves need no gradient)
+      const float* o = a.obs + (ok ? row : 0) * a.ldo;
+      float ms = 0.f;
+      for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
+      const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
+#pragma unroll
+      for (int f = 0; f < 32; ++f) {
+        if (f < a.F) {
+          const float4 w = ld4(a.W + f * 64 + c4);
+          float dof = sum16(f4sum(f4mul(dz, w)));
+          if (ok && (lane & 15) == 0) dsobs[f] += dof * o[f] * rstd;
+        }
+      }
+    }
+  }
+  block_store_colsum(dsln, a.slab_sln + (long)blockIdx.x * 64, lds);
+  if (mode == 0) {
+    // lanes 0,16,32,48 of each wave hold partial sums
+#pragma unroll
+    for (int f = 0; f < 32; ++f) {
+      float v = dsobs[f];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane == 0) sobs_acc[wave][f] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32)
+      a.slab_sobs[(long)blockIdx.x * 32 + threadIdx.x] =
+          (sobs_acc[0][threadIdx.x] + sobs_acc[1][threadIdx.x]) + (sobs_acc[2][threadIdx.x] + sobs_acc[3][threadIdx.x]);
+  }
+}
+
+// Materialise the (normalised) observation features padded to 64 columns, or the one-hot of an index,
+// as the [R][64] left operand of the small weight-gradient GEMMs (dW_obs, dW_act, actor pre-torso).
+__global__ void k_small_operand(const float* __restrict__ obs, int ldo, int F, const float* __restrict__ s_obs,
+                                const int* __restrict__ idx, int idx_stride, float* __restrict__ out, long R, int mode) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * 64) return;
+  long row = i >> 6;
+  int f = (int)(i & 63);
+  float v = 0.f;
+  if (mode == 0) {        // rmsnorm_F(obs) * s_obs
+    const float* o = obs + row * ldo;
+    float ms = 0.f;
+    for (int k = 0; k < F; ++k) ms += o[k] * o[k];
+    if (f < F) v = o[f] * rsqrtf(ms / (float)F + NORM_EPS) * s_obs[f];
+  } else if (mode == 1) { // one-hot(idx)
+    v = (idx[row * idx_stride] == f) ? 1.f : 0.f;
+  } else {                // raw obs
+    if (f < F) v = obs[row * ldo + f];
+  }
+  out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Retention epilogue: rn = GroupNorm(r) (per-row over the 64 head channels, fast variance),
+// u = swish(gpre) * rn                                                  (retention.py:289-294)
+__global__ __launch_bounds__(256) void k_retpost_fwd(const float* __restrict__ r, int ldr, const float* __restrict__ gp, int ldg,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ u, int ldu, long R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 ga = ld4(gamma + c4), be = ld4(beta + c4);
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < R;
+    float4 x = f4zero(), g = f4zero();
+    if (ok) { x = ld4(r + row * ldr + c4); g = ld4(gp + row * ldg + c4); }
+    const float mu = rowmean64(x);
+    const float m2 = rowmean64(f4mul(x, x));
+    const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + NORM_EPS);
+    float4 rn = make_float4((x.x - mu) * rstd * ga.x + be.x, (x.y - mu) * rstd * ga.y + be.y,
+                            (x.z - mu) * rstd * ga.z + be.z, (x.w - mu) * rstd * ga.w + be.w);
+    float4 o = make_float4(swishf_(g.x) * rn.x, swishf_(g.y) * rn.y, swishf_(g.z) * rn.z, swishf_(g.w) * rn.w);
+    if (ok) st4(u + row * ldu + c4, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_retpost_bwd(const float* __restrict__ r, int ldr, const float* __restrict__ gp, int ldg,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ du, int lddu,
+                                                     float* __restrict__ dr, int lddr, float* __restrict__ dgp, int lddg,
+                                                     float* __restrict__ slab_gamma, float* __restrict__ slab_beta, long R) {
+  __shared__ float lds[4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 ga = ld4(gamma + c4), be = ld4(beta + c4);
+  float4 dga = f4zero(), dbe = f4zero();
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < R;
+    float4 x = f4zero(), g = f4zero(), d = f4zero();
+    if (ok) { x = ld4(r + row * ldr + c4); g = ld4(gp + row * ldg + c4); d = ld4(du + row * lddu + c4); }
+    const float mu = rowmean64(x);
+    const float m2 = rowmean64(f4mul(x, x));
+    const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + NORM_EPS);
+    float4 xh = make_float4((x.x - mu) * rstd, (x.y - mu) * rstd, (x.z - mu) * rstd, (x.w - mu) * rstd);
+    float4 rn = f4add(f4mul(xh, ga), be);
+    float4 sw = make_float4(swishf_(g.x), swishf_(g.y), swishf_(g.z), swishf_(g.w));
+    float4 drn = f4mul(d, sw);
+    float4 dg = make_float4(d.x * rn.x * swish_grad(g.x), d.y * rn.y * swish_grad(g.y), d.z * rn.z * swish_grad(g.z),
+                            d.w * rn.w * swish_grad(g.w));
+    dga = f4add(dga, f4mul(drn, xh));
+    dbe = f4add(dbe, drn);
+    float4 gg = f4mul(drn, ga);
+    const float mg = rowmean64(gg);
+    const float mgx = rowmean64(f4mul(gg, xh));
+    float4 dx = make_float4((gg.x - mg - xh.x * mgx) * rstd, (gg.y - mg - xh.y * mgx) * rstd,
+                            (gg.z - mg - xh.z * mgx) * rstd, (gg.w - mg - xh.w * mgx) * rstd);
+    if (ok) { st4(dr + row * lddr + c4, dx); st4(dgp + row * lddg + c4, dg); }
+  }
+  block_store_colsum(dga, slab_gamma + (long)blockIdx.x * 64, lds);
+  block_store_colsum(dbe, slab_beta + (long)blockIdx.x * 64, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residual + RMSNorm (+ second RMSNorm where the zero SwiGLU sits between two norms) (+ pe):
+//   x1 = rmsnorm(a + y) * s1 ; x2 = s2 ? rmsnorm(x1) * s2 : x1 ; out = x2 ; outpe = x2 + pe[pos]
+// (sable_network.py:69-70, 78-79, 203, 214-215, 233, 239-240)
+struct ResNormArgs {
+  const float* a; const float* y; int lda, ldy;
+  const float* s1; const float* s2;
+  const float* pe; const int* pos; int pos_stride; int npos;
+  float* out; float* outpe; int ldout, ldoutpe;
+  long R;
+};
+__global__ __launch_bounds__(256) void k_resnorm_fwd(ResNormArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 s1 = ld4(p.s1 + c4);
+  const float4 s2 = p.s2 ? ld4(p.s2 + c4) : f4zero();
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < p.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < p.R;
+    float4 x = f4zero();
+    if (ok) x = f4add(ld4(p.a + row * p.lda + c4), ld4(p.y + row * p.ldy + c4));
+    float4 o = rms_fwd(x, s1).y;
+    if (p.s2) o = rms_fwd(o, s2).y;
+    if (ok) {
+      if (p.out) st4(p.out + row * p.ldout + c4, o);
+      if (p.outpe) {
+        int ps = p.pos[row * p.pos_stride];
+        ps = ps < 0 ? 0 : (ps >= p.npos ? p.npos - 1 : ps);
+        st4(p.outpe + row * p.ldoutpe + c4, f4add(o, ld4(p.pe + (long)ps * 64 + c4)));
+      }
+    }
+  }
+}
+
+struct ResNormBwdArgs {
+  const float* a; const float* y; int lda, ldy;
+  const float* s1; const float* s2;
+  const float* d0; const float* d1; const float* d2; int ldd0, ldd1, ldd2;
+  float* dsum; int lddsum;          // d(a + y)
+  float* slab_s1; float* slab_s2;   // [grid][64]
+  long R;
+};
+__global__ __launch_bounds__(256) void k_resnorm_bwd(ResNormBwdArgs p) {
+  __shared__ float lds[4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 s1 = ld4(p.s1 + c4);
+  const float4 s2 = p.s2 ? ld4(p.s2 + c4) : f4zero();
+  float4 ds1 = f4zero(), ds2 = f4zero();
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < p.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < p.R;
+    float4 x = f4zero(), d = f4zero();
+    if (ok) {
+      x = f4add(ld4(p.a + row * p.lda + c4), ld4(p.y + row * p.ldy + c4));
+      d = ld4(p.d0 + row * p.ldd0 + c4);
+      if (p.d1) d = f4add(d, ld4(p.d1 + row * p.ldd1 + c4));
+      if (p.d2) d = f4add(d, ld4(p.d2 + row * p.ldd2 + c4));
+    }
+    RmsFwd n1 = rms_fwd(x, s1);
+    if (p.s2) {
+      RmsFwd n2 = rms_fwd(n1.y, s2);
+      d = rms_bwd(d, n2, s2, ds2);
+    }
+    float4 dx = rms_bwd(d, n1, s1, ds1);
+    if (ok) st4(p.dsum + row * p.lddsum + c4, dx);
+  }
+  block_store_colsum(ds1, p.slab_s1 + (long)blockIdx.x * 64, lds);
+  if (p.s2) block_store_colsum(ds2, p.slab_s2 + (long)blockIdx.x * 64, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head middle: h = gelu(hpre) ; hn = rmsnorm(h) * s ; mode 0 -> out hn ; mode 1 -> value = hn . w + b
+// (sable_network.py:102-109 value head, :277-284 logit head)
+__global__ __launch_bounds__(256) void k_headmid_fwd(const float* __restrict__ hpre, int ldh, const float* __restrict__ s,
+                                                     float* __restrict__ hn, int ldhn,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     float* __restrict__ value, int value_stride, long R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 sc = ld4(s + c4);
+  const float4 wv = w ? ld4(w + c4) : f4zero();
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < R;
+    float4 z = ok ? ld4(hpre + row * ldh + c4) : f4zero();
+    float4 h = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
+    float4 o = rms_fwd(h, sc).y;
+    if (hn && ok) st4(hn + row * ldhn + c4, o);
+    if (w) {
+      float v = sum16(f4sum(f4mul(o, wv))) + b[0];
+      if (ok && (lane & 15) == 0) value[row * value_stride] = v;
+    }
+  }
+}
+
+// Backward: incoming either dhn [R,64] (mode 0) or dvalue [R] (mode 1, dhn = dvalue * w).
+// Outputs dhpre; slabs ds[64]; mode 1 also dw[64] (slab) and db (slab_b[grid]).
+__global__ __launch_bounds__(256) void k_headmid_bwd(const float* __restrict__ hpre, int ldh, const float* __restrict__ s,
+                                                     const float* __restrict__ dhn, int lddhn,
+                                                     const float* __restrict__ w, const float* __restrict__ dvalue, int dvalue_stride,
+                                                     float* __restrict__ dhpre, int lddh,
+                                                     float* __restrict__ slab_s, float* __restrict__ slab_w, float* __restrict__ slab_b,
+                                                     long R) {
+  __shared__ float lds[4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const float4 sc = ld4(s + c4);
+  const float4 wv = w ? ld4(w + c4) : f4zero();
+  float4 ds = f4zero(), dw = f4zero();
+  float db = 0.f;
+  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long row = base + wave * 4 + (lane >> 4);
+    const bool ok = row < R;
+    float4 z = ok ? ld4(hpre + row * ldh + c4) : f4zero();
+    float4 h = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
+    RmsFwd n = rms_fwd(h, sc);
+    float4 d;
+    if (w) {
+      const float dv = ok ? dvalue[row * dvalue_stride] : 0.f;
+      d = f4scale(wv, dv);
+      dw = f4add(dw, f4scale(n.y, dv));
+      if ((lane & 15) == 0) db += dv;
+    } else {
+      d = ok ? ld4(dhn + row * lddhn + c4) : f4zero();
+    }
+    float4 dh = rms_bwd(d, n, sc, ds);
+    float4 dz = make_float4(dh.x * gelu_tanh_grad(z.x), dh.y * gelu_tanh_grad(z.y), dh.z * gelu_tanh_grad(z.z),
+                            dh.w * gelu_tanh_grad(z.w));
+    if (ok) st4(dhpre + row * lddh + c4, dz);
+  }
+  block_store_colsum(ds, slab_s + (long)blockIdx.x * 64, lds);
+  if (w) {
+    block_store_colsum(dw, slab_w + (long)blockIdx.x * 64, lds);
+    float v = wave_sum(db);
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) slab_b[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  }
+}
+
+// generic elementwise helpers -------------------------------------------------------------------
+// y = relu'(act) * dy  (act is the post-relu activation), in place allowed
+__global__ void k_relu_bwd(const float* __restrict__ act, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = ld4(act + i), d = ld4(dy + i);
+  st4(dx + i, make_float4(a.x > 0.f ? d.x : 0.f, a.y > 0.f ? d.y : 0.f, a.z > 0.f ? d.z : 0.f, a.w > 0.f ? d.w : 0.f));
+}
+
+}  // namespace magpo
+
+using namespace magpo;
+
+static inline int row_grid(long R) {
+  long b = (R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+extern "C" int magpo_row_grid(long R) { return row_grid(R); }
+
+extern "C" int magpo_pe_table(float* pe, int npos, int E, hipStream_t st) {
+  int n = npos * E;
+  hipLaunchKernelGGL(k_pe_table, dim3((n + 255) / 256), dim3(256), 0, st, pe, npos, E);
+  return check_launch("magpo_pe_table");
+}
+
+extern "C" int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const float* s_obs, const float* W,
+                               const int* idx, int idx_stride, const float* s_ln, const float* pe, const int* pos,
+                               int pos_stride, int npos, float* z, int ldz, float* xn, int ldxn, float* kin, int ldkin,
+                               long R, hipStream_t st) {
+  if (mode == 0 && F > 1024) { set_error("magpo_embed_fwd: F too large"); return MAGPO_EINVAL; }
+  EmbedArgs a{obs, ldo, F, s_obs, W, idx, idx_stride, s_ln, pe, pos, pos_stride, npos, z, xn, kin, ldz, ldxn, ldkin, R};
+  hipLaunchKernelGGL(k_embed_fwd, dim3(row_grid(R)), dim3(256), 0, st, a, mode);
+  return check_launch("magpo_embed_fwd");
+}
+
+// slab_sln: [grid][64], slab_sobs: [grid][32]; grid = magpo_row_grid(R)
+extern "C" int magpo_embed_bwd(int mode, const float* z, int ldz, const float* d0, int ldd0, const float* d1, int ldd1,
+                               const float* d2, int ldd2, const float* s_ln, float* dz, int lddz, float* slab_sln,
+                               const float* obs, int ldo, int F, const float* s_obs, const float* W, float* slab_sobs,
+                               long R, hipStream_t st) {
+  if (mode == 0 && F > 32) { set_error("magpo_embed_bwd: F > 32 not supported"); return MAGPO_EINVAL; }
+  EmbedBwdArgs a{z, ldz, d0, d1, d2, ldd0, ldd1, ldd2, s_ln, dz, lddz, slab_sln, obs, ldo, F, s_obs, W, slab_sobs, R};
+  hipLaunchKernelGGL(k_embed_bwd, dim3(row_grid(R)), dim3(256), 0, st, a, mode);
+  return check_launch("magpo_embed_bwd");
+}
+
+extern "C" int magpo_small_operand(int mode, const float* obs, int ldo, int F, const float* s_obs, const int* idx,
+                                   int idx_stride, float* out, long R, hipStream_t st) {
+  if (F > 64) { set_error("magpo_small_operand: F > 64 not supported"); return MAGPO_EINVAL; }
+  long n = R * 64;
+  hipLaunchKernelGGL(k_small_operand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, obs, ldo, F, s_obs, idx, idx_stride, out, R, mode);
+  return check_launch("magpo_small_operand");
+}
+
+extern "C" int magpo_retpost_fwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
+                                 float* u, int ldu, long R, hipStream_t st) {
+  hipLaunchKernelGGL(k_retpost_fwd, dim3(row_grid(R)), dim3(256), 0, st, r, ldr, gp, ldg, gamma, beta, u, ldu, R);
+  return check_launch("magpo_retpost_fwd");
+}
+
+extern "C" int magpo_retpost_bwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
+                                 const float* du, int lddu, float* dr, int lddr, float* dgp, int lddg, float* slab_gamma,
+                                 float* slab_beta, long R, hipStream_t st) {
+  hipLaunchKernelGGL(k_retpost_bwd, dim3(row_grid(R)), dim3(256), 0, st, r, ldr, gp, ldg, gamma, beta, du, lddu, dr, lddr,
+                     dgp, lddg, slab_gamma, slab_beta, R);
+  return check_launch("magpo_retpost_bwd");
+}
+
+extern "C" int magpo_resnorm_fwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
+                                 const float* pe, const int* pos, int pos_stride, int npos, float* out, int ldout,
+                                 float* outpe, int ldoutpe, long R, hipStream_t st) {
+  ResNormArgs p{a, y, lda, ldy, s1, s2, pe, pos, pos_stride, npos, out, outpe, ldout, ldoutpe, R};
+  hipLaunchKernelGGL(k_resnorm_fwd, dim3(row_grid(R)), dim3(256), 0, st, p);
+  return check_launch("magpo_resnorm_fwd");
+}
+
+extern "C" int magpo_resnorm_bwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
+                                 const float* d0, int ldd0, const float* d1, int ldd1, const float* d2, int ldd2,
+                                 float* dsum, int lddsum, float* slab_s1, float* slab_s2, long R, hipStream_t st) {
+  ResNormBwdArgs p{a, y, lda, ldy, s1, s2, d0, d1, d2, ldd0, ldd1, ldd2, dsum, lddsum, slab_s1, slab_s2, R};
+  hipLaunchKernelGGL(k_resnorm_bwd, dim3(row_grid(R)), dim3(256), 0, st, p);
+  return check_launch("magpo_resnorm_bwd");
+}
+
+extern "C" int magpo_headmid_fwd(const float* hpre, int ldh, const float* s, float* hn, int ldhn, const float* w,
+                                 const float* b, float* value, int value_stride, long R, hipStream_t st) {
+  hipLaunchKernelGGL(k_headmid_fwd, dim3(row_grid(R)), dim3(256), 0, st, hpre, ldh, s, hn, ldhn, w, b, value, value_stride, R);
+  return check_launch("magpo_headmid_fwd");
+}
+
+extern "C" int magpo_headmid_bwd(const float* hpre, int ldh, const float* s, const float* dhn, int lddhn, const float* w,
+                                 const float* dvalue, int dvalue_stride, float* dhpre, int lddh, float* slab_s,
+                                 float* slab_w, float* slab_b, long R, hipStream_t st) {
+  hipLaunchKernelGGL(k_headmid_bwd, dim3(row_grid(R)), dim3(256), 0, st, hpre, ldh, s, dhn, lddhn, w, dvalue, dvalue_stride,
+                     dhpre, lddh, slab_s, slab_w, slab_b, R);
+  return check_launch("magpo_headmid_bwd");
+}
+
+extern "C" int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, hipStream_t st) {
+  if (n & 3) { set_error("magpo_relu_bwd: n must be a multiple of 4"); return MAGPO_EINVAL; }
+  hipLaunchKernelGGL(k_relu_bwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, act, dy, dx, n);
+  return check_launch("magpo_relu_bwd");
+}

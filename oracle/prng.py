@@ -98,9 +98,12 @@ def bits_to_uniform(bits: np.ndarray, minval: float = 0.0, maxval: float = 1.0) 
 
 
 def bits_to_gumbel(bits: np.ndarray) -> np.ndarray:
-    """jax.random.gumbel (mode 'low'): -log(-log(uniform(tiny, 1)))."""
+    """jax.random.gumbel (mode 'low'): -log(-log(uniform(tiny, 1))).
+    The two logs are evaluated in float64 and rounded once to float32 so that every
+    implementation (this oracle, the HIP kernel) produces the same, correctly rounded value;
+    XLA's own float32 log may differ from it in the last ulp (PARITY UNPINNED)."""
     u = bits_to_uniform(bits, np.finfo(np.float32).tiny, 1.0)
-    return (-np.log(-np.log(u))).astype(np.float32)
+    return (-np.log(-np.log(u.astype(np.float64)))).astype(np.float32)
 
 
 def categorical(key: np.ndarray, logits: np.ndarray) -> np.ndarray:

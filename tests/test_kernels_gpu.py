@@ -1,0 +1,525 @@
+"""GPU parity of every primitive HIP kernel against the CPU oracle / torch fp64 (through the C ABI)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coordsum as ocs
+from oracle import learner as olearn
+from oracle import networks as onets
+from oracle import prng as oprng
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dev(x, dtype=None):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.to(DEV).contiguous()
+
+
+def close(a, b, rtol=2e-5, atol=2e-6, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} vs ref scale {ref:.3e}"
+
+
+def transpose_pad(L, st, W):
+    K, N = W.shape
+    Np = (N + 31) // 32 * 32
+    Wt = torch.empty(Np, K, device=DEV)
+    L.call("magpo_transpose_pad", W, Wt, K, N, Np, st)
+    return Wt
+
+
+@pytest.mark.parametrize("KIN,NOUT,R,act", [(64, 64, 200, 0), (64, 256, 130, 2), (128, 384, 64, 0), (256, 64, 77, 0),
+                                             (64, 20, 100, 0), (128, 128, 300, 1), (192, 64, 65, 0), (384, 128, 70, 0)])
+def test_linear(L, stream, KIN, NOUT, R, act):
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(R, KIN, generator=g)
+    W = torch.randn(KIN, NOUT, generator=g) / math.sqrt(KIN)
+    b = torch.randn(NOUT, generator=g)
+    Xd, Wd, bd = dev(X), dev(W), dev(b)
+    Wt = transpose_pad(L, stream, Wd)
+    close(Wt[:NOUT], W.T, 0, 0, "transpose")
+    ld = (NOUT + 3) // 4 * 4
+    Y = torch.zeros(R, ld, device=DEV)
+    Yp = torch.zeros(R, ld, device=DEV)
+    L.call("magpo_linear", Xd, KIN, Wt, bd, Y, ld, Yp, R, KIN, NOUT, act, stream)
+    ref = X.double() @ W.double() + b.double()
+    close(Yp[:, :NOUT], ref, what="pre")
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    close(Y[:, :NOUT], ref, what="act")
+
+
+@pytest.mark.parametrize("KIN,NOUT,R", [(64, 64, 1000), (64, 256, 333), (128, 384, 200), (64, 20, 500), (256, 64, 100)])
+def test_wgrad(L, stream, KIN, NOUT, R):
+    g = torch.Generator().manual_seed(2)
+    X = torch.randn(R, KIN, generator=g)
+    ld = (NOUT + 3) // 4 * 4
+    dY = torch.zeros(R, ld)
+    dY[:, :NOUT] = torch.randn(R, NOUT, generator=g)
+    G = 7
+    ws = torch.empty(L.call("magpo_wgrad_workspace_floats", KIN, NOUT, G), device=DEV)
+    dW = torch.zeros(KIN, NOUT, device=DEV)
+    db = torch.zeros(NOUT, device=DEV)
+    L.call("magpo_wgrad", dev(X), KIN, dev(dY), ld, R, KIN, KIN, NOUT, dW, db, ws, G, 0.5, 0, stream)
+    close(dW, 0.5 * X.double().T @ dY[:, :NOUT].double(), what="dW")
+    close(db, 0.5 * dY[:, :NOUT].double().sum(0), what="db")
+
+
+def _pe_table(L, st, npos=101):
+    pe = torch.empty(npos, 64, device=DEV)
+    L.call("magpo_pe_table", pe, npos, 64, st)
+    return pe
+
+
+def test_pe_table(L, stream):
+    pe = _pe_table(L, stream)
+    ref = onets.positional_encoding(torch.arange(101), 64, torch.float32)
+    close(pe, ref, 0, 2e-6, "pe")
+
+
+def _slabsum(slab):
+    return slab.double().sum(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_embed_fwd_bwd(L, stream, mode):
+    g = torch.Generator().manual_seed(3)
+    R, F, K = 333, 5, 20
+    pe = _pe_table(L, stream)
+    pos = torch.randint(0, 101, (R,), generator=g, dtype=torch.int32)
+    s_ln = 1 + 0.1 * torch.randn(64, generator=g)
+    obs = torch.randint(0, 60, (R, F), generator=g).float()
+    s_obs = 1 + 0.1 * torch.randn(F, generator=g)
+    W = torch.randn(F if mode == 0 else K + 1, 64, generator=g) * 0.5
+    idx = torch.randint(0, K + 1, (R,), generator=g, dtype=torch.int32)
+    z = torch.empty(R, 64, device=DEV); xn = torch.empty_like(z); kin = torch.empty_like(z)
+    L.call("magpo_embed_fwd", mode, dev(obs), F, F, dev(s_obs), dev(W), dev(idx), 1, dev(s_ln), pe, dev(pos), 1, 101,
+           z, 64, xn, 64, kin, 64, R, stream)
+    # reference (fp64 autograd)
+    Wd = W.double().requires_grad_(True); sl = s_ln.double().requires_grad_(True); so = s_obs.double().requires_grad_(True)
+    if mode == 0:
+        zr = onets.rmsnorm(obs.double(), so) @ Wd
+    else:
+        zr = Wd[idx.long()]
+    xnr = onets.rmsnorm(onets.gelu(zr), sl)
+    kinr = xnr + pe.cpu().double()[pos.long()]
+    close(z, zr, what="z"); close(xn, xnr, what="xn"); close(kin, kinr, what="kin")
+    d0 = torch.randn(R, 64, generator=g); d1 = torch.randn(R, 64, generator=g)
+    (xnr * d0.double() + kinr * d1.double()).sum().backward()
+    grid = L.call("magpo_row_grid", R)
+    dz = torch.empty(R, 64, device=DEV)
+    slab_sln = torch.zeros(grid, 64, device=DEV); slab_sobs = torch.zeros(grid, 32, device=DEV)
+    L.call("magpo_embed_bwd", mode, z, 64, dev(d0), 64, dev(d1), 64, None, 0, dev(s_ln), dz, 64, slab_sln,
+           dev(obs), F, F, dev(s_obs), dev(W), slab_sobs, R, stream)
+    close(_slabsum(slab_sln), sl.grad, 1e-4, 1e-5, "ds_ln")
+    # dW through the small-operand + wgrad path
+    op = torch.empty(R, 64, device=DEV)
+    L.call("magpo_small_operand", mode, dev(obs), F, F, dev(s_obs), dev(idx), 1, op, R, stream)
+    rows = F if mode == 0 else K + 1
+    G = 5
+    ws = torch.empty(L.call("magpo_wgrad_workspace_floats", 64, 64, G), device=DEV)
+    dW = torch.zeros(rows, 64, device=DEV)
+    L.call("magpo_wgrad", op, 64, dz, 64, R, 64, rows, 64, dW, None, ws, G, 1.0, 0, stream)
+    close(dW, Wd.grad, 1e-4, 1e-5, "dW")
+    if mode == 0:
+        close(_slabsum(slab_sobs)[:F], so.grad, 1e-4, 1e-5, "ds_obs")
+
+
+def test_retpost_resnorm_headmid(L, stream):
+    g = torch.Generator().manual_seed(4)
+    R = 300
+    pe = _pe_table(L, stream)
+    pos = torch.randint(0, 101, (R,), generator=g, dtype=torch.int32)
+    grid = L.call("magpo_row_grid", R)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    # retpost
+    r, gp, du = rn(R, 64), rn(R, 64), rn(R, 64)
+    ga, be = 1 + 0.1 * rn(64), 0.1 * rn(64)
+    u = torch.empty(R, 64, device=DEV)
+    L.call("magpo_retpost_fwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), u, 64, R, stream)
+    rd, gpd, gad, bed = (t.double().requires_grad_(True) for t in (r, gp, ga, be))
+    ur = onets.swish(gpd) * onets.groupnorm_rows(rd, gad, bed, 1)
+    close(u, ur, what="u")
+    (ur * du.double()).sum().backward()
+    dr = torch.empty(R, 64, device=DEV); dgp = torch.empty(R, 64, device=DEV)
+    sg = torch.zeros(grid, 64, device=DEV); sb = torch.zeros(grid, 64, device=DEV)
+    L.call("magpo_retpost_bwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), dev(du), 64, dr, 64, dgp, 64, sg, sb, R, stream)
+    close(dr, rd.grad, 1e-4, 1e-5, "dr"); close(dgp, gpd.grad, 1e-4, 1e-5, "dgp")
+    close(_slabsum(sg), gad.grad, 1e-4, 1e-5, "dgamma"); close(_slabsum(sb), bed.grad, 1e-4, 1e-5, "dbeta")
+    # resnorm (two norms + pe) and (one norm)
+    for two in (True, False):
+        a, y, d0, d1 = rn(R, 64), rn(R, 64), rn(R, 64), rn(R, 64)
+        s1, s2 = 1 + 0.1 * rn(64), 1 + 0.1 * rn(64)
+        out = torch.empty(R, 64, device=DEV); outpe = torch.empty(R, 64, device=DEV)
+        L.call("magpo_resnorm_fwd", dev(a), 64, dev(y), 64, dev(s1), dev(s2) if two else None, pe, dev(pos), 1, 101,
+               out, 64, outpe, 64, R, stream)
+        ad, yd, s1d, s2d = (t.double().requires_grad_(True) for t in (a, y, s1, s2))
+        o = onets.rmsnorm(ad + yd, s1d)
+        if two:
+            o = onets.rmsnorm(o, s2d)
+        ope = o + pe.cpu().double()[pos.long()]
+        close(out, o, what="resnorm out"); close(outpe, ope, what="resnorm outpe")
+        (o * d0.double() + ope * d1.double()).sum().backward()
+        dsum = torch.empty(R, 64, device=DEV)
+        sl1 = torch.zeros(grid, 64, device=DEV); sl2 = torch.zeros(grid, 64, device=DEV)
+        L.call("magpo_resnorm_bwd", dev(a), 64, dev(y), 64, dev(s1), dev(s2) if two else None, dev(d0), 64, dev(d1), 64,
+               None, 0, dsum, 64, sl1, sl2, R, stream)
+        close(dsum, ad.grad, 1e-4, 1e-5, "dsum"); close(_slabsum(sl1), s1d.grad, 1e-4, 1e-5, "ds1")
+        if two:
+            close(_slabsum(sl2), s2d.grad, 1e-4, 1e-5, "ds2")
+    # headmid: logits mode and value mode
+    hpre, dhn = rn(R, 64), rn(R, 64)
+    s, w, b, dv = 1 + 0.1 * rn(64), rn(64), rn(1), rn(R)
+    hn = torch.empty(R, 64, device=DEV)
+    L.call("magpo_headmid_fwd", dev(hpre), 64, dev(s), hn, 64, None, None, None, 0, R, stream)
+    hd, sd, wd, bd = (t.double().requires_grad_(True) for t in (hpre, s, w, b))
+    hnr = onets.rmsnorm(onets.gelu(hd), sd)
+    close(hn, hnr, what="hn")
+    (hnr * dhn.double()).sum().backward()
+    dh = torch.empty(R, 64, device=DEV); ss = torch.zeros(grid, 64, device=DEV)
+    L.call("magpo_headmid_bwd", dev(hpre), 64, dev(s), dev(dhn), 64, None, None, 0, dh, 64, ss, None, None, R, stream)
+    close(dh, hd.grad, 1e-4, 1e-5, "dhpre"); close(_slabsum(ss), sd.grad, 1e-4, 1e-5, "ds")
+    hd.grad = None; sd.grad = None
+    val = torch.empty(R, device=DEV)
+    L.call("magpo_headmid_fwd", dev(hpre), 64, dev(s), None, 0, dev(w), dev(b), val, 1, R, stream)
+    vr = onets.rmsnorm(onets.gelu(hd), sd) @ wd + bd
+    close(val, vr, what="value")
+    (vr * dv.double()).sum().backward()
+    sw = torch.zeros(grid, 64, device=DEV); sbb = torch.zeros(grid, device=DEV)
+    L.call("magpo_headmid_bwd", dev(hpre), 64, dev(s), None, 0, dev(w), dev(dv), 1, dh, 64, ss, sw, sbb, R, stream)
+    close(dh, hd.grad, 1e-4, 1e-5, "dhpre(v)"); close(_slabsum(ss), sd.grad, 1e-4, 1e-5, "ds(v)")
+    close(_slabsum(sw), wd.grad, 1e-4, 1e-5, "dw"); close(sbb.double().sum(), bd.grad[0], 1e-4, 1e-5, "db")
+
+
+def _ret_reference(q, k, v, s0, dones_t, A, kappa, masked):
+    """Oracle decay-matrix form (retention.py:66-100) in fp64."""
+    B, C, _ = q.shape
+    dones = dones_t[:, :, None].expand(-1, -1, A).reshape(B, C)
+    D = onets.decay_matrix(dones, A, kappa, masked, torch.float64)
+    xi = onets.xi_vector(dones, A, kappa, torch.float64)
+    return ((q @ k.transpose(1, 2)) * D) @ v + (q @ s0) * xi
+
+
+@pytest.mark.parametrize("A,T,masked", [(4, 40, 1), (4, 128, 0), (2, 50, 1), (3, 45, 1), (8, 24, 0), (5, 30, 1)])
+def test_retention_chunk(L, stream, A, T, masked):
+    g = torch.Generator().manual_seed(5)
+    B, kappa = 5, 0.775
+    C = T * A
+    q, k, v, dr = (torch.randn(B, C, 64, generator=g) * 0.5 for _ in range(4))
+    s0 = torch.randn(B, 64, 64, generator=g) * 0.3
+    dones = torch.rand(B, T, generator=g) < 0.08
+    dones[0, 0] = True
+    dones[1, :] = False
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = _ret_reference(qd, kd, vd, s0.double(), dones, A, kappa, bool(masked))
+    (ref * dr.double()).sum().backward()
+    nch = L.call("magpo_retention_num_chunks", T, A)
+    # q, k, v live in one [R, 256] buffer like the fused projection output
+    buf = torch.zeros(B * C, 256, device=DEV)
+    buf[:, 0:64] = dev(q.reshape(-1, 64)); buf[:, 64:128] = dev(k.reshape(-1, 64)); buf[:, 128:192] = dev(v.reshape(-1, 64))
+    r = torch.zeros(B * C, 64, device=DEV)
+    states = torch.zeros(B, nch, 64, 64, device=DEV)
+    sfin = torch.zeros(B, 64, 64, device=DEV)
+    perm = torch.tensor([3, 1, 4, 0, 2], dtype=torch.int32)
+    s0_store = torch.zeros(B, 64, 64)
+    s0_store[perm.long()] = s0
+    dn = dev(dones.to(torch.uint8))
+    L.call("magpo_retention_chunk_fwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, r, 64, dev(s0_store), dev(perm),
+           dn, states, sfin, B, T, A, masked, kappa, stream)
+    close(r.reshape(B, C, 64), ref, 1e-4, 1e-5, "ret fwd")
+    dbuf = torch.zeros(B * C, 256, device=DEV)
+    L.call("magpo_retention_chunk_bwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, dev(dr.reshape(-1, 64)), 64,
+           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, stream)
+    close(dbuf[:, 0:64].reshape(B, C, 64), qd.grad, 1e-4, 1e-5, "dq")
+    close(dbuf[:, 64:128].reshape(B, C, 64), kd.grad, 1e-4, 1e-5, "dk")
+    close(dbuf[:, 128:192].reshape(B, C, 64), vd.grad, 1e-4, 1e-5, "dv")
+
+
+def test_retention_recurrent(L, stream):
+    g = torch.Generator().manual_seed(6)
+    N, A = 37, 4
+    S = torch.randn(N, 64, 64, generator=g)
+    q, k, v = (torch.randn(N * A, 64, generator=g) for _ in range(3))
+    Sd = dev(S)
+    r = torch.zeros(N * A, 64, device=DEV)
+    L.call("magpo_retention_recurrent", Sd, dev(q), 64, dev(k), 64, dev(v), 64, A, r, 64, N, A, 0.775, stream)
+    qq, kk, vv = (t.double().reshape(N, A, 64) for t in (q, k, v))
+    Sn = 0.775 * S.double() + kk.transpose(1, 2) @ vv
+    close(Sd, Sn, what="S"); close(r.reshape(N, A, 64), qq @ Sn, what="ret")
+    # single token (decoder iteration): token 2 of each env, no decay
+    S2 = dev(S)
+    L.call("magpo_retention_recurrent", S2, dev(q)[2:], 64, dev(k)[2:], 64, dev(v)[2:], 64, A, r[2:], 64, N, 1, 1.0, stream)
+    Sn = S.double() + kk[:, 2:3].transpose(1, 2) @ vv[:, 2:3]
+    close(S2, Sn, what="S1"); close(r.reshape(N, A, 64)[:, 2], (qq[:, 2:3] @ Sn)[:, 0], what="ret1")
+
+
+def test_gru_scan(L, stream):
+    g = torch.Generator().manual_seed(7)
+    nseq, T, A, F, K, H = 21, 9, 4, 5, 20, 128
+    p = onets.init_actor_params(3, F, H, K, dtype=torch.float64)
+    for n in ("gru.ir.bias", "gru.iz.bias", "gru.in.bias", "gru.hn.bias"):
+        p[n] = torch.randn(H, generator=g, dtype=torch.float64) * 0.1
+    p = {n: t.requires_grad_(True) for n, t in p.items()}
+    emb = torch.randn(T, nseq, A, H, generator=g).double().requires_grad_(True)
+    h0 = torch.randn(nseq, A, H, generator=g).double()
+    done = torch.rand(nseq, T, generator=g) < 0.2
+    done[0, 0] = True
+    # oracle scan on pre-computed embeddings
+    h = h0
+    hs = []
+    for t in range(T):
+        h = torch.where(done[:, t][:, None, None], torch.zeros_like(h), h)
+        h = onets.gru_cell(p, h, emb[t])
+        hs.append(h)
+    hs = torch.stack(hs)  # (T, nseq, A, H)
+    dhs = torch.randn(T, nseq, A, H, generator=g)
+    (hs * dhs.double()).sum().backward()
+    # device layout rows (seq, t, a)
+    to_rows = lambda x: x.detach().permute(1, 0, 2, 3).reshape(nseq * T * A, -1).float()
+    Wi = torch.cat([p["gru.ir.kernel"], p["gru.iz.kernel"], p["gru.in.kernel"]], 1).detach().float()
+    bi = torch.cat([p["gru.ir.bias"], p["gru.iz.bias"], p["gru.in.bias"]]).detach().float()
+    Wh = torch.cat([p["gru.hr.kernel"], p["gru.hz.kernel"], p["gru.hn.kernel"]], 1).detach().float()
+    R = nseq * T * A
+    xi = torch.empty(R, 3 * H, device=DEV)
+    L.call("magpo_linear", dev(to_rows(emb)), H, transpose_pad(L, stream, dev(Wi)), dev(bi), xi, 3 * H, None, R, H, 3 * H, 0, stream)
+    hsd = torch.empty(R, H, device=DEV); gates = torch.empty(R, 4 * H, device=DEV); hprev = torch.empty(R, H, device=DEV)
+    perm = torch.randperm(nseq * A, generator=g).int()
+    h0_store = torch.zeros(nseq * A, H)
+    h0_store[perm.long()] = h0.reshape(-1, H).float()
+    rs = dev(done.to(torch.uint8))
+    Wht = transpose_pad(L, stream, dev(Wh))
+    L.call("magpo_gru_scan_fwd", xi, Wht, dev(p["gru.hn.bias"].detach().float()), dev(h0_store), dev(perm), rs, hsd, gates, hprev,
+           nseq, T, A, stream)
+    close(hsd, to_rows(hs), 1e-4, 1e-5, "hs")
+    dxi = torch.empty(R, 3 * H, device=DEV); dhh = torch.empty(R, 3 * H, device=DEV)
+    nblk = (nseq * A + 63) // 64
+    slab = torch.zeros(nblk, H, device=DEV)
+    L.call("magpo_gru_scan_bwd", gates, hprev, rs, dev(to_rows(dhs)), dev(Wh), dxi, dhh, slab, nseq, T, A, stream)
+    # check through the parameter gradients
+    G = 3
+    ws = torch.empty(L.call("magpo_wgrad_workspace_floats", H, 3 * H, G), device=DEV)
+    dWi = torch.zeros(H, 3 * H, device=DEV); dbi = torch.zeros(3 * H, device=DEV); dWh = torch.zeros(H, 3 * H, device=DEV)
+    L.call("magpo_wgrad", dev(to_rows(emb)), H, dxi, 3 * H, R, H, H, 3 * H, dWi, dbi, ws, G, 1.0, 0, stream)
+    L.call("magpo_wgrad", hprev, H, dhh, 3 * H, R, H, H, 3 * H, dWh, None, ws, G, 1.0, 0, stream)
+    refWi = torch.cat([p["gru.ir.kernel"].grad, p["gru.iz.kernel"].grad, p["gru.in.kernel"].grad], 1)
+    refWh = torch.cat([p["gru.hr.kernel"].grad, p["gru.hz.kernel"].grad, p["gru.hn.kernel"].grad], 1)
+    refbi = torch.cat([p["gru.ir.bias"].grad, p["gru.iz.bias"].grad, p["gru.in.bias"].grad])
+    close(dWi, refWi, 1e-4, 1e-5, "dWi"); close(dWh, refWh, 1e-4, 1e-5, "dWh"); close(dbi, refbi, 1e-4, 1e-5, "dbi")
+    close(_slabsum(slab), p["gru.hn.bias"].grad, 1e-4, 1e-5, "dbhn")
+    demb = torch.empty(R, H, device=DEV)
+    L.call("magpo_linear", dxi, 3 * H, dev(Wi), None, demb, H, None, R, 3 * H, H, 0, stream)
+    close(demb, to_rows(emb.grad), 1e-4, 1e-5, "demb")
+
+
+def test_sample_categorical(L, stream):
+    g = torch.Generator().manual_seed(8)
+    N, K, A = 1000, 20, 4
+    logits = torch.randn(N, 32, generator=g)
+    key = oprng.split(oprng.prng_key(7), 3)[2]
+    act = torch.zeros(N, A, dtype=torch.int32, device=DEV); lp = torch.zeros(N, A, device=DEV)
+    nxt = torch.zeros(N, A, dtype=torch.int32, device=DEV); lpall = torch.zeros(N, 32, device=DEV)
+    L.call("magpo_sample_categorical", dev(logits), 32, None, 0, int(key[0]), int(key[1]), act[:, 1:], A, lp[:, 1:], A,
+           nxt[:, 2:], A, lpall, 32, N, K, stream)
+    lpd = lpall[:, :K].cpu()
+    ref_lp = torch.log_softmax(logits[:, :K].double(), -1)
+    close(lpd, ref_lp, 1e-5, 1e-6, "log-softmax")
+    ref_a = oprng.categorical(key, lpd.numpy()[:, None, :])[:, 0]  # oracle sampling on the device's own log-probs
+    assert np.array_equal(act[:, 1].cpu().numpy(), ref_a), "sampled action indices must be bit-exact"
+    assert np.array_equal(nxt[:, 2].cpu().numpy(), ref_a + 1)
+    close(lp[:, 1], lpd.gather(1, torch.from_numpy(ref_a).long()[:, None])[:, 0], 0, 0, "logp")
+
+
+def test_threefry_device(L, stream):
+    key = oprng.prng_key(1234)
+    out = torch.zeros(1000, 2, dtype=torch.int32, device=DEV)
+    kd = dev(key.view(np.int32))
+    L.call("magpo_threefry_split", kd, out, 1000, stream)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), oprng.split(key, 1000))
+    bits = torch.zeros(777, dtype=torch.int32, device=DEV)
+    L.call("magpo_threefry_random_bits", kd, bits, 777, stream)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), oprng.random_bits(key, 777))
+
+
+class DevEnv:
+    def __init__(self, L, st, spec, N):
+        self.L, self.st, self.spec, self.N = L, st, spec, N
+        A, K, TL = spec.num_agents, spec.num_actions, spec.time_limit
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=DEV)
+        self.step_count, self.target, self.record = i32(N), i32(N, TL + 1), i32(N, K, TL)
+        self.key, self.mkey = i32(N, 2), i32(N, 2)
+        self.run_ret, self.run_len = torch.zeros(N, device=DEV), i32(N)
+        self.ep_ret, self.ep_len = torch.zeros(N, device=DEV), i32(N)
+        self.obs, self.obs_step = torch.zeros(N, A, A + 1, device=DEV), i32(N)
+        self.reward = torch.zeros(N, A, device=DEV)
+        self.done = torch.zeros(N, dtype=torch.uint8, device=DEV)
+        self.m_ret, self.m_len, self.m_term = torch.zeros(N, device=DEV), i32(N), torch.zeros(N, dtype=torch.uint8, device=DEV)
+
+    def _state(self):
+        return (self.step_count, self.target, self.record, self.key, self.mkey, self.run_ret, self.run_len, self.ep_ret, self.ep_len)
+
+    def _cfg(self):
+        s = self.spec
+        return (self.N, s.num_agents, s.num_actions, s.time_limit, s.maxval)
+
+    def reset(self, env_keys):
+        self.L.call("magpo_coordsum_reset", *self._state(), *self._cfg(), dev(env_keys.view(np.int32)), self.obs, self.obs_step, self.st)
+
+    def step(self, actions, auto_reset=1):
+        self.L.call("magpo_coordsum_step", *self._state(), *self._cfg(), actions, self.spec.num_agents, self.reward, self.done,
+                    self.obs, self.obs_step, self.m_ret, self.m_len, self.m_term, auto_reset, self.st)
+
+
+@pytest.mark.parametrize("A,K,TL,maxval,auto", [(4, 20, 100, 60, 1), (2, 3, 4, 5, 1), (8, 15, 100, 100, 1), (3, 10, 20, 30, 0)])
+def test_coordsum_env(L, stream, A, K, TL, maxval, auto):
+    spec = ocs.CoordSumSpec(A, K, TL, maxval)
+    N = 64
+    keys = oprng.split(oprng.prng_key(11), N)
+    st, ts = ocs.reset(spec, keys)
+    env = DevEnv(L, stream, spec, N)
+    env.reset(keys)
+    assert np.array_equal(env.target.cpu().numpy(), st["target"])
+    assert np.array_equal(env.key.cpu().numpy().view(np.uint32), st["key"])
+    assert np.array_equal(env.obs.cpu().numpy(), ts["observation"]["agents_view"].astype(np.float32))
+    rng = np.random.default_rng(0)
+    nsteps = 2 * TL + 7 if auto else TL + 3
+    for i in range(nsteps):
+        tgt = st["target"][np.arange(N), np.minimum(st["step_count"], TL)]
+        acts = rng.integers(0, K, size=(N, A)).astype(np.int32)
+        # make the sum match on roughly half the envs so both reward branches run
+        fix = rng.random(N) < 0.5
+        for n in np.nonzero(fix)[0]:
+            rest = int(tgt[n]) - int(acts[n, 1:].sum())
+            if 0 <= rest < K:
+                acts[n, 0] = rest
+        st, ts = ocs.step(spec, st, acts, auto_reset=bool(auto))
+        env.step(dev(acts), auto)
+        assert np.array_equal(env.reward.cpu().numpy(), ts["reward"]), f"reward step {i}"
+        assert np.array_equal(env.done.cpu().numpy().astype(bool), ts["step_type"] == ocs.STEP_LAST)
+        assert np.array_equal(env.obs.cpu().numpy(), ts["observation"]["agents_view"].astype(np.float32)), f"obs step {i}"
+        assert np.array_equal(env.obs_step.cpu().numpy(), ts["observation"]["step_count"][:, 0])
+        assert np.array_equal(env.m_ret.cpu().numpy(), ts["episode_metrics"]["episode_return"])
+        assert np.array_equal(env.m_len.cpu().numpy(), ts["episode_metrics"]["episode_length"])
+    assert np.array_equal(env.record.cpu().numpy(), st["record"])
+    assert np.array_equal(env.target.cpu().numpy(), st["target"])
+    assert np.array_equal(env.key.cpu().numpy().view(np.uint32), st["key"])
+
+
+def test_gae(L, stream):
+    g = torch.Generator().manual_seed(9)
+    T, N, A = 37, 50, 4
+    reward, value = torch.randn(T, N, A, generator=g), torch.randn(T, N, A, generator=g)
+    done_env = torch.rand(T, N, generator=g) < 0.1
+    last_val = torch.randn(N, A, generator=g)
+    last_done_env = torch.rand(N, generator=g) < 0.3
+    adv, tg = olearn.calculate_gae(reward.double(), value.double(), done_env[:, :, None].expand(T, N, A), last_val.double(),
+                                   last_done_env[:, None].expand(N, A), 0.99, 0.95)
+    a = torch.empty(T, N, A, device=DEV); t = torch.empty(T, N, A, device=DEV)
+    L.call("magpo_gae", dev(reward), dev(value), dev(done_env.to(torch.uint8)), dev(last_val), dev(last_done_env.to(torch.uint8)),
+           a, t, T, N, A, 0.99, 0.95, stream)
+    close(a, adv, 1e-5, 1e-5, "adv"); close(t, tg, 1e-5, 1e-5, "targets")
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_loss_fwd_bwd(L, stream, masked):
+    g = torch.Generator().manual_seed(10)
+    R, K = 1500, 20
+    sysc = olearn.SystemCfg()
+    gl = torch.randn(R, K, generator=g) * 0.7
+    al = gl + torch.randn(R, K, generator=g) * 0.6   # far enough that the clip_gpo mask triggers on some rows
+    mask = torch.ones(R, K, dtype=torch.bool)
+    if masked:
+        mask = torch.rand(R, K, generator=g) < 0.8
+        mask[:, 0] = True
+    action = torch.multinomial(mask.float(), 1, generator=g)[:, 0]
+    value, vold, tgt, adv = (torch.randn(R, generator=g) for _ in range(4))
+    value = vold + 0.3 * value
+    gld, ald, vd = (t.double().requires_grad_(True) for t in (gl, al, value))
+    glp = onets.masked_log_softmax(gld, mask); alp = onets.masked_log_softmax(ald, mask)
+    g_logp = glp.gather(1, action[:, None])[:, 0]; a_logp = alp.gather(1, action[:, None])[:, 0]
+    old = (g_logp + 0.1 * torch.randn(R, generator=g).double()).detach()
+    pr = glp.exp()
+    ent = -torch.where(pr == 0, torch.zeros_like(pr), pr * glp).sum(-1)
+    mb = dict(log_prob=old, adv=adv.double(), value=vold.double(), targets=tgt.double())
+    tl_g, gi = olearn.guider_loss(sysc, vd, g_logp, ent, glp, alp, a_logp, mb)
+    tl_a, ai = olearn.actor_loss(sysc, glp, alp, a_logp, mb)
+    gg, gv = torch.autograd.grad(tl_g, [gld, vd], retain_graph=True)
+    (ga,) = torch.autograd.grad(tl_a, [ald])
+    pad = lambda x: torch.cat([x, torch.zeros(R, 32 - K)], 1)
+    stats = torch.empty(2, device=DEV)
+    ws = torch.empty(8 * 1024, dtype=torch.float64, device=DEV)
+    L.call("magpo_adv_moments", dev(adv), R, ws, stats, stream)
+    close(stats[0], adv.double().mean(), 1e-6, 1e-7, "adv mean")
+    close(stats[1], 1 / (adv.double().std(unbiased=False) + 1e-8), 1e-5, 0, "adv rstd")
+    dg = torch.empty(R, 32, device=DEV); da = torch.empty(R, 32, device=DEV); dv = torch.empty(R, device=DEV)
+    lo = torch.empty(9, device=DEV)
+    L.call("magpo_loss_fwd_bwd", dev(pad(gl)), 32, dev(pad(al)), 32, dev(mask.to(torch.uint8)) if masked else None, dev(action.int()),
+           dev(old.float()), dev(vold), dev(value), dev(adv), dev(tgt), stats, dg, 32, da, 32, dv, ws, lo,
+           R, K, sysc.clip_eps, sysc.clip_gpo, sysc.ent_coef, sysc.vf_coef, sysc.alpha, stream)
+    lo = lo.cpu()
+    assert float(gi["kl_loss"]) > 0, "test must exercise the clip_gpo mask"
+    for i, ref in [(1, gi["value_loss"]), (2, ai["actor_loss"]), (3, gi["guider_loss"]), (4, gi["kl_loss"]), (5, gi["entropy"]),
+                   (6, ai["actor_kl"]), (7, tl_g), (8, tl_a)]:
+        close(lo[i], ref.detach(), 2e-5, 1e-6, f"loss[{i}]")
+    close(dg[:, :K], gg, 2e-4, 1e-9, "dlogits_g"); close(da[:, :K], ga, 2e-4, 1e-9, "dlogits_a"); close(dv, gv, 2e-4, 1e-9, "dvalue")
+    assert dg[:, K:].abs().max().item() == 0
+
+
+def test_clip_adam(L, stream):
+    g = torch.Generator().manual_seed(12)
+    n = 5000
+    for scale in (1e-3, 3.0):  # below / above the clipping threshold
+        p = {"w": torch.randn(n, generator=g)}
+        gr = {"w": torch.randn(n, generator=g) * scale}
+        opt = olearn.adam_init(p)
+        pd, md, vd = dev(p["w"]), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        ws = torch.empty(1024, dtype=torch.float64, device=DEV); gn = torch.empty(1, device=DEV)
+        for step in range(1, 4):
+            p, opt, gnorm = olearn.clip_adam_step(p, gr, opt, 2.5e-4, 0.5)
+            bc1 = float(np.float32(1) - np.float32(0.9) ** np.float32(step)); bc2 = float(np.float32(1) - np.float32(0.999) ** np.float32(step))
+            L.call("magpo_clip_adam", pd, dev(gr["w"] * 2), md, vd, n, 0.5, 0.5, 2.5e-4, 0.9, 0.999, 1e-5, bc1, bc2, ws, gn, stream)
+            close(gn[0], gnorm, 1e-6, 0, "gnorm")
+            close(pd, p["w"], 1e-6, 1e-7, "params")
+
+
+def test_gather_minibatch(L, stream):
+    g = torch.Generator().manual_seed(13)
+    T, N, A, F, K, mb = 6, 10, 4, 5, 20, 5
+    obs = torch.randn(T, N, A, F, generator=g)
+    action = torch.randint(0, K, (T, N, A), generator=g, dtype=torch.int32)
+    sc = torch.randint(0, 100, (T, N), generator=g, dtype=torch.int32)
+    done = (torch.rand(T, N, generator=g) < 0.3).to(torch.uint8)
+    val, lp, adv, tg = (torch.randn(T, N, A, generator=g) for _ in range(4))
+    bp = torch.randperm(N, generator=g).int(); ap = torch.randperm(A, generator=g).int()
+    env_idx = bp[mb:2 * mb]
+    R = mb * T * A
+    o_obs = torch.empty(R, F, device=DEV); o_act = torch.empty(R, dtype=torch.int32, device=DEV); o_prev = torch.empty_like(o_act)
+    o_pos = torch.empty_like(o_act); o_done = torch.empty(mb, T, dtype=torch.uint8, device=DEV)
+    o_val, o_lp, o_adv, o_tg = (torch.empty(R, device=DEV) for _ in range(4))
+    o_h0 = torch.empty(mb * A, dtype=torch.int32, device=DEV)
+    L.call("magpo_gather_minibatch", dev(obs), dev(action), dev(sc), dev(done), None, dev(val), dev(lp), dev(adv), dev(tg),
+           dev(env_idx), dev(ap), o_obs, o_act, o_prev, o_pos, o_done, None, o_val, o_lp, o_adv, o_tg, o_h0, T, N, A, F, K, mb, stream)
+
+    def prep(x):  # rec_magpo.py:445-453 on the selected envs
+        x = x.index_select(1, env_idx.long()).index_select(2, ap.long()).transpose(0, 1)
+        return x.reshape(mb, T * A, *x.shape[3:])
+    assert torch.equal(o_obs.cpu().reshape(mb, T * A, F), prep(obs))
+    assert torch.equal(o_act.cpu().reshape(mb, T * A), prep(action))
+    assert torch.equal(o_val.cpu().reshape(mb, T * A), prep(val))
+    assert torch.equal(o_adv.cpu().reshape(mb, T * A), prep(adv))
+    sh = onets.shifted_actions(prep(action), K, A, torch.float32).argmax(-1).int()
+    assert torch.equal(o_prev.cpu().reshape(mb, T * A), sh)
+    assert torch.equal(o_pos.cpu().reshape(mb, T, A)[:, :, 0], sc.index_select(1, env_idx.long()).T)
+    assert torch.equal(o_done.cpu(), done.index_select(1, env_idx.long()).T)
+    assert torch.equal(o_h0.cpu().reshape(mb, A), env_idx[:, None] * A + ap[None, :])
