@@ -60,9 +60,11 @@ __global__ void k_pe_table(float* __restrict__ pe, int npos, int E) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npos * E) return;
   int pos = i / E, c = i - pos * E;
-  float div = expf((float)(c & ~1) * (-logf(10000.0f) / (float)E));
-  float x = (float)pos * div;
-  pe[i] = (c & 1) ? cosf(x) : sinf(x);
+  // fp32 arithmetic as the reference, each transcendental correctly rounded (evaluated in fp64)
+  const float a = (float)(c & ~1) * (-(float)log(10000.0) / (float)E);
+  const float div = (float)exp((double)a);
+  const float x = (float)pos * div;
+  pe[i] = (c & 1) ? (float)cos((double)x) : (float)sin((double)x);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -86,7 +86,7 @@ def _pe_table(L, st, npos=101):
 def test_pe_table(L, stream):
     pe = _pe_table(L, stream)
     ref = onets.positional_encoding(torch.arange(101), 64, torch.float32)
-    close(pe, ref, 0, 2e-6, "pe")
+    close(pe, ref, 0, 1e-5, "pe")  # fp32 exp/sin ulp x position <= 100
 
 
 def _slabsum(slab):
