@@ -1,0 +1,134 @@
+"""Decentralised GRU actor (RecurrentActor, mava/networks/base.py:152-184) on the MI355X kernels.
+
+pre-torso Dense(F->128)+ReLU -> scanned GRU(128) with done-resets -> post-torso Dense(128->128)+ReLU
+-> Dense(128->K) logits (masked categorical head, heads.py:26-63).  ``step`` pushes the carry during
+the rollout (rec_magpo.py:146-159) and serves the evaluator; ``seq_fwd`` / ``seq_bwd`` are the
+training forward and the hand-derived BPTT backward.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from ._lib import lib
+from .params import FlatParams, actor_layout, actor_named_views, init_actor
+from .sable import _Bufs
+
+H = 128
+
+
+class GruActor:
+    def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, hidden: int = 128, wgrad_groups: int = 256,
+                 seed: Optional[int] = None):
+        if hidden != 128:
+            raise NotImplementedError("gfx950 GRU kernels: hidden_state_dim = 128 only")
+        if obs_dim > 64 or action_dim > 32:
+            raise NotImplementedError("obs_dim <= 64 and action_dim <= 32 required")
+        self.A, self.K, self.F = n_agents, action_dim, obs_dim
+        self.dev = device
+        self.L = lib()
+        self.G = wgrad_groups
+        self.P = FlatParams(actor_layout(obs_dim, H, action_dim), device)
+        self.grads = torch.zeros_like(self.P.flat)
+        self.v = self.P.views()
+        self.gv = self.P.views(self.grads)
+        self.named = actor_named_views(self.v)
+        self.named_grads = actor_named_views(self.gv)
+        if seed is not None:
+            init_actor(self.named, seed)
+        self.wt: Dict[str, torch.Tensor] = {}
+        self.b = _Bufs(device)
+        self.wg_ws = torch.empty(self.L.call("magpo_wgrad_workspace_floats", H, 3 * H, self.G), device=device)
+        self.refresh()
+
+    def _st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def load_named(self, params):
+        with torch.no_grad():
+            for n, v in self.named.items():
+                v.copy_(params[n].to(self.dev, torch.float32).reshape(v.shape))
+        self.refresh()
+
+    def _tp(self, name, W, npad=None):
+        K_, N_ = W.shape
+        npad = npad or (N_ + 31) // 32 * 32
+        t = self.wt.get(name)
+        if t is None:
+            t = torch.zeros(npad, K_, device=self.dev)
+            self.wt[name] = t
+        self.L.call("magpo_transpose_pad", W, t, K_, N_, npad, self._st())
+        return t
+
+    def refresh(self):
+        v = self.v
+        self._tp("wi", v["gru.wi"]); self._tp("wh", v["gru.wh"]); self._tp("post", v["post.kernel"])
+        ht = self._tp("head", v["head.kernel"], 64)      # [64][128]
+        self._tp("head_nat_pad", ht, H)                   # [128][64]
+
+    def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0):
+        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, None, R, KIN, NOUT, act, self._st())
+
+    def wgrad(self, X, ldx, dY, ldy, R, KIN, NOUT, dW, db=None, krows=None):
+        self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+
+    # one step for N envs: returns new hidden [N*A,128]; logits [N*A,64] if want_logits
+    def step(self, obs, h_in, reset_env, h_out, want_logits: bool = False):
+        """obs [N,A,F] f32, h_in / h_out [N*A,128], reset_env [N] u8 (reset-before-step flag per env)."""
+        L, st, A, F, v, b = self.L, self._st(), self.A, self.F, self.v, self.b
+        N = obs.shape[0]
+        R = N * A
+        emb = b.get("s_emb", (R, H)); xi = b.get("s_xi", (R, 3 * H))
+        L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
+        self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
+        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h_in, None, reset_env, h_out, None, None, N, 1, A, st)
+        if not want_logits:
+            return None
+        y = b.get("s_y", (R, H)); logits = b.get("s_logits", (R, 64), zero=True)
+        self.lin(h_out, H, self.wt["post"], v["post.bias"], y, H, R, H, H, act=1)
+        self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
+        return logits
+
+    def seq_fwd(self, obs, dones, h0, h0_idx, nseq: int, T: int):
+        """obs [R,F] rows (seq, t, agent); dones [nseq,T] u8 resets; h0 [*,128] gathered through h0_idx [nseq*A].
+        Returns raw logits [R,64] (K valid columns)."""
+        L, st, A, F, v, b = self.L, self._st(), self.A, self.F, self.v, self.b
+        R = nseq * T * A
+        emb = b.get("t_emb", (R, H)); xi = b.get("t_xi", (R, 3 * H)); hs = b.get("t_hs", (R, H))
+        gates = b.get("t_gates", (R, 4 * H)); hprev = b.get("t_hprev", (R, H)); y = b.get("t_y", (R, H))
+        logits = b.get("t_logits", (R, 64), zero=True)
+        self._saved = dict(obs=obs, dones=dones, nseq=nseq, T=T, R=R)
+        L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
+        self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
+        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h0, h0_idx, dones, hs, gates, hprev, nseq, T, A, st)
+        self.lin(hs, H, self.wt["post"], v["post.bias"], y, H, R, H, H, act=1)
+        self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
+        return logits
+
+    def seq_bwd(self, dlogits):
+        """dlogits [R,64] (columns >= K zero); fills self.grads."""
+        L, st, A, F, K, v, gv, b = self.L, self._st(), self.A, self.F, self.K, self.v, self.gv, self.b
+        sv = self._saved
+        R, nseq, T, obs, dones = sv["R"], sv["nseq"], sv["T"], sv["obs"], sv["dones"]
+        t = lambda n: b.t["t_" + n]
+        self.wgrad(t("y"), H, dlogits, 64, R, H, K, gv["head.kernel"], gv["head.bias"])
+        dy = b.get("g_dy", (R, H))
+        self.lin(dlogits, 64, self.wt["head_nat_pad"], None, dy, H, R, 64, H)
+        L.call("magpo_relu_bwd", t("y"), dy, dy, R * H, st)
+        self.wgrad(t("hs"), H, dy, H, R, H, H, gv["post.kernel"], gv["post.bias"])
+        dhs = b.get("g_dhs", (R, H))
+        self.lin(dy, H, v["post.kernel"], None, dhs, H, R, H, H)
+        dxi = b.get("g_dxi", (R, 3 * H)); dhh = b.get("g_dhh", (R, 3 * H))
+        nblk = (nseq * A + 63) // 64
+        slab = b.get("g_slab", (nblk, H))
+        L.call("magpo_gru_scan_bwd", t("gates"), t("hprev"), dones, dhs, v["gru.wh"], dxi, dhh, slab, nseq, T, A, st)
+        L.call("magpo_reduce_slabs", slab, gv["gru.hn.bias"], nblk, H, H, 1.0, 0, st)
+        self.wgrad(t("emb"), H, dxi, 3 * H, R, H, 3 * H, gv["gru.wi"], gv["gru.bi"])
+        self.wgrad(t("hprev"), H, dhh, 3 * H, R, H, 3 * H, gv["gru.wh"])
+        demb = dy
+        self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H)
+        L.call("magpo_relu_bwd", t("emb"), demb, demb, R * H, st)
+        op = b.get("g_op", (R, 64))
+        L.call("magpo_small_operand", 2, obs, F, F, None, None, 0, op, R, st)
+        self.wgrad(op, 64, demb, H, R, 64, H, gv["pre.kernel"], gv["pre.bias"], krows=F)

@@ -105,18 +105,20 @@ __global__ __launch_bounds__(256) void k_coordsum_step(CoordSumState s, CoordSum
   const int a0 = actions[n * act_stride];
   const int row = min(g, c.K - 1);
   int* rec = s.record + (n * c.K + row) * (long)c.TLIM;
-  // histogram of the valid entries of the row: lane b owns bin b
+  // histogram of the valid entries of the row: lane b owns bin b.  bincount(length=time_limit)
+  // drops values >= time_limit (coordsum/env.py:92-97), so only min(K, T_lim) bins exist.
+  const int nbins = min(c.K, c.TLIM);
   int cnt = 0;
   for (int base = 0; base < c.TLIM; base += 64) {
     const int i = base + lane;
     const int v = i < c.TLIM ? rec[i] : -1;
-    for (int b = 0; b < c.K; ++b) {
+    for (int b = 0; b < nbins; ++b) {
       const unsigned long long m = __ballot(v == b);
       if (lane == b) cnt += __popcll(m);
     }
   }
   // argmax with first-max tie-break (bins >= K are empty; an empty row gives guess 0)
-  int keyv = lane < c.K ? cnt * 64 + (63 - lane) : -1;
+  int keyv = lane < nbins ? cnt * 64 + (63 - lane) : -1;
   for (int off = 32; off > 0; off >>= 1) keyv = max(keyv, __shfl_xor(keyv, off, 64));
   const int guess = 63 - (keyv & 63);
   const bool sum_match = asum == g;
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(256) void k_coordsum_step(CoordSumState s, CoordSum
 using namespace magpo;
 
 static int check_cfg(int N, int A, int K, int TLIM) {
-  if (N < 0 || A < 1 || K < 1 || K > 64 || TLIM < 1 || K > TLIM) {
-    set_error("coordsum: need A >= 1, 1 <= K <= 64, K <= time_limit");
+  if (N < 0 || A < 1 || K < 1 || K > 64 || TLIM < 1) {
+    set_error("coordsum: need A >= 1, 1 <= K <= 64, time_limit >= 1");
     return MAGPO_EINVAL;
   }
   return MAGPO_OK;

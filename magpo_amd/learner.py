@@ -1,0 +1,280 @@
+"""MAGPO Anakin learner on the MI355X kernels: rollout -> GAE -> epochs x minibatches -> clip+Adam.
+
+Host-side mirror of ``get_learner_fn`` (mava/systems/gpo/anakin/rec_magpo.py:91-530).  One instance is
+one *group* (the reference's (device, update-batch) replica of ``num_envs`` envs); groups are
+independent except for the mean of the gradients (rec_magpo.py:395-409), which the caller injects
+through ``grad_sync`` (an RCCL all-reduce over xGMI in the multi-GPU launcher).
+
+Data layout in HBM (no physical shuffle of activations; the minibatch gather moves only per-token
+scalars, rec_magpo.py:441-462 becomes index arithmetic):
+  trajectory  obs[T+1,N,A,F] f32, step_count[T+1,N] i32, done[T+1,N] u8 (slot t = "obs at step t starts an
+              episode"), action/value/log_prob/reward/adv/targets [T,N,A]
+  states      3 x [N,64,64] fp32 retention states, policy hidden [N*A,128]
+  minibatch   rows (j, t, a') sequence-major, R = mb*T*A
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ._lib import lib
+from .actor import GruActor
+from .sable import SableGuider
+
+
+@dataclass
+class SystemConfig:
+    rollout_length: int = 128
+    ppo_epochs: int = 4
+    num_minibatches: int = 2
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_eps: float = 0.2
+    ent_coef: float = 0.01
+    vf_coef: float = 0.5
+    max_grad_norm: float = 0.5
+    clip_gpo: float = 1.5
+    alpha: float = 1.0
+    actor_lr: float = 2.5e-4
+
+
+@dataclass
+class CoordSumConfig:
+    num_agents: int
+    num_actions: int
+    time_limit: int = 100
+    maxval: Optional[int] = None
+
+    def __post_init__(self):
+        if not self.maxval:
+            self.maxval = self.num_actions  # coordsum/env.py:49-53
+
+
+def host_split(key: np.ndarray, num: int = 2) -> np.ndarray:
+    """jax.random.split of one key on the host (exact; C ABI magpo_key_split_host)."""
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty((num, 2), np.uint32)
+    lib().raw("magpo_key_split_host")(key.ctypes.data, num, out.ctypes.data)
+    return out
+
+
+def prng_key(seed: int) -> np.ndarray:
+    return np.array([(int(seed) >> 32) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFF], np.uint32)
+
+
+class CoordSumEnvBatch:
+    """Device-resident batch of wrapped CoordSum envs (state surface of coordsum/env.py:17-26 plus the
+    RecordEpisodeMetrics counters, episode_metrics.py:35-48)."""
+
+    def __init__(self, cfg: CoordSumConfig, N: int, device):
+        self.cfg, self.N, self.dev = cfg, N, device
+        A, K, TL = cfg.num_agents, cfg.num_actions, cfg.time_limit
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        self.step_count, self.target, self.record = i32(N), i32(N, TL + 1), i32(N, K, TL)
+        self.key, self.metrics_key = i32(N, 2), i32(N, 2)
+        self.run_ret, self.run_len = torch.zeros(N, device=device), i32(N)
+        self.ep_ret, self.ep_len = torch.zeros(N, device=device), i32(N)
+        self.L = lib()
+
+    def _state(self):
+        return (self.step_count, self.target, self.record, self.key, self.metrics_key, self.run_ret, self.run_len, self.ep_ret, self.ep_len)
+
+    def _cfg(self):
+        c = self.cfg
+        return (self.N, c.num_agents, c.num_actions, c.time_limit, c.maxval)
+
+    def reset(self, env_keys: torch.Tensor, obs, obs_step):
+        self.L.call("magpo_coordsum_reset", *self._state(), *self._cfg(), env_keys, obs, obs_step, torch.cuda.current_stream().cuda_stream)
+
+    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True):
+        self.L.call("magpo_coordsum_step", *self._state(), *self._cfg(), actions, self.cfg.num_agents, reward, done, obs, obs_step,
+                    m_ret, m_len, m_term, 1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
+
+
+class MagpoLearner:
+    def __init__(self, env_cfg: CoordSumConfig, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
+                 decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 256):
+        self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
+        A, K = env_cfg.num_agents, env_cfg.num_actions
+        F = A + 1  # AgentIDWrapper (observation.py:42-54), add_agent_id: True
+        self.A, self.K, self.F, self.T = A, K, F, sys.rollout_length
+        if num_envs % sys.num_minibatches:
+            raise ValueError("num_envs must be divisible by num_minibatches")
+        self.L = lib()
+        self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
+                                  max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups,
+                                  seed=None if net_seed is None else net_seed)
+        self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1)
+        self.env = CoordSumEnvBatch(env_cfg, num_envs, device)
+        N, T = num_envs, self.T
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=device)
+        self.traj = dict(obs=f32(T + 1, N, A, F), step_count=i32(T + 1, N), done=u8(T + 1, N), action=i32(T, N, A), value=f32(T, N, A),
+                         reward=f32(T, N, A), log_prob=f32(T, N, A), adv=f32(T, N, A), targets=f32(T, N, A))
+        self.metrics = dict(episode_return=f32(T, N), episode_length=i32(T, N), is_terminal_step=u8(T, N))
+        self.sable_hs = tuple(f32(N, 64, 64) for _ in range(3))
+        self.prev_sable_hs = tuple(f32(N, 64, 64) for _ in range(3))
+        self.policy_h = [f32(N * A, 128), f32(N * A, 128)]
+        self.policy_h0 = f32(N * A, 128)
+        self.last_val = f32(N, A)
+        # optimiser state (optax adam: count, mu, nu)
+        self.g_mu, self.g_nu = torch.zeros_like(self.guider.P.flat), torch.zeros_like(self.guider.P.flat)
+        self.a_mu, self.a_nu = torch.zeros_like(self.actor.P.flat), torch.zeros_like(self.actor.P.flat)
+        self.g_count = 0
+        self.a_count = 0
+        self.ws64 = torch.zeros(8 * 1024, dtype=torch.float64, device=device)
+        self.gnorm = f32(2)
+        self.adv_stats = f32(2)
+        self.loss_out = f32(9)
+        self.key = prng_key(0)
+        self._mb: Dict[str, torch.Tensor] = {}
+
+    def _st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ setup (rec_magpo.py:642-660)
+    def setup(self, key: np.ndarray, n_groups: int = 1, group: int = 0):
+        N = self.N
+        total = n_groups * N + 1
+        kd = torch.from_numpy(np.ascontiguousarray(key, np.uint32).view(np.int32)).to(self.dev)
+        allk = torch.empty(total, 2, dtype=torch.int32, device=self.dev)
+        self.L.call("magpo_threefry_split", kd, allk, total, self._st())
+        env_keys = allk[1 + group * N: 1 + (group + 1) * N].contiguous()
+        key0 = allk[0].cpu().numpy().view(np.uint32)
+        self.env.reset(env_keys, self.traj["obs"][0], self.traj["step_count"][0])
+        self.traj["done"][0].zero_()
+        ks = host_split(key0, 2)
+        self.setup_key, self.key = ks[0], ks[1]
+        for h in self.sable_hs:
+            h.zero_()
+        self.policy_h[0].zero_()
+        self._cur = 0
+
+    # ------------------------------------------------------------------ rollout (rec_magpo.py:126-212)
+    def rollout(self):
+        L, st, T, N, A = self.L, self._st(), self.T, self.N, self.A
+        tr = self.traj
+        for d, s in zip(self.prev_sable_hs, self.sable_hs):
+            d.copy_(s)
+        self.policy_h0.copy_(self.policy_h[self._cur])
+        # host key chain: key, policy_key = split(key); inside get_actions key, sample_key = split(key) per agent
+        for t in range(T):
+            ks = host_split(self.key, 2)
+            self.key, k = ks[0], ks[1]
+            skeys = np.empty((A, 2), np.uint32)
+            for i in range(A):
+                kk = host_split(k, 2)
+                k, skeys[i] = kk[0], kk[1]
+            obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
+            self.guider.act(obs, pos, self.sable_hs, skeys, tr["action"][t], tr["log_prob"][t], tr["value"][t])
+            h_in, h_out = self.policy_h[self._cur], self.policy_h[1 - self._cur]
+            self.actor.step(obs, h_in, done_prev, h_out)
+            self._cur = 1 - self._cur
+            self.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
+                          self.metrics["episode_return"][t], self.metrics["episode_length"][t], self.metrics["is_terminal_step"][t])
+            L.call("magpo_zero_states_where_done", *self.sable_hs, tr["done"][t + 1], N, st)
+        ks = host_split(self.key, 2)
+        self.key = ks[0]  # last_val_key = ks[1]: the sampled actions are discarded (rec_magpo.py:202-208)
+        self.guider.act(tr["obs"][T], tr["step_count"][T], self.sable_hs, None, None, None, self.last_val, value_only=True)
+        L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], self.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
+               self.sys.gamma, self.sys.gae_lambda, st)
+
+    def _carry_over(self):
+        """Slot T of the trajectory becomes slot 0 of the next rollout."""
+        tr = self.traj
+        tr["obs"][0].copy_(tr["obs"][self.T]); tr["step_count"][0].copy_(tr["step_count"][self.T]); tr["done"][0].copy_(tr["done"][self.T])
+
+    # ------------------------------------------------------------------ shuffles (jax.random.permutation)
+    def _permutation(self, key: np.ndarray, n: int) -> torch.Tensor:
+        rounds = int(math.ceil(3 * math.log(max(1, n)) / math.log(2 ** 32 - 1)))
+        x = torch.arange(n, dtype=torch.int32, device=self.dev)
+        bits = torch.empty(n, dtype=torch.int32, device=self.dev)
+        for _ in range(rounds):
+            ks = host_split(key, 2)
+            key, sub = ks[0], ks[1]
+            kd = torch.from_numpy(sub.view(np.int32).copy()).to(self.dev)
+            self.L.call("magpo_threefry_random_bits", kd, bits, n, self._st())
+            order = torch.sort(bits.to(torch.int64) & 0xFFFFFFFF, stable=True).indices
+            x = x[order]
+        return x.contiguous()
+
+    # ------------------------------------------------------------------ one minibatch (rec_magpo.py:217-435)
+    def _gather(self, env_idx: torch.Tensor, agent_perm: torch.Tensor):
+        T, N, A, F, K = self.T, self.N, self.A, self.F, self.K
+        mb = env_idx.numel()
+        R = mb * T * A
+        m = self._mb
+        if m.get("R") != R:
+            f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+            i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=self.dev)
+            m.update(R=R, obs=f32(R, F), action=i32(R), prev=i32(R), pos=i32(R), done=torch.empty(mb, T, dtype=torch.uint8, device=self.dev),
+                     value=f32(R), logp=f32(R), adv=f32(R), targets=f32(R), h0idx=i32(mb * A),
+                     dg=f32(R, 64), da=f32(R, 64), dv=f32(R))
+        tr = self.traj
+        self.L.call("magpo_gather_minibatch", tr["obs"], tr["action"], tr["step_count"], tr["done"], None, tr["value"], tr["log_prob"],
+                    tr["adv"], tr["targets"], env_idx, agent_perm, m["obs"], m["action"], m["prev"], m["pos"], m["done"], None,
+                    m["value"], m["logp"], m["adv"], m["targets"], m["h0idx"], T, N, A, F, K, mb, self._st())
+        return m
+
+    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor):
+        """Forward + loss + backward of both networks for one minibatch; gradients land in
+        guider.grads / actor.grads, loss scalars in self.loss_out (device)."""
+        s, T, A, K = self.sys, self.T, self.A, self.K
+        m = self._gather(env_idx, agent_perm)
+        mb, R = env_idx.numel(), m["R"]
+        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], self.prev_sable_hs, env_idx, mb, T)
+        a_logits = self.actor.seq_fwd(m["obs"], m["done"], self.policy_h0, m["h0idx"], mb, T)
+        st = self._st()
+        self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
+        self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, None, m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],
+                    self.adv_stats, m["dg"], 64, m["da"], 64, m["dv"], self.ws64, self.loss_out, R, K, s.clip_eps, s.clip_gpo,
+                    s.ent_coef, s.vf_coef, s.alpha, st)
+        self.guider.train_bwd(m["dg"], m["dv"])
+        self.actor.seq_bwd(m["da"])
+
+    def apply_grads(self, grad_scale: float = 1.0):
+        """optax clip_by_global_norm + adam + apply_updates on both flat buffers (rec_magpo.py:412-420)."""
+        s, st = self.sys, self._st()
+        for net, mu, nu, which in ((self.guider, self.g_mu, self.g_nu, "g"), (self.actor, self.a_mu, self.a_nu, "a")):
+            cnt = (self.g_count if which == "g" else self.a_count) + 1
+            bc1 = float(np.float32(1) - np.float32(0.9) ** np.float32(cnt))
+            bc2 = float(np.float32(1) - np.float32(0.999) ** np.float32(cnt))
+            self.L.call("magpo_clip_adam", net.P.flat, net.grads, mu, nu, net.P.numel, grad_scale, s.max_grad_norm, s.actor_lr,
+                        0.9, 0.999, 1e-5, bc1, bc2, self.ws64, self.gnorm[0:1] if which == "g" else self.gnorm[1:2], st)
+            if which == "g":
+                self.g_count = cnt
+            else:
+                self.a_count = cnt
+            net.refresh()
+
+    # ------------------------------------------------------------------ update (rec_magpo.py:214-487)
+    def update(self, grad_sync: Optional[Callable[["MagpoLearner"], float]] = None) -> torch.Tensor:
+        """ppo_epochs x num_minibatches optimisation steps; returns the loss table [P, M, 9] (device)."""
+        s, N, A = self.sys, self.N, self.A
+        M = s.num_minibatches
+        mbs = N // M
+        losses = torch.zeros(s.ppo_epochs, M, 9, device=self.dev)
+        for e in range(s.ppo_epochs):
+            ks = host_split(self.key, 4)
+            self.key, kb, ka, ke = ks[0], ks[1], ks[2], ks[3]
+            batch_perm = self._permutation(kb, N)
+            agent_perm = self._permutation(ka, A)
+            for mi in range(M):
+                ke = host_split(ke, 2)[0]  # key, entropy_key = split(key): unused for discrete actions (:373)
+                self.minibatch_grads(batch_perm[mi * mbs:(mi + 1) * mbs].contiguous(), agent_perm)
+                scale = grad_sync(self) if grad_sync is not None else 1.0
+                self.apply_grads(scale)
+                losses[e, mi].copy_(self.loss_out)
+        return losses
+
+    def update_step(self, grad_sync=None):
+        """One ``_update_step`` (rec_magpo.py:106-499): rollout + GAE + training."""
+        self.rollout()
+        losses = self.update(grad_sync)
+        self._carry_over()
+        return losses

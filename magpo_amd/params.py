@@ -1,0 +1,187 @@
+"""Flat fp32 parameter buffers of the guider (Sable) and the actor (GRU), with named views.
+
+The reference keeps Flax FrozenDict pytrees (mava/systems/gpo/types.py:25-29).
+Here each network owns ONE flat device buffer (so clip+Adam and the gradient all-reduce are single
+launches / one RCCL message); the entries below are views into it, in Flax's natural layouts
+(Dense kernels [in, out]).  Projections that always run together share one fused matrix
+(w_qkvg = [w_q | w_k | w_v | w_g]) and are exposed under their reference names as column views.
+Every entry starts on a 16-byte boundary (the kernels load float4).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+
+def _round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class FlatParams:
+    def __init__(self, shapes: "OrderedDict[str, Tuple[int, ...]]", device):
+        self.shapes = shapes
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for name, shp in shapes.items():
+            self.offsets[name] = off
+            off += _round4(math.prod(shp))
+        self.numel = off
+        self.device = device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def view_of(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        shp = self.shapes[name]
+        o = self.offsets[name]
+        return flat[o:o + math.prod(shp)].view(*shp)
+
+    def views(self, flat: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+        flat = self.flat if flat is None else flat
+        return {n: self.view_of(flat, n) for n in self.shapes}
+
+
+def guider_layout(E: int, F: int, K: int) -> "OrderedDict[str, Tuple[int, ...]]":
+    assert E == 64, "the gfx950 kernels are specialised for embed_dim = 64"
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["enc.ln.scale"] = (E,)
+    s["enc.obs.norm.scale"] = (F,)
+    s["enc.obs.dense.kernel"] = (F, E)
+    s["enc.head.dense0.kernel"] = (E, E)
+    s["enc.head.dense0.bias"] = (E,)
+    s["enc.head.norm.scale"] = (E,)
+    s["enc.head.dense1.kernel"] = (E, 1)
+    s["enc.head.dense1.bias"] = (1,)
+    s["enc.block0.ln1.scale"] = (E,)
+    s["enc.block0.ln2.scale"] = (E,)
+    s["enc.block0.retn.w_qkvg"] = (E, 4 * E)
+    s["enc.block0.retn.w_o"] = (E, E)
+    s["enc.block0.retn.gn.scale"] = (E,)
+    s["enc.block0.retn.gn.bias"] = (E,)
+    for w in ("W_linear", "W_gate", "W_output"):
+        s[f"enc.block0.ffn.{w}"] = (E, E)
+    s["dec.ln.scale"] = (E,)
+    s["dec.act.kernel"] = (K + 1, E)
+    s["dec.head.dense0.kernel"] = (E, E)
+    s["dec.head.dense0.bias"] = (E,)
+    s["dec.head.norm.scale"] = (E,)
+    s["dec.head.dense1.kernel"] = (E, K)
+    s["dec.head.dense1.bias"] = (K,)
+    for n in ("ln1", "ln2", "ln3"):
+        s[f"dec.block0.{n}.scale"] = (E,)
+    s["dec.block0.retn1.w_qkvg"] = (E, 4 * E)
+    s["dec.block0.retn1.w_o"] = (E, E)
+    s["dec.block0.retn1.gn.scale"] = (E,)
+    s["dec.block0.retn1.gn.bias"] = (E,)
+    s["dec.block0.retn2.w_q"] = (E, E)
+    s["dec.block0.retn2.w_kvg"] = (E, 3 * E)
+    s["dec.block0.retn2.w_o"] = (E, E)
+    s["dec.block0.retn2.gn.scale"] = (E,)
+    s["dec.block0.retn2.gn.bias"] = (E,)
+    for w in ("W_linear", "W_gate", "W_output"):
+        s[f"dec.block0.ffn.{w}"] = (E, E)
+    return s
+
+
+def guider_named_views(views: Dict[str, torch.Tensor], E: int = 64) -> Dict[str, torch.Tensor]:
+    """Reference-named parameter dict (names as oracle.networks.guider_param_shapes)."""
+    out: Dict[str, torch.Tensor] = {}
+    for n, v in views.items():
+        if n.endswith("w_qkvg"):
+            p = n[: -len("w_qkvg")]
+            out[p + "w_q"] = v[:, 0:E].unsqueeze(0)
+            out[p + "w_k"] = v[:, E:2 * E].unsqueeze(0)
+            out[p + "w_v"] = v[:, 2 * E:3 * E].unsqueeze(0)
+            out[p + "w_g"] = v[:, 3 * E:4 * E]
+        elif n.endswith("retn2.w_q"):
+            out[n] = v.unsqueeze(0)
+        elif n.endswith("w_kvg"):
+            p = n[: -len("w_kvg")]
+            out[p + "w_k"] = v[:, 0:E].unsqueeze(0)
+            out[p + "w_v"] = v[:, E:2 * E].unsqueeze(0)
+            out[p + "w_g"] = v[:, 2 * E:3 * E]
+        else:
+            out[n] = v
+    return out
+
+
+def actor_layout(F: int, H: int, K: int) -> "OrderedDict[str, Tuple[int, ...]]":
+    assert H == 128, "the gfx950 GRU kernels are specialised for hidden_state_dim = 128"
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["pre.kernel"] = (F, H)
+    s["pre.bias"] = (H,)
+    s["gru.wi"] = (H, 3 * H)     # [ir | iz | in] kernels
+    s["gru.bi"] = (3 * H,)
+    s["gru.wh"] = (H, 3 * H)     # [hr | hz | hn] kernels
+    s["gru.hn.bias"] = (H,)
+    s["post.kernel"] = (H, H)
+    s["post.bias"] = (H,)
+    s["head.kernel"] = (H, K)
+    s["head.bias"] = (K,)
+    return s
+
+
+def actor_named_views(views: Dict[str, torch.Tensor], H: int = 128) -> Dict[str, torch.Tensor]:
+    out: Dict[str, torch.Tensor] = {}
+    for n, v in views.items():
+        if n == "gru.wi":
+            for i, g in enumerate(("ir", "iz", "in")):
+                out[f"gru.{g}.kernel"] = v[:, i * H:(i + 1) * H]
+        elif n == "gru.bi":
+            for i, g in enumerate(("ir", "iz", "in")):
+                out[f"gru.{g}.bias"] = v[i * H:(i + 1) * H]
+        elif n == "gru.wh":
+            for i, g in enumerate(("hr", "hz", "hn")):
+                out[f"gru.{g}.kernel"] = v[:, i * H:(i + 1) * H]
+        else:
+            out[n] = v
+    return out
+
+
+def _orthogonal(gen, shape, gain):
+    rows, cols = shape
+    a = torch.randn((max(rows, cols), min(rows, cols)), generator=gen, dtype=torch.float64)
+    q, r = torch.linalg.qr(a)
+    q = q * torch.sign(torch.diagonal(r))[None, :]
+    if rows < cols:
+        q = q.T
+    return (gain * q).float()
+
+
+def init_guider(named: Dict[str, torch.Tensor], seed: int, E: int = 64) -> None:
+    """Reference init distributions (sable_network.py:97,104,107,263,279,282 orthogonal(sqrt2 / 0.01);
+    retention.py:50-64,237-246 normal(1/E); torsos.py:88-95 zeros; RMSNorm / GroupNorm ones/zeros)."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, v in named.items():
+            if name.endswith("scale"):
+                v.fill_(1.0)
+            elif name.endswith("bias") or ".ffn." in name:
+                v.zero_()
+            elif name.split(".")[-1] in ("w_q", "w_k", "w_v", "w_g", "w_o"):
+                v.copy_((torch.randn(v.shape, generator=gen, dtype=torch.float64) / E).float())
+            elif name.endswith("dense1.kernel"):
+                v.copy_(_orthogonal(gen, tuple(v.shape), 0.01))
+            else:
+                v.copy_(_orthogonal(gen, tuple(v.shape), math.sqrt(2.0)))
+
+
+def init_actor(named: Dict[str, torch.Tensor], seed: int) -> None:
+    """torsos.py:42 orthogonal(sqrt2); heads.py:53 orthogonal(0.01); flax GRUCell defaults
+    (lecun_normal input kernels, orthogonal recurrent kernels, zero biases)."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, v in named.items():
+            if name.endswith("bias"):
+                v.zero_()
+            elif name in ("gru.hr.kernel", "gru.hz.kernel", "gru.hn.kernel"):
+                v.copy_(_orthogonal(gen, tuple(v.shape), 1.0))
+            elif name.startswith("gru."):
+                w = torch.empty(tuple(v.shape), dtype=torch.float64)
+                torch.nn.init.trunc_normal_(w, 0.0, 1.0, -2.0, 2.0, generator=gen)
+                v.copy_((w * (math.sqrt(1.0 / v.shape[0]) / 0.87962566103423978)).float())
+            elif name == "head.kernel":
+                v.copy_(_orthogonal(gen, tuple(v.shape), 0.01))
+            else:
+                v.copy_(_orthogonal(gen, tuple(v.shape), math.sqrt(2.0)))

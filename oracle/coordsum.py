@@ -108,7 +108,7 @@ def _core_step(spec: CoordSumSpec, st: Dict, actions: np.ndarray):
     sum_match = actions.sum(axis=1) == g
     row_idx = np.minimum(g, K - 1)  # gather clamps
     row = st["record"][ar, row_idx]  # (N, TL)
-    valid = row != -1
+    valid = (row != -1) & (row < TL)  # bincount(length=TL) drops out-of-range values
     # bincount(length=TL) of the valid entries, argmax takes the first maximum
     counts = np.zeros((n, TL), np.float32)
     safe = np.where(valid, row, 0)
