@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MAGPO env-steps/sec on CoordSum-4ag, 16384 envs per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full ``_update_step`` of the reference learner (rec_magpo.py:106-499): a 128-step rollout of
+all envs (guider acting, actor push, env step), GAE, then ppo_epochs x num_minibatches optimisation steps of
+both networks (forward, fused losses, hand-written backward, gradient all-reduce across GPUs, clip + Adam).
+Nothing is skipped.  value = n_gpus * num_envs * rollout_length * K / wall (the reference's steps_per_second,
+rec_magpo.py:720-726,761), inputs resident in HBM, weak scaling (per-GPU envs fixed).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+PEAK_F32_MFMA_TF = 157.3   # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_f32)
+
+
+class KernelTimer:
+    """HIP-event timing of the heavy kernel families inside the timed region (events on the stream the
+    kernels are launched on = torch's current stream).  Cost model = ALGORITHMIC bytes / flops per launch
+    (DESIGN.md section 4), so re-reads and padding do not count as work."""
+
+    def __init__(self, min_rows: int):
+        self.min_rows = min_rows
+        self.rec = {}
+        self.pending = []
+        self.enabled = False
+
+    def _model(self, name, a):
+        if name == "magpo_linear":
+            R, KIN, NOUT = a[7], a[8], a[9]
+            if R < self.min_rows:
+                return None
+            return f"linear_k{KIN}", 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
+        if name == "magpo_wgrad":
+            R, KIN, NOUT = a[4], a[5], a[7]
+            if R < self.min_rows:
+                return None
+            return "wgrad", 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
+        if name in ("magpo_retention_chunk_fwd", "magpo_retention_chunk_bwd"):
+            fwd = name.endswith("fwd")
+            nseq, T, A = (a[13], a[14], a[15]) if fwd else (a[16], a[17], a[18])
+            lt = 64 // A
+            nch = (T + lt - 1) // lt
+            gemms = 4 if fwd else 9
+            rows = nseq * T * A
+            byts = 4.0 * rows * 64 * (4 if fwd else 7) + 4.0 * nseq * nch * 4096
+            return ("ret_chunk_fwd" if fwd else "ret_chunk_bwd"), byts, gemms * 2.0 * 64 ** 3 * nseq * nch
+        if name == "magpo_retention_recurrent":
+            nenv, ntok = a[10], a[11]
+            return "ret_recurrent", 4.0 * nenv * (2 * 4096 + 4 * ntok * 64), 4.0 * nenv * ntok * 4096 + 2.0 * nenv * 4096
+        if name == "magpo_gru_scan_fwd":
+            nseq, T, A = a[9], a[10], a[11]
+            if T == 1:
+                return None
+            rows = nseq * T * A
+            return "gru_scan_fwd", 4.0 * rows * (384 + 128 + 512 + 128), 2.0 * rows * 128 * 384
+        if name == "magpo_gru_scan_bwd":
+            nseq, T, A = a[8], a[9], a[10]
+            rows = nseq * T * A
+            return "gru_scan_bwd", 4.0 * rows * (512 + 128 + 128 + 768), 2.0 * rows * 384 * 128
+        if name == "magpo_loss_fwd_bwd":
+            R, K = a[19], a[20]
+            return "loss", 4.0 * R * (4 * K + 8), 60.0 * R * K
+        return None
+
+    def begin(self, name, args):
+        if not self.enabled:
+            return None
+        m = self._model(name, args)
+        if m is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (m, e0, e1)
+
+    def end(self, tok):
+        m, e0, e1 = tok
+        e1.record()
+        self.pending.append((m, e0, e1))
+
+    def collect(self):
+        torch.cuda.synchronize()
+        for (key, byts, flops), e0, e1 in self.pending:
+            r = self.rec.setdefault(key, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+            r["calls"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            r["bytes"] += byts
+            r["flops"] += flops
+        self.pending = []
+
+    def dominant(self):
+        if not self.rec:
+            return None, None
+        key = max(self.rec, key=lambda k: self.rec[k]["ms"])
+        r = self.rec[key]
+        avg_s = r["ms"] / r["calls"] / 1e3
+        gbs = r["bytes"] / r["calls"] / avg_s / 1e9
+        tfs = r["flops"] / r["calls"] / avg_s / 1e12
+        # the bound is whichever resource the algorithmic work needs longer at peak
+        if gbs / PEAK_HBM_GBS >= tfs / PEAK_F32_MFMA_TF:
+            roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
+        else:
+            roof = dict(bound="mfma", achieved=round(tfs, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(tfs / PEAK_F32_MFMA_TF, 4))
+        roof.update(kernel=key, avg_us=round(avg_s * 1e6, 1), calls=r["calls"], traffic=None)
+        table = {k: dict(calls=v["calls"], ms=round(v["ms"], 2), gbs=round(v["bytes"] / v["ms"] / 1e6, 1),
+                         tflops=round(v["flops"] / v["ms"] / 1e9, 2)) for k, v in sorted(self.rec.items(), key=lambda kv: -kv[1]["ms"])}
+        return roof, table
+
+
+def cpu_baseline(seconds_budget: float = 20.0):
+    """The CPU oracle (a torch-CPU port of the reference loop; the reference's own JAX path cannot run here:
+    jax / flax / jumanji are not installed) timed on this box's host cores on a bounded sample of the same
+    workload: CoordSum-4ag, same network sizes, rollout_length=128, 4 epochs x 2 minibatches, 16 envs."""
+    from oracle import coordsum as ocs
+    from oracle import learner as olearn
+    from oracle import networks as onets
+    from oracle import prng as oprng
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box gives one GPU a 16-core share; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    A, K, N = 4, 20, 16
+    ol = olearn.OracleLearner(ocs.CoordSumSpec(A, K, 100, 60), N, olearn.SystemCfg(), onets.SableCfg(A, K, A + 1),
+                              onets.init_guider_params(1, 64, A + 1, K), onets.init_actor_params(2, A + 1, 128, K))
+    ol.setup(oprng.split(oprng.prng_key(42), 4)[0])
+    t0 = time.time()
+    steps = 0
+    while True:
+        ol.update_step()
+        steps += 1
+        if time.time() - t0 > seconds_budget or steps >= 8:
+            break
+    dt = time.time() - t0
+    return dict(value=round(steps * N * 128 / dt, 1), unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{steps} full update step(s) of CoordSum-4ag at num_envs={N} (rollout 128, 4 epochs x 2 minibatches), "
+                       f"torch-CPU fp32 oracle, {cores} threads, {dt:.1f}s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from magpo_amd import distributed as mdist
+    from magpo_amd._lib import lib
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    import torch.distributed as dist
+
+    rank, world, local = mdist.init_from_env()
+    if world != args.gpus:
+        if args.gpus != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    sysc = SystemConfig()  # reference defaults (configs/system/gpo/rec_magpo.yaml)
+    env_cfg = CoordSumConfig(num_agents=4, num_actions=20, time_limit=100, maxval=60)
+    N = args.num_envs
+    learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0)  # same seed => replicated parameters on every rank
+    key = host_split(prng_key(42), 4)[0]
+    learner.setup(key, n_groups=world, group=rank)
+    grad_sync = mdist.make_grad_sync(world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    for i in range(args.warmup):
+        learner.update_step(grad_sync)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
+    timer = KernelTimer(min_rows=1 << 16)
+    if not args.no_kernel_timing and rank == 0:
+        lib().timer = timer
+        timer.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        learner.update_step(grad_sync)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    lib().timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
+    if rank == 0:
+        timer.collect()
+        roof, table = timer.dominant()
+        env_steps = world * N * sysc.rollout_length * args.steps
+        out = {
+            "metric": "env-steps/sec (all agents stepping jointly), CoordSum-4ag, full MAGPO update loop",
+            "value": round(env_steps / elapsed, 1),
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (fixed-seed CoordSum episodes, random-init networks)",
+            "config": {"workload": f"CoordSum 4-agent (num_actions=20, maxval=60, time_limit=100), {N} envs/GPU x {world} GPU, "
+                                   "rollout_length=128, ppo_epochs=4, num_minibatches=2, Sable embed 64 / 1 head / 1 block, GRU 128",
+                       "agent_steps_per_s": round(env_steps * env_cfg.num_agents / elapsed, 1),
+                       "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},
+            "roofline": roof,
+            "kernel_table": table,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle baseline ...")
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,8 +70,20 @@ class _Lib:
     def raw(self, name):
         return getattr(self._dll, name)
 
+    timer = None  # optional object with .begin(name, args) -> token and .end(token) (bench.py instrumentation)
+
     def call(self, name: str, *args):
         """Call an int-status entry point; tensors are passed as their data_ptr()."""
+        if self.timer is not None:
+            tok = self.timer.begin(name, args)
+            if tok is not None:
+                try:
+                    return self._call(name, *args)
+                finally:
+                    self.timer.end(tok)
+        return self._call(name, *args)
+
+    def _call(self, name: str, *args):
         fn = getattr(self._dll, name)
         conv = []
         for a in args:

@@ -20,7 +20,7 @@ H = 128
 
 class GruActor:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, hidden: int = 128, wgrad_groups: int = 256,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
         if hidden != 128:
             raise NotImplementedError("gfx950 GRU kernels: hidden_state_dim = 128 only")
         if obs_dim > 64 or action_dim > 32:
@@ -30,7 +30,8 @@ class GruActor:
         self.L = lib()
         self.G = wgrad_groups
         self.P = FlatParams(actor_layout(obs_dim, H, action_dim), device)
-        self.grads = torch.zeros_like(self.P.flat)
+        self.grads = torch.zeros_like(self.P.flat) if grads is None else grads
+        assert self.grads.numel() == self.P.numel
         self.v = self.P.views()
         self.gv = self.P.views(self.grads)
         self.named = actor_named_views(self.v)

@@ -105,10 +105,17 @@ class MagpoLearner:
         if num_envs % sys.num_minibatches:
             raise ValueError("num_envs must be divisible by num_minibatches")
         self.L = lib()
+        # one contiguous buffer [guider grads | actor grads | loss scalars] = one all-reduce message (rec_magpo.py:395-409)
+        from .params import FlatParams, actor_layout, guider_layout
+        gn = FlatParams(guider_layout(64, F, K), "cpu").numel
+        an = FlatParams(actor_layout(F, 128, K), "cpu").numel
+        self.grad_all = torch.zeros(gn + an + 16, dtype=torch.float32, device=device)
         self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
                                   max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups,
-                                  seed=None if net_seed is None else net_seed)
-        self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1)
+                                  seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn])
+        self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
+                              grads=self.grad_all[gn:gn + an])
+        self.loss_out = self.grad_all[gn + an:gn + an + 9]
         self.env = CoordSumEnvBatch(env_cfg, num_envs, device)
         N, T = num_envs, self.T
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
@@ -130,7 +137,6 @@ class MagpoLearner:
         self.ws64 = torch.zeros(8 * 1024, dtype=torch.float64, device=device)
         self.gnorm = f32(2)
         self.adv_stats = f32(2)
-        self.loss_out = f32(9)
         self.key = prng_key(0)
         self._mb: Dict[str, torch.Tensor] = {}
 

@@ -44,7 +44,7 @@ class _Bufs:
 class SableGuider:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, embed_dim: int = 64, n_head: int = 1,
                  n_block: int = 1, decay_scaling_factor: float = 0.8, use_pe: bool = True, max_pos: int = 101,
-                 wgrad_groups: int = 256, seed: Optional[int] = None):
+                 wgrad_groups: int = 256, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
         if embed_dim != 64 or n_head != 1 or n_block != 1:
             raise NotImplementedError("gfx950 Sable kernels: embed_dim=64, n_head=1, n_block=1 only (SURVEY 8f rank 3)")
         if obs_dim > 32 or action_dim > 32:
@@ -55,7 +55,8 @@ class SableGuider:
         self.kappa = decay_kappa(1, decay_scaling_factor)
         self.G = wgrad_groups
         self.P = FlatParams(guider_layout(E, obs_dim, action_dim), device)
-        self.grads = torch.zeros_like(self.P.flat)
+        self.grads = torch.zeros_like(self.P.flat) if grads is None else grads
+        assert self.grads.numel() == self.P.numel
         self.v = self.P.views()
         self.gv = self.P.views(self.grads)
         self.named = guider_named_views(self.v)
