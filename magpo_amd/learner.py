@@ -95,9 +95,32 @@ class CoordSumEnvBatch:
                     m_ret, m_len, m_term, 1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
 
 
+class EnvGroup:
+    """Per-group rollout state: envs, trajectory, retention / GRU states, PRNG key.  A group is the
+    reference's (device, update-batch) replica (rec_magpo.py:519, :648-653); all groups of a process share
+    the parameters and the training workspaces."""
+
+    def __init__(self, env_cfg: CoordSumConfig, N: int, T: int, device):
+        A, F = env_cfg.num_agents, env_cfg.num_agents + 1
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=device)
+        self.env = CoordSumEnvBatch(env_cfg, N, device)
+        self.traj = dict(obs=f32(T + 1, N, A, F), step_count=i32(T + 1, N), done=u8(T + 1, N), action=i32(T, N, A), value=f32(T, N, A),
+                         reward=f32(T, N, A), log_prob=f32(T, N, A), adv=f32(T, N, A), targets=f32(T, N, A))
+        self.metrics = dict(episode_return=f32(T, N), episode_length=i32(T, N), is_terminal_step=u8(T, N))
+        self.sable_hs = tuple(f32(N, 64, 64) for _ in range(3))
+        self.prev_sable_hs = tuple(f32(N, 64, 64) for _ in range(3))
+        self.policy_h = [f32(N * A, 128), f32(N * A, 128)]
+        self.policy_h0 = f32(N * A, 128)
+        self.last_val = f32(N, A)
+        self.key = prng_key(0)
+        self.cur = 0
+
+
 class MagpoLearner:
     def __init__(self, env_cfg: CoordSumConfig, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
-                 decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 256):
+                 decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 256, num_groups: int = 1):
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
         F = A + 1  # AgentIDWrapper (observation.py:42-54), add_agent_id: True
@@ -110,25 +133,15 @@ class MagpoLearner:
         gn = FlatParams(guider_layout(64, F, K), "cpu").numel
         an = FlatParams(actor_layout(F, 128, K), "cpu").numel
         self.grad_all = torch.zeros(gn + an + 16, dtype=torch.float32, device=device)
+        self.grad_acc = torch.zeros_like(self.grad_all) if num_groups > 1 else None
         self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
                                   max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups,
                                   seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn])
         self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
                               grads=self.grad_all[gn:gn + an])
         self.loss_out = self.grad_all[gn + an:gn + an + 9]
-        self.env = CoordSumEnvBatch(env_cfg, num_envs, device)
-        N, T = num_envs, self.T
+        self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device) for _ in range(num_groups)]
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
-        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
-        u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=device)
-        self.traj = dict(obs=f32(T + 1, N, A, F), step_count=i32(T + 1, N), done=u8(T + 1, N), action=i32(T, N, A), value=f32(T, N, A),
-                         reward=f32(T, N, A), log_prob=f32(T, N, A), adv=f32(T, N, A), targets=f32(T, N, A))
-        self.metrics = dict(episode_return=f32(T, N), episode_length=i32(T, N), is_terminal_step=u8(T, N))
-        self.sable_hs = tuple(f32(N, 64, 64) for _ in range(3))
-        self.prev_sable_hs = tuple(f32(N, 64, 64) for _ in range(3))
-        self.policy_h = [f32(N * A, 128), f32(N * A, 128)]
-        self.policy_h0 = f32(N * A, 128)
-        self.last_val = f32(N, A)
         # optimiser state (optax adam: count, mu, nu)
         self.g_mu, self.g_nu = torch.zeros_like(self.guider.P.flat), torch.zeros_like(self.guider.P.flat)
         self.a_mu, self.a_nu = torch.zeros_like(self.actor.P.flat), torch.zeros_like(self.actor.P.flat)
@@ -137,63 +150,85 @@ class MagpoLearner:
         self.ws64 = torch.zeros(8 * 1024, dtype=torch.float64, device=device)
         self.gnorm = f32(2)
         self.adv_stats = f32(2)
-        self.key = prng_key(0)
         self._mb: Dict[str, torch.Tensor] = {}
+
+    # group-0 shortcuts (single-group callers and the parity tests)
+    env = property(lambda self: self.groups[0].env)
+    traj = property(lambda self: self.groups[0].traj)
+    metrics = property(lambda self: self.groups[0].metrics)
+    sable_hs = property(lambda self: self.groups[0].sable_hs)
+    policy_h = property(lambda self: self.groups[0].policy_h)
+    last_val = property(lambda self: self.groups[0].last_val)
+    _cur = property(lambda self: self.groups[0].cur)
+
+    @property
+    def key(self):
+        return self.groups[0].key
 
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
 
     # ------------------------------------------------------------------ setup (rec_magpo.py:642-660)
     def setup(self, key: np.ndarray, n_groups: int = 1, group: int = 0):
+        """``n_groups`` = total number of groups in the job (ranks x local groups), ``group`` = global index of
+        this process's first group.  Reset keys are rows 1.. of split(key, n_groups*N + 1) laid out row-major
+        over (group, env); ONE step key is shared by every group (rec_magpo.py:660-671)."""
         N = self.N
         total = n_groups * N + 1
         kd = torch.from_numpy(np.ascontiguousarray(key, np.uint32).view(np.int32)).to(self.dev)
         allk = torch.empty(total, 2, dtype=torch.int32, device=self.dev)
         self.L.call("magpo_threefry_split", kd, allk, total, self._st())
-        env_keys = allk[1 + group * N: 1 + (group + 1) * N].contiguous()
         key0 = allk[0].cpu().numpy().view(np.uint32)
-        self.env.reset(env_keys, self.traj["obs"][0], self.traj["step_count"][0])
-        self.traj["done"][0].zero_()
         ks = host_split(key0, 2)
-        self.setup_key, self.key = ks[0], ks[1]
-        for h in self.sable_hs:
-            h.zero_()
-        self.policy_h[0].zero_()
-        self._cur = 0
+        self.setup_key = ks[0]
+        for gi, g in enumerate(self.groups):
+            env_keys = allk[1 + (group + gi) * N: 1 + (group + gi + 1) * N].contiguous()
+            g.env.reset(env_keys, g.traj["obs"][0], g.traj["step_count"][0])
+            g.traj["done"][0].zero_()
+            g.key = ks[1].copy()
+            for h in g.sable_hs:
+                h.zero_()
+            g.policy_h[0].zero_()
+            g.cur = 0
 
     # ------------------------------------------------------------------ rollout (rec_magpo.py:126-212)
     def rollout(self):
+        for g in self.groups:
+            self._rollout_group(g)
+
+    def _rollout_group(self, g: EnvGroup):
         L, st, T, N, A = self.L, self._st(), self.T, self.N, self.A
-        tr = self.traj
-        for d, s in zip(self.prev_sable_hs, self.sable_hs):
+        tr = g.traj
+        for d, s in zip(g.prev_sable_hs, g.sable_hs):
             d.copy_(s)
-        self.policy_h0.copy_(self.policy_h[self._cur])
+        g.policy_h0.copy_(g.policy_h[g.cur])
         # host key chain: key, policy_key = split(key); inside get_actions key, sample_key = split(key) per agent
         for t in range(T):
-            ks = host_split(self.key, 2)
-            self.key, k = ks[0], ks[1]
+            ks = host_split(g.key, 2)
+            g.key, k = ks[0], ks[1]
             skeys = np.empty((A, 2), np.uint32)
             for i in range(A):
                 kk = host_split(k, 2)
                 k, skeys[i] = kk[0], kk[1]
             obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
-            self.guider.act(obs, pos, self.sable_hs, skeys, tr["action"][t], tr["log_prob"][t], tr["value"][t])
-            h_in, h_out = self.policy_h[self._cur], self.policy_h[1 - self._cur]
+            self.guider.act(obs, pos, g.sable_hs, skeys, tr["action"][t], tr["log_prob"][t], tr["value"][t])
+            h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
             self.actor.step(obs, h_in, done_prev, h_out)
-            self._cur = 1 - self._cur
-            self.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
-                          self.metrics["episode_return"][t], self.metrics["episode_length"][t], self.metrics["is_terminal_step"][t])
-            L.call("magpo_zero_states_where_done", *self.sable_hs, tr["done"][t + 1], N, st)
-        ks = host_split(self.key, 2)
-        self.key = ks[0]  # last_val_key = ks[1]: the sampled actions are discarded (rec_magpo.py:202-208)
-        self.guider.act(tr["obs"][T], tr["step_count"][T], self.sable_hs, None, None, None, self.last_val, value_only=True)
-        L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], self.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
+            g.cur = 1 - g.cur
+            g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
+                       g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t])
+            L.call("magpo_zero_states_where_done", *g.sable_hs, tr["done"][t + 1], N, st)
+        ks = host_split(g.key, 2)
+        g.key = ks[0]  # last_val_key = ks[1]: the sampled actions are discarded (rec_magpo.py:202-208)
+        self.guider.act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
+        L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], g.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
                self.sys.gamma, self.sys.gae_lambda, st)
 
     def _carry_over(self):
         """Slot T of the trajectory becomes slot 0 of the next rollout."""
-        tr = self.traj
-        tr["obs"][0].copy_(tr["obs"][self.T]); tr["step_count"][0].copy_(tr["step_count"][self.T]); tr["done"][0].copy_(tr["done"][self.T])
+        for g in self.groups:
+            tr = g.traj
+            tr["obs"][0].copy_(tr["obs"][self.T]); tr["step_count"][0].copy_(tr["step_count"][self.T]); tr["done"][0].copy_(tr["done"][self.T])
 
     # ------------------------------------------------------------------ shuffles (jax.random.permutation)
     def _permutation(self, key: np.ndarray, n: int) -> torch.Tensor:
@@ -210,7 +245,7 @@ class MagpoLearner:
         return x.contiguous()
 
     # ------------------------------------------------------------------ one minibatch (rec_magpo.py:217-435)
-    def _gather(self, env_idx: torch.Tensor, agent_perm: torch.Tensor):
+    def _gather(self, g: EnvGroup, env_idx: torch.Tensor, agent_perm: torch.Tensor):
         T, N, A, F, K = self.T, self.N, self.A, self.F, self.K
         mb = env_idx.numel()
         R = mb * T * A
@@ -221,20 +256,21 @@ class MagpoLearner:
             m.update(R=R, obs=f32(R, F), action=i32(R), prev=i32(R), pos=i32(R), done=torch.empty(mb, T, dtype=torch.uint8, device=self.dev),
                      value=f32(R), logp=f32(R), adv=f32(R), targets=f32(R), h0idx=i32(mb * A),
                      dg=f32(R, 64), da=f32(R, 64), dv=f32(R))
-        tr = self.traj
+        tr = g.traj
         self.L.call("magpo_gather_minibatch", tr["obs"], tr["action"], tr["step_count"], tr["done"], None, tr["value"], tr["log_prob"],
                     tr["adv"], tr["targets"], env_idx, agent_perm, m["obs"], m["action"], m["prev"], m["pos"], m["done"], None,
                     m["value"], m["logp"], m["adv"], m["targets"], m["h0idx"], T, N, A, F, K, mb, self._st())
         return m
 
-    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor):
-        """Forward + loss + backward of both networks for one minibatch; gradients land in
-        guider.grads / actor.grads, loss scalars in self.loss_out (device)."""
+    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group: int = 0):
+        """Forward + loss + backward of both networks for one minibatch of one group; gradients land in
+        guider.grads / actor.grads, loss scalars in self.loss_out (all inside self.grad_all, on device)."""
         s, T, A, K = self.sys, self.T, self.A, self.K
-        m = self._gather(env_idx, agent_perm)
+        g = self.groups[group]
+        m = self._gather(g, env_idx, agent_perm)
         mb, R = env_idx.numel(), m["R"]
-        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], self.prev_sable_hs, env_idx, mb, T)
-        a_logits = self.actor.seq_fwd(m["obs"], m["done"], self.policy_h0, m["h0idx"], mb, T)
+        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], g.prev_sable_hs, env_idx, mb, T)
+        a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T)
         st = self._st()
         self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
         self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, None, m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],
@@ -260,22 +296,36 @@ class MagpoLearner:
 
     # ------------------------------------------------------------------ update (rec_magpo.py:214-487)
     def update(self, grad_sync: Optional[Callable[["MagpoLearner"], float]] = None) -> torch.Tensor:
-        """ppo_epochs x num_minibatches optimisation steps; returns the loss table [P, M, 9] (device)."""
+        """ppo_epochs x num_minibatches optimisation steps; returns the loss table [P, M, 9] (device), already
+        averaged over groups (and ranks when grad_sync all-reduces)."""
         s, N, A = self.sys, self.N, self.A
         M = s.num_minibatches
         mbs = N // M
+        U = len(self.groups)
         losses = torch.zeros(s.ppo_epochs, M, 9, device=self.dev)
         for e in range(s.ppo_epochs):
-            ks = host_split(self.key, 4)
-            self.key, kb, ka, ke = ks[0], ks[1], ks[2], ks[3]
+            # every group holds the same key (SURVEY B9) => one permutation serves all groups
+            ks = host_split(self.groups[0].key, 4)
+            kb, ka, ke = ks[1], ks[2], ks[3]
+            for g in self.groups:
+                g.key = ks[0].copy()
             batch_perm = self._permutation(kb, N)
             agent_perm = self._permutation(ka, A)
             for mi in range(M):
                 ke = host_split(ke, 2)[0]  # key, entropy_key = split(key): unused for discrete actions (:373)
-                self.minibatch_grads(batch_perm[mi * mbs:(mi + 1) * mbs].contiguous(), agent_perm)
-                scale = grad_sync(self) if grad_sync is not None else 1.0
+                idx = batch_perm[mi * mbs:(mi + 1) * mbs].contiguous()
+                if U == 1:
+                    self.minibatch_grads(idx, agent_perm, 0)
+                else:  # pmean over the "batch" axis (:395-397): accumulate, the 1/U goes into grad_scale
+                    self.grad_acc.zero_()
+                    for gi in range(U):
+                        self.minibatch_grads(idx, agent_perm, gi)
+                        self.grad_acc.add_(self.grad_all)
+                    self.grad_all.copy_(self.grad_acc)
+                scale = (grad_sync(self) if grad_sync is not None else 1.0) / U
                 self.apply_grads(scale)
                 losses[e, mi].copy_(self.loss_out)
+                losses[e, mi].mul_(scale)
         return losses
 
     def update_step(self, grad_sync=None):

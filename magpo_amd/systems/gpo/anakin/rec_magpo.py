@@ -1,0 +1,197 @@
+"""MAGPO system entry point on MI355X -- drop-in for mava/systems/gpo/anakin/rec_magpo.py.
+
+Same public names and call contract as the reference system file:
+    hydra_entry_point / main(overrides)      rec_magpo.py:818-831
+    run_experiment(config) -> float          rec_magpo.py:688-815
+    learner_setup(env, keys, config) -> (learn, actor_network, init_learner_state)   rec_magpo.py:533-685
+    get_learner_fn(env, apply_fns, update_fn, config) -> LearnerFn                   rec_magpo.py:91-530
+The bodies drive the HIP kernels (magpo_amd.learner.MagpoLearner); there is no JAX, no XLA, no Triton.
+
+    python -m magpo_amd.systems.gpo.anakin.rec_magpo env=coordsum env/scenario=8x15-100 arch.num_envs=64
+
+Multi-GPU: launch one process per GPU with torch.distributed.run; ``n_devices`` = world size, each rank owns
+``update_batch_size`` groups of ``arch.num_envs`` envs, gradients are averaged with one RCCL all-reduce.
+"""
+from __future__ import annotations
+
+import copy
+import sys
+import time
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from magpo_amd import distributed as mdist
+from magpo_amd.actor import GruActor
+from magpo_amd.config import Config, compose
+from magpo_amd.evaluator import get_eval_fn, get_num_eval_envs, make_rec_eval_act_fn
+from magpo_amd.learner import MagpoLearner, SystemConfig, host_split, prng_key
+from magpo_amd.types import ExperimentOutput, GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
+from magpo_amd.utils import make_env as environments
+from magpo_amd.utils.config import check_total_timesteps
+from magpo_amd.utils.logger import LogEvent, MavaLogger
+
+LearnerState = GPOLearnerState
+
+
+def _system_config(config) -> SystemConfig:
+    s = config.system
+    if s.get("decay_learning_rates", False):
+        raise NotImplementedError("decay_learning_rates=True (linear lr decay) is not implemented")
+    return SystemConfig(rollout_length=int(s.rollout_length), ppo_epochs=int(s.ppo_epochs), num_minibatches=int(s.num_minibatches),
+                        gamma=float(s.gamma), gae_lambda=float(s.gae_lambda), clip_eps=float(s.clip_eps), ent_coef=float(s.ent_coef),
+                        vf_coef=float(s.vf_coef), max_grad_norm=float(s.max_grad_norm), clip_gpo=float(s.clip_gpo),
+                        alpha=float(s.alpha), actor_lr=float(s.actor_lr))
+
+
+def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:
+    """LearnerState view of the learner.  Parameters and optimiser moments are CLONED so that the state a caller
+    holds stays readable after the next learn() call (the harness evaluates the pre-interval parameters,
+    rec_magpo.py:770); rollout state leaves are live views."""
+    g0 = learner.groups[0]
+    params = Params({k: v.clone() for k, v in learner.guider.named.items()}, {k: v.clone() for k, v in learner.actor.named.items()})
+    opt = OptStates(dict(count=learner.g_count, mu=learner.g_mu.clone(), nu=learner.g_nu.clone()),
+                    dict(count=learner.a_count, mu=learner.a_mu.clone(), nu=learner.a_nu.clone()))
+    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i] for g in learner.groups]) for i in range(3)]),
+                      torch.stack([g.policy_h[g.cur] for g in learner.groups]))
+    env_state = [dict(step_count=g.env.step_count, target=g.env.target, record=g.env.record, key=g.env.key) for g in learner.groups]
+    timestep = [dict(agents_view=g.traj["obs"][0], step_count=g.traj["step_count"][0]) for g in learner.groups]
+    dones = torch.stack([g.traj["done"][0] for g in learner.groups])
+    return GPOLearnerState(params, opt, g0.key.copy(), env_state, timestep, dones, hs)
+
+
+def get_learner_fn(env, apply_fns, update_fn, config):
+    """Returns ``learn(learner_state) -> ExperimentOutput``: ``config.system.num_updates_per_eval`` update steps
+    (rec_magpo.py:501-528).  ``apply_fns`` carries the MagpoLearner that owns kernels and buffers; ``update_fn``
+    is the optional gradient-sync hook (RCCL all-reduce)."""
+    learner: MagpoLearner = apply_fns
+    grad_sync = update_fn
+
+    def learner_fn(learner_state: GPOLearnerState) -> ExperimentOutput:
+        n_up = int(config.system.num_updates_per_eval)
+        ep: Dict[str, List[np.ndarray]] = {"episode_return": [], "episode_length": [], "is_terminal_step": []}
+        train = []
+        for _ in range(n_up):
+            losses = learner.update_step(grad_sync)
+            train.append(losses)
+            for k in ep:
+                ep[k].append(torch.stack([g.metrics[k] for g in learner.groups]).cpu().numpy())
+        tl = torch.stack(train).cpu().numpy()  # (updates, P, M, 9)
+        names = ["total_loss", "value_loss", "actor_loss", "guider_loss", "kl_loss", "entropy"]
+        train_metrics = {n: tl[..., i] for i, n in enumerate(names)}
+        episode_metrics = {k: np.stack(v) for k, v in ep.items()}
+        episode_metrics["is_terminal_step"] = episode_metrics["is_terminal_step"].astype(bool)
+        return ExperimentOutput(_snapshot_state(learner), episode_metrics, train_metrics)
+
+    return learner_fn
+
+
+def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1):
+    """Initialise learner_fn, networks, optimiser, environments and states (rec_magpo.py:533-685)."""
+    key, actor_net_key, net_key = keys
+    config.system.num_agents = env.num_agents
+    nc, mc = config.network.net_config, config.network.memory_config
+    if mc.timestep_chunk_size:
+        raise NotImplementedError("timestep_chunk_size: the HIP path evaluates the rollout as one chunk (chunked state hand-off "
+                                  "inside the kernel); set memory_config.timestep_chunk_size=~")
+    mc.chunk_size = config.system.rollout_length * env.num_agents
+    if mc.type != "rec_sable":
+        raise NotImplementedError("memory_config.type must be rec_sable")
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    U = int(config.system.update_batch_size)
+    learner = MagpoLearner(env.cfg, int(config.arch.num_envs), _system_config(config), device,
+                           net_seed=int(net_key[1]) & 0x7FFFFFFF, decay_scaling_factor=float(mc.decay_scaling_factor),
+                           use_pe=bool(mc.timestep_positional_encoding), num_groups=U)
+    if int(nc.embed_dim) != 64 or int(nc.n_head) != 1 or int(nc.n_block) != 1 or int(config.network.hidden_state_dim) != 128:
+        raise NotImplementedError("HIP kernels support embed_dim=64, n_head=1, n_block=1, hidden_state_dim=128")
+    learner.setup(key, n_groups=world * U, group=rank * U)
+    grad_sync = mdist.make_grad_sync(world)
+    learn = get_learner_fn(env, learner, grad_sync, config)
+    learn.learner = learner
+    return learn, learner.actor, _snapshot_state(learner)
+
+
+def run_experiment(_config) -> float:
+    """Runs experiment (rec_magpo.py:688-815)."""
+    _config.logger.system_name = "rec_magpo"
+    config = copy.deepcopy(_config)
+    rank, world, local = mdist.init_from_env()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    n_devices = world
+
+    env, eval_env = environments.make(config)
+    ks = host_split(prng_key(int(config.system.seed)), 4)
+    key, key_e, actor_net_key, net_key = ks[0], ks[1], ks[2], ks[3]
+    learn, actor_network, learner_state = learner_setup(env, (key, actor_net_key, net_key), config, device, rank, world)
+
+    eval_actor = GruActor(env.num_agents, env.action_dim, env.obs_dim, device)
+    eval_act_fn = make_rec_eval_act_fn(eval_actor, config)
+    evaluator = get_eval_fn(eval_env, eval_act_fn, config, absolute_metric=False, device=device, n_devices=n_devices)
+
+    config = check_total_timesteps(config, n_devices)
+    assert config.system.num_updates > config.arch.num_evaluation, \
+        "Number of updates per evaluation must be less than total number of updates."
+    config.system.num_updates_per_eval = config.system.num_updates // config.arch.num_evaluation
+    steps_per_rollout = (n_devices * config.system.num_updates_per_eval * config.system.rollout_length
+                         * config.system.update_batch_size * config.arch.num_envs)
+    logger = MavaLogger(config) if rank == 0 else None
+    eval_batch = get_num_eval_envs(config, absolute_metric=False, n_devices=n_devices)
+    eval_hs = {"hidden_state": torch.zeros(eval_batch * env.num_agents, 128, device=device)}
+
+    max_episode_return = -np.inf
+    best_params = None
+    eval_metrics: Dict[str, Any] = {}
+    for eval_step in range(int(config.arch.num_evaluation)):
+        start = time.time()
+        learner_output = learn(learner_state)
+        torch.cuda.synchronize()
+        elapsed = time.time() - start
+        t = int(steps_per_rollout * (eval_step + 1))
+        em = learner_output.episode_metrics
+        term = em["is_terminal_step"]
+        ep_completed = bool(term.any())
+        if logger:
+            logger.log({"timestep": t}, t, eval_step, LogEvent.MISC)
+            if ep_completed:
+                logger.log({"episode_return": em["episode_return"][term], "episode_length": em["episode_length"][term],
+                            "steps_per_second": steps_per_rollout / elapsed}, t, eval_step, LogEvent.ACT)
+            logger.log(learner_output.train_metrics, t, eval_step, LogEvent.TRAIN)
+        # evaluate the PRE-interval actor parameters, as the reference does (rec_magpo.py:770)
+        trained_params = learner_state.params.actor_params
+        ks = host_split(key_e, n_devices + 1)
+        key_e, eval_key = ks[0], ks[1 + rank]
+        eval_metrics = evaluator(trained_params, eval_key, eval_hs)
+        if logger:
+            logger.log(eval_metrics, t, eval_step, LogEvent.EVAL)
+        episode_return = float(np.mean(eval_metrics["episode_return"]))
+        if config.arch.absolute_metric and max_episode_return <= episode_return:
+            best_params = {k: v.clone() for k, v in trained_params.items()}
+            max_episode_return = episode_return
+        learner_state = learner_output.learner_state
+
+    eval_performance = float(np.mean(eval_metrics[config.env.eval_metric]))
+    if config.arch.absolute_metric:
+        eb = get_num_eval_envs(config, absolute_metric=True, n_devices=n_devices)
+        abs_hs = {"hidden_state": torch.zeros(eb * env.num_agents, 128, device=device)}
+        abs_eval = get_eval_fn(eval_env, eval_act_fn, config, absolute_metric=True, device=device, n_devices=n_devices)
+        abs_key = host_split(key, n_devices)[rank]
+        m = abs_eval(best_params, abs_key, abs_hs)
+        if logger:
+            logger.log(m, int(steps_per_rollout * config.arch.num_evaluation), int(config.arch.num_evaluation) - 1, LogEvent.ABSOLUTE)
+    if logger:
+        logger.stop()
+    return eval_performance
+
+
+def hydra_entry_point(overrides: Optional[List[str]] = None) -> float:
+    """Experiment entry point (rec_magpo.py:818-831): compose configs/default/rec_magpo.yaml + CLI overrides."""
+    cfg = compose("rec_magpo", sys.argv[1:] if overrides is None else overrides)
+    perf = run_experiment(cfg)
+    print("MAGPO experiment completed")
+    return perf
+
+
+if __name__ == "__main__":
+    hydra_entry_point()

@@ -1,0 +1,67 @@
+"""Environment factory (mava/utils/make_env.py:202-218, 288-315): config -> (train_env, eval_env) descriptors.
+
+Only the CoordSum branch is implemented (the env dynamics live in the HIP kernel, csrc/coordsum.hip).
+LBF / RWARE dynamics live in third-party Jumanji, which is absent from the reference tree and from this
+image: they cannot be restated faithfully offline and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from ..learner import CoordSumConfig
+
+COORDSUM_REGISTRY = {  # mava/coordsum/__init__.py:6-45
+    "5x20-80-v0": dict(num_agents=5, num_actions=20, time_limit=100, maxval=80),
+    "3x30-50-v0": dict(num_agents=3, num_actions=30, time_limit=100, maxval=50),
+    "3x10-30-v0": dict(num_agents=3, num_actions=10, time_limit=100, maxval=30),
+    "8x15-100-v0": dict(num_agents=8, num_actions=15, time_limit=100, maxval=100),
+}
+
+
+@dataclass
+class MarlEnvSpec:
+    """What the system file reads from a MarlEnv (mava/types.py:45-123)."""
+    cfg: CoordSumConfig
+    auto_reset: bool
+    add_agent_id: bool = True
+
+    @property
+    def num_agents(self) -> int:
+        return self.cfg.num_agents
+
+    @property
+    def action_dim(self) -> int:
+        return self.cfg.num_actions
+
+    @property
+    def time_limit(self) -> int:
+        return self.cfg.time_limit
+
+    @property
+    def obs_dim(self) -> int:
+        return self.cfg.num_agents + 1 if self.add_agent_id else 1
+
+
+def make_coordsum_env(config):
+    task = config.env.scenario.task_name
+    if task not in COORDSUM_REGISTRY:
+        raise ValueError(f"{task} is not a registered CoordSum scenario")
+    kw = dict(COORDSUM_REGISTRY[task])
+    kw.update(config.env.kwargs.to_container())  # **config.env.kwargs override the registered kwargs (make_env.py:211-213)
+    add_id = bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id)
+    config.system.add_agent_id = add_id
+    if not add_id:
+        raise NotImplementedError("system.add_agent_id=False is not supported by the HIP env kernel (obs = [agent id | target])")
+    cfg = CoordSumConfig(**kw)
+    return MarlEnvSpec(cfg, auto_reset=True), MarlEnvSpec(cfg, auto_reset=False)
+
+
+def make(config):
+    env_name = config.env.env_name
+    if env_name == "CoordSum":
+        return make_coordsum_env(config)
+    if env_name in ("RobotWarehouse", "LevelBasedForaging"):
+        raise NotImplementedError(
+            f"{env_name}: dynamics live in Jumanji (git pin 9ced6b8), which is not part of the reference tree; "
+            "no verified HIP kernel exists yet (SURVEY 8f rank 2). Use env=coordsum.")
+    raise ValueError(f"{env_name} is not a supported environment.")

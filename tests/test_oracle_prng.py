@@ -1,0 +1,50 @@
+"""Oracle PRNG pinned against the Random123 threefry2x32 known-answer vectors (the only golden
+vectors that exist for this path: the reference ships no tests)."""
+import numpy as np
+
+from oracle import prng
+
+
+def test_threefry_known_answers():
+    kat = [((0x00000000, 0x00000000), (0x00000000, 0x00000000), (0x6B200159, 0x99BA4EFE)),
+           ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+           ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))]
+    for key, ctr, exp in kat:
+        x0, x1 = prng.threefry2x32(np.uint32(key[0]), np.uint32(key[1]), np.uint32(ctr[0]), np.uint32(ctr[1]))
+        assert (int(x0), int(x1)) == exp
+
+
+def test_split_is_threefry_of_counter():
+    k = prng.prng_key(42)
+    assert k.tolist() == [0, 42]
+    s = prng.split(k, 3)
+    for i in range(3):
+        x0, x1 = prng.threefry2x32(k[0], k[1], np.uint32(0), np.uint32(i))
+        assert s[i].tolist() == [int(x0), int(x1)]
+    # batched keys
+    sb = prng.split(s, 2)
+    assert sb.shape == (3, 2, 2) and np.array_equal(sb[1], prng.split(s[1], 2))
+
+
+def test_uniform_gumbel_randint_permutation():
+    k = prng.prng_key(7)
+    bits = prng.random_bits(k, 1000)
+    u = prng.bits_to_uniform(bits)
+    assert u.dtype == np.float32 and (u >= 0).all() and (u < 1).all()
+    assert prng.bits_to_uniform(np.array([0], np.uint32), np.finfo(np.float32).tiny, 1.0)[0] == np.finfo(np.float32).tiny
+    g = prng.bits_to_gumbel(bits)
+    assert np.isfinite(g).all()
+    r = prng.randint(k, 5000, 0, 60)
+    assert r.min() >= 0 and r.max() < 60 and len(np.unique(r)) == 60
+    for n in (4, 8, 16384):
+        p = prng.permutation(k, n)
+        assert np.array_equal(np.sort(p), np.arange(n))
+    assert np.array_equal(prng.permutation(k, 16), prng.permutation(k, 16))
+
+
+def test_categorical_matches_manual_gumbel_argmax():
+    k = prng.prng_key(3)
+    logits = np.random.default_rng(0).normal(size=(50, 1, 7)).astype(np.float32)
+    a = prng.categorical(k, logits)
+    g = prng.bits_to_gumbel(prng.random_bits(k, logits.size)).reshape(logits.shape)
+    assert np.array_equal(a, np.argmax(g + logits, -1))
