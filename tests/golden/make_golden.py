@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the CPU oracle (run from the repo root:
+``python tests/golden/make_golden.py``).
+
+The reference itself cannot be imported here (jax / flax / optax / distrax / jumanji are not installed,
+SURVEY 8c), so these vectors pin the ORACLE (guarding it against drift) and give the HIP path committed
+input/output pairs; they are not outputs of the reference.  Fixtures are data only: inputs and expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import coordsum as ocs  # noqa: E402
+from oracle import learner as olearn  # noqa: E402
+from oracle import networks as onets  # noqa: E402
+from oracle import prng as oprng  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def prng_fixture():
+    key = oprng.prng_key(20260101)
+    ks = oprng.split(key, 6)
+    np.savez_compressed(os.path.join(OUT, "prng.npz"), key=key, split6=ks, bits32=oprng.random_bits(ks[1], 32),
+                        randint_0_60=oprng.randint(ks[2], 101, 0, 60), perm16=oprng.permutation(ks[3], 16),
+                        perm1000=oprng.permutation(ks[4], 1000),
+                        cat_logits=np.linspace(-1, 1, 60, dtype=np.float32).reshape(3, 1, 20),
+                        cat_sample=oprng.categorical(ks[5], np.linspace(-1, 1, 60, dtype=np.float32).reshape(3, 1, 20)))
+
+
+def env_fixture():
+    spec = ocs.CoordSumSpec(4, 20, 12, 60)
+    keys = oprng.split(oprng.prng_key(7), 6)
+    st, ts = ocs.reset(spec, keys)
+    rng = np.random.default_rng(5)
+    acts, rews, obs, dones, rets = [], [], [], [], []
+    for i in range(30):
+        a = rng.integers(0, 20, size=(6, 4)).astype(np.int32)
+        tgt = st["target"][np.arange(6), np.minimum(st["step_count"], 12)]
+        for n in range(0, 6, 2):
+            rest = int(tgt[n]) - int(a[n, 1:].sum())
+            if 0 <= rest < 20:
+                a[n, 0] = rest
+        st, ts = ocs.step(spec, st, a)
+        acts.append(a); rews.append(ts["reward"][:, 0].copy()); obs.append(ts["observation"]["agents_view"][:, 0, -1].copy())
+        dones.append(ts["step_type"] == ocs.STEP_LAST); rets.append(ts["episode_metrics"]["episode_return"].copy())
+    np.savez_compressed(os.path.join(OUT, "coordsum.npz"), cfg=np.array([4, 20, 12, 60]), env_keys=keys, actions=np.stack(acts),
+                        reward=np.stack(rews), obs_target=np.stack(obs), done=np.stack(dones), episode_return=np.stack(rets),
+                        final_target=st["target"], final_record=st["record"], final_key=st["key"])
+
+
+def learner_fixture():
+    A, K, TL, maxval, N, T = 2, 6, 5, 9, 4, 8
+    gp = onets.init_guider_params(11, 64, A + 1, K)
+    ap = onets.init_actor_params(12, A + 1, 128, K)
+    ol = olearn.OracleLearner(ocs.CoordSumSpec(A, K, TL, maxval), N, olearn.SystemCfg(rollout_length=T, ppo_epochs=2, num_minibatches=2),
+                              onets.SableCfg(A, K, A + 1), gp, ap)
+    key = oprng.split(oprng.prng_key(3), 4)[0]
+    ol.setup(key)
+    ol.rollout()
+    tr = {k: ol.traj[k].numpy() for k in ("action", "value", "log_prob", "reward", "adv", "targets")}
+    ol.update()
+    out = dict(cfg=np.array([A, K, TL, maxval, N, T]), key=key, key_after=ol.key, **{"traj_" + k: v for k, v in tr.items()})
+    # initial parameters are regenerated from their seeds (11, 12); they are pinned here by checksums.
+    # Post-update parameters are pinned by (sum, sum |.|, first 8 elements) per tensor to keep the fixture small.
+    def stat(v):
+        x = v.double().reshape(-1)
+        return np.concatenate([[x.sum().item(), x.abs().sum().item()], x[:8].numpy(), np.zeros(max(0, 8 - x.numel()))])
+    for tag, d in (("gp0", gp), ("ap0", ap), ("gp1", ol.gp), ("ap1", ol.ap)):
+        for n, v in d.items():
+            out[tag + "/" + n] = stat(v)
+    np.savez_compressed(os.path.join(OUT, "learner.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)  # bit-stable reductions
+    prng_fixture()
+    env_fixture()
+    learner_fixture()
+    print("golden fixtures written to", OUT)

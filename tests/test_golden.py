@@ -1,0 +1,111 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle):
+the CPU test guards the oracle against drift; the GPU tests check the HIP path against the same vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coordsum as ocs
+from oracle import learner as olearn
+from oracle import networks as onets
+from oracle import prng as oprng
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_reproduces_prng_and_env_fixtures():
+    f = np.load(os.path.join(G, "prng.npz"))
+    ks = oprng.split(f["key"], 6)
+    assert np.array_equal(ks, f["split6"]) and np.array_equal(oprng.random_bits(ks[1], 32), f["bits32"])
+    assert np.array_equal(oprng.randint(ks[2], 101, 0, 60), f["randint_0_60"])
+    assert np.array_equal(oprng.permutation(ks[3], 16), f["perm16"]) and np.array_equal(oprng.permutation(ks[4], 1000), f["perm1000"])
+    assert np.array_equal(oprng.categorical(ks[5], f["cat_logits"]), f["cat_sample"])
+    e = np.load(os.path.join(G, "coordsum.npz"))
+    A, K, TL, mv = e["cfg"]
+    spec = ocs.CoordSumSpec(A, K, TL, mv)
+    st, _ = ocs.reset(spec, e["env_keys"])
+    for i in range(e["actions"].shape[0]):
+        st, ts = ocs.step(spec, st, e["actions"][i])
+        assert np.array_equal(ts["reward"][:, 0], e["reward"][i]) and np.array_equal(ts["step_type"] == ocs.STEP_LAST, e["done"][i])
+    assert np.array_equal(st["record"], e["final_record"]) and np.array_equal(st["key"], e["final_key"])
+
+
+def _stat(v):
+    x = v.detach().cpu().double().reshape(-1)
+    return np.concatenate([[x.sum().item(), x.abs().sum().item()], x[:8].numpy(), np.zeros(max(0, 8 - x.numel()))])
+
+
+def _load_learner():
+    f = np.load(os.path.join(G, "learner.npz"))
+    A, K = int(f["cfg"][0]), int(f["cfg"][1])
+    gp0 = onets.init_guider_params(11, 64, A + 1, K)
+    ap0 = onets.init_actor_params(12, A + 1, 128, K)
+    for n, v in gp0.items():  # the seeds must regenerate the exact initial parameters the fixture was made with
+        assert np.allclose(_stat(v), f["gp0/" + n], rtol=0, atol=1e-9), n
+    for n, v in ap0.items():
+        assert np.allclose(_stat(v), f["ap0/" + n], rtol=0, atol=1e-9), n
+    return f, gp0, ap0
+
+
+def test_oracle_reproduces_learner_fixture():
+    torch.set_num_threads(1)
+    f, gp0, ap0 = _load_learner()
+    A, K, TL, mv, N, T = (int(x) for x in f["cfg"])
+    ol = olearn.OracleLearner(ocs.CoordSumSpec(A, K, TL, mv), N, olearn.SystemCfg(rollout_length=T, ppo_epochs=2, num_minibatches=2),
+                              onets.SableCfg(A, K, A + 1), gp0, ap0)
+    ol.setup(f["key"])
+    ol.rollout()
+    assert np.array_equal(ol.traj["action"].numpy(), f["traj_action"])
+    assert np.allclose(ol.traj["value"].numpy(), f["traj_value"], atol=1e-6)
+    ol.update()
+    assert np.array_equal(ol.key, f["key_after"])
+    for n, v in ol.gp.items():
+        assert np.allclose(_stat(v), f["gp1/" + n], rtol=1e-5, atol=1e-4), n
+
+
+@pytest.mark.gpu
+def test_hip_env_and_prng_match_golden(L, stream):
+    from tests.test_kernels_gpu import DevEnv, dev
+    f = np.load(os.path.join(G, "prng.npz"))
+    out = torch.zeros(6, 2, dtype=torch.int32, device="cuda")
+    L.call("magpo_threefry_split", dev(f["key"].view(np.int32)), out, 6, stream)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), f["split6"])
+    e = np.load(os.path.join(G, "coordsum.npz"))
+    A, K, TL, mv = (int(x) for x in e["cfg"])
+    env = DevEnv(L, stream, ocs.CoordSumSpec(A, K, TL, mv), 6)
+    env.reset(e["env_keys"])
+    for i in range(e["actions"].shape[0]):
+        env.step(dev(e["actions"][i]))
+        assert np.array_equal(env.reward[:, 0].cpu().numpy(), e["reward"][i]), i
+        assert np.array_equal(env.obs[:, 0, -1].cpu().numpy(), e["obs_target"][i].astype(np.float32))
+        assert np.array_equal(env.m_ret.cpu().numpy(), e["episode_return"][i])
+    assert np.array_equal(env.record.cpu().numpy(), e["final_record"])
+    assert np.array_equal(env.key.cpu().numpy().view(np.uint32), e["final_key"])
+
+
+@pytest.mark.gpu
+def test_hip_learner_matches_golden():
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
+    f, gp0, ap0 = _load_learner()
+    A, K, TL, mv, N, T = (int(x) for x in f["cfg"])
+    dl = MagpoLearner(CoordSumConfig(A, K, TL, mv), N, SystemConfig(rollout_length=T, ppo_epochs=2, num_minibatches=2), "cuda",
+                      net_seed=None, wgrad_groups=4)
+    dl.guider.load_named(gp0)
+    dl.actor.load_named(ap0)
+    dl.setup(f["key"])
+    dl.rollout()
+    assert np.array_equal(dl.traj["action"].cpu().numpy(), f["traj_action"]), "sampled actions must be bit-exact"
+    assert np.array_equal(dl.traj["reward"].cpu().numpy(), f["traj_reward"])
+    for k in ("value", "log_prob", "adv", "targets"):
+        assert np.allclose(dl.traj[k].cpu().numpy(), f["traj_" + k], rtol=1e-4, atol=1e-5), k
+    dl.update()
+    assert np.array_equal(dl.key, f["key_after"])
+    for n, v in dl.guider.named.items():
+        st = _stat(v)
+        assert np.allclose(st[2:], f["gp1/" + n][2:], atol=3e-5), n          # leading elements
+        assert abs(st[0] - f["gp1/" + n][0]) <= 3e-5 * v.numel(), n          # checksum
+    for n, v in dl.actor.named.items():
+        st = _stat(v)
+        assert np.allclose(st[2:], f["ap1/" + n][2:], atol=3e-5), n
+        assert abs(st[0] - f["ap1/" + n][0]) <= 3e-5 * v.numel(), n

@@ -1,0 +1,127 @@
+"""Host-side logic that needs no GPU: parameter layout, config composer, env factory, logger, grad sync (gloo, world 2)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from magpo_amd import params as P
+from magpo_amd.config import compose
+from oracle import networks as onets
+
+
+def test_flat_layout_matches_reference_parameter_tree():
+    E, F, K = 64, 5, 20
+    fp = P.FlatParams(P.guider_layout(E, F, K), "cpu")
+    named = P.guider_named_views(fp.views())
+    ref = onets.guider_param_shapes(E, F, K)
+    assert set(named) == set(ref)
+    for n, shp in ref.items():
+        assert tuple(named[n].shape) == tuple(shp), n
+    assert sum(int(np.prod(s)) for s in ref.values()) == 98330
+    for off in fp.offsets.values():
+        assert off % 4 == 0
+    named["enc.block0.retn.w_k"][0, 3, 7] = 5.0  # views alias the flat buffer
+    assert fp.flat[fp.offsets["enc.block0.retn.w_qkvg"] + 3 * 256 + 64 + 7] == 5.0
+    fa = P.FlatParams(P.actor_layout(F, 128, K), "cpu")
+    an = P.actor_named_views(fa.views())
+    aref = onets.actor_param_shapes(F, 128, K)
+    assert set(an) == set(aref) and all(tuple(an[n].shape) == tuple(s) for n, s in aref.items())
+    assert sum(int(np.prod(s)) for s in aref.values()) == 118676
+
+
+def test_init_distributions():
+    fp = P.FlatParams(P.guider_layout(64, 5, 20), "cpu")
+    named = P.guider_named_views(fp.views())
+    P.init_guider(named, 0)
+    assert float(named["enc.block0.ffn.W_gate"].abs().max()) == 0.0 and float(named["enc.ln.scale"].min()) == 1.0
+    w = named["enc.head.dense0.kernel"]
+    assert torch.allclose(w.T @ w, 2.0 * torch.eye(64), atol=1e-4)       # orthogonal(sqrt 2)
+    assert abs(float(named["dec.block0.retn1.w_g"].std()) - 1 / 64) < 2e-3  # normal(1/E)
+    assert float(named["dec.head.dense1.kernel"].abs().max()) < 0.011
+
+
+def test_config_compose_and_overrides():
+    c = compose("rec_magpo", ["env=coordsum", "env/scenario=8x15-100", "arch.num_envs=64", "+env.kwargs.num_agents=4",
+                              "system.total_timesteps=~", "system.ppo_epochs=15"])
+    assert c.env.scenario.task_name == "8x15-100-v0" and c.arch.num_envs == 64 and c.system.ppo_epochs == 15
+    assert c.env.kwargs.to_container() == {"time_limit": 100, "num_agents": 4}
+    assert c.system.total_timesteps is None and c.system.clip_gpo == 1.5 and c.system.update_batch_size == 2
+    assert c.logger.loggers.json.task_name == "8x15-100-v0"  # ${env.scenario.task_name}
+    assert c.network.memory_config.timestep_chunk_size is None and c.network.net_config.embed_dim == 64
+    c.system.num_agents = 8  # struct mode off (rec_magpo.py:826)
+    assert c.system.num_agents == 8
+    d = compose("rec_magpo")
+    assert d.env.env_name == "RobotWarehouse"  # reference default env is rware (configs/default/rec_magpo.yaml)
+    with pytest.raises(KeyError):
+        compose("rec_magpo", ["system.not_a_key=1"])
+
+
+def test_env_factory():
+    from magpo_amd.utils import make_env
+    c = compose("rec_magpo", ["env=coordsum", "env/scenario=5x20-80"])
+    tr, ev = make_env.make(c)
+    assert (tr.num_agents, tr.action_dim, tr.time_limit, tr.cfg.maxval, tr.obs_dim) == (5, 20, 100, 80, 6)
+    assert tr.auto_reset and not ev.auto_reset
+    c = compose("rec_magpo", ["env=coordsum", "+env.kwargs.num_agents=4", "+env.kwargs.num_actions=20", "+env.kwargs.maxval=60"])
+    tr, _ = make_env.make(c)
+    assert (tr.num_agents, tr.action_dim, tr.cfg.maxval) == (4, 20, 60)
+    with pytest.raises(NotImplementedError):
+        make_env.make(compose("rec_magpo"))
+
+
+def test_check_total_timesteps_and_logger(tmp_path, capsys):
+    from magpo_amd.utils.config import check_total_timesteps
+    from magpo_amd.utils.logger import LogEvent, MavaLogger
+    c = compose("rec_magpo", ["env=coordsum", "logger.loggers.json.enabled=True", f"logger.base_exp_path={tmp_path}/", "logger.loggers.json.path=x"])
+    c = check_total_timesteps(c, n_devices=1)
+    assert c.system.num_updates == 20_000_000 // 128 // 2 // 16 == 4882
+    c.logger.system_name = "rec_magpo"
+    lg = MavaLogger(c)
+    lg.log({"episode_return": np.array([1.0, 3.0]), "episode_length": np.array([100, 100]), "steps_per_second": 5.0}, 4096, 0, LogEvent.EVAL)
+    lg.log({"total_loss": np.ones((2, 2))}, 4096, 0, LogEvent.TRAIN)
+    run = json.load(open(os.path.join(tmp_path, "json", "x", "metrics.json")))["CoordSum"]["3x10-30-v0"]["rec_magpo"]["seed_42"]
+    assert run["step_0"]["mean_episode_return"] == [2.0] and run["step_0"]["step_count"] == 4096
+    assert "EVALUATOR" in capsys.readouterr().out
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from magpo_amd import distributed as mdist
+    r, w, _ = mdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+
+    class Fake:  # the only attribute grad_sync touches
+        grad_all = torch.full((1000,), float(rank + 1))
+
+    sync = mdist.make_grad_sync(w)
+    scale = sync(Fake)
+    keys = torch.arange(2 * (world * 4 + 1)).view(-1, 2)
+    mine = mdist.shard_env_keys(keys, 4, rank)
+    q.put((rank, float(Fake.grad_all[0]) * scale, mine[0, 0].item(), mine.shape[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_world2_gloo():
+    """N > 1 path on CPU: sum all-reduce of the flat gradient buffer, mean via the returned scale; env-key sharding."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 1.5           # mean of 1 and 2
+    assert res[0][2] == 2 and res[1][2] == 10 and res[0][3] == 4  # rank r owns rows 1 + r*N ...
+
+
+def test_make_grad_sync_single_group_is_none():
+    from magpo_amd import distributed as mdist
+    assert mdist.make_grad_sync(1) is None
