@@ -19,7 +19,7 @@ H = 128
 
 
 class GruActor:
-    def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, hidden: int = 128, wgrad_groups: int = 256,
+    def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, hidden: int = 128, wgrad_groups: int = 512,
                  seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
         if hidden != 128:
             raise NotImplementedError("gfx950 GRU kernels: hidden_state_dim = 128 only")

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int
   }
 }
 
-// dW slab: grid (G, ceil(NOUT / (64 NB)), KIN / 64)
+// dW slab: grid (G, ceil(NOUT / (64 NB)), KIN / 64).  Software pipeline: the next row tile is fetched
+// from HBM into registers while the MFMAs of the current tile run out of LDS.
 template <int NB>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
                                                int R, int KIN, int NOUT, float* __restrict__ slab,
@@ -100,34 +101,58 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
     for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
   float bsum = 0.f;
   const bool do_bias = bias_slab != nullptr && kb == 0;
+  const bool full_cols = (c0 + 64 * NB <= NOUT) && ((ldy & 3) == 0);
 
-  for (int tile = g; tile < ntiles; tile += G) {
+  float4 xr[4], yr[4 * NB];
+  auto fetch = [&](int tile) {
     const long row0 = (long)tile * 64;
-    __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {
-      int r = i >> 4, c4 = i & 15;
-      long gr = row0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < R) v = *reinterpret_cast<const float4*>(X + gr * (long)ldx + kb * 64 + 4 * c4);
-      *reinterpret_cast<float4*>(&xs[r * LDX + 4 * c4]) = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j;
+      const int r = i >> 4, c4 = i & 15;
+      const long gr = row0 + r;
+      xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < R) xr[j] = *reinterpret_cast<const float4*>(X + gr * (long)ldx + kb * 64 + 4 * c4);
     }
-    for (int i = tid; i < 64 * 16 * NB; i += 256) {
-      int r = i / (16 * NB), c4 = i - r * (16 * NB);
-      long gr = row0 + r;
-      int col = c0 + 4 * c4;
+#pragma unroll
+    for (int j = 0; j < 4 * NB; ++j) {
+      const int i = tid + 256 * j;
+      const int r = i / (16 * NB), c4 = i - r * (16 * NB);
+      const long gr = row0 + r;
+      const int col = c0 + 4 * c4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < R) {
         const float* p = dY + gr * (long)ldy + col;
-        if (col + 3 < NOUT) v = *reinterpret_cast<const float4*>(p);
+        if (full_cols || col + 3 < NOUT) v = *reinterpret_cast<const float4*>(p);
         else {
           if (col + 0 < NOUT) v.x = p[0];
           if (col + 1 < NOUT) v.y = p[1];
           if (col + 2 < NOUT) v.z = p[2];
         }
       }
-      *reinterpret_cast<float4*>(&ys[r * LDY + 4 * c4]) = v;
+      yr[j] = v;
     }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j;
+      *reinterpret_cast<float4*>(&xs[(i >> 4) * LDX + 4 * (i & 15)]) = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4 * NB; ++j) {
+      const int i = tid + 256 * j;
+      const int r = i / (16 * NB), c4 = i - r * (16 * NB);
+      *reinterpret_cast<float4*>(&ys[r * LDY + 4 * c4]) = yr[j];
+    }
+  };
+
+  if (g < ntiles) fetch(g);
+  for (int tile = g; tile < ntiles; tile += G) {
+    __syncthreads();          // MFMAs of the previous tile have finished reading LDS
+    stash();
     __syncthreads();
+    if (tile + G < ntiles) fetch(tile + G);   // in flight during the MFMA loop below
 #pragma unroll 4
     for (int s = 0; s < 32; ++s) {
       const int tok = 32 * h + s;
@@ -139,10 +164,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
       }
     }
     if (do_bias && tid < 64 * NB) {
-      float s = 0.f;
+      float sb = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 64; ++r) s += ys[r * LDY + tid];
-      bsum += s;
+      for (int r = 0; r < 64; ++r) sb += ys[r * LDY + tid];
+      bsum += sb;
     }
   }
   float* out = slab + (long)g * KIN * NOUT;
@@ -160,15 +185,33 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
   if (do_bias && tid < 64 * NB && c0 + tid < NOUT) bias_slab[(long)g * NOUT + c0 + tid] = bsum;
 }
 
-// out[p] = scale * sum_g slab[g][p]  (fixed order => bit-stable)
-__global__ void k_reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, int G, long P, long stride,
-                               float scale, int accumulate) {
-  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  float s = 0.f;
-  for (int g = 0; g < G; ++g) s += slab[(long)g * stride + p];
-  s *= scale;
-  out[p] = accumulate ? out[p] + s : s;
+// out[p] = scale * sum_g slab[g*stride + p]  (fixed summation tree => bit-stable).
+// Block = 64 columns x 16 row-lanes; each row-lane sums every 16th slab, then a fixed LDS tree.
+__global__ __launch_bounds__(1024) void k_reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, int G, long P, long stride,
+                                                       float scale, int accumulate) {
+  __shared__ float sh[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long p = (long)blockIdx.x * 64 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (p < P) {
+    int g = ty;
+    for (; g + 48 < G; g += 64) {
+      s0 += slab[(long)g * stride + p];
+      s1 += slab[(long)(g + 16) * stride + p];
+      s2 += slab[(long)(g + 32) * stride + p];
+      s3 += slab[(long)(g + 48) * stride + p];
+    }
+    for (; g < G; g += 16) s0 += slab[(long)g * stride + p];
+  }
+  sh[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && p < P) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += sh[i][tx];
+    s *= scale;
+    out[p] = accumulate ? out[p] + s : s;
+  }
 }
 
 // Wt[Npad][K] = W[K][N]^T, rows N..Npad-1 zero.
@@ -224,13 +267,13 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   if (nb == 2) hipLaunchKernelGGL(k_wgrad<2>, grid, block, 0, stream, X, ldx, dY, ldy, (int)R, KIN, NOUT, slab, bslab);
   else hipLaunchKernelGGL(k_wgrad<1>, grid, block, 0, stream, X, ldx, dY, ldy, (int)R, KIN, NOUT, slab, bslab);
   long P = (long)krows * NOUT;
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
-  if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 255) / 256), dim3(256), 0, stream, bslab, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
+  if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 63) / 64), dim3(1024), 0, stream, bslab, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
   return check_launch("magpo_wgrad");
 }
 
 extern "C" int magpo_reduce_slabs(const float* slab, float* out, int G, long P, long stride, float scale, int accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, slab, out, G, P, stride, scale, accumulate);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, stream, slab, out, G, P, stride, scale, accumulate);
   return check_launch("magpo_reduce_slabs");
 }
 

@@ -169,38 +169,51 @@ __device__ __forceinline__ float min_grad_weight(float l1, float l2, bool first)
   if (l1 == l2) return 0.5f;
   return ((l1 < l2) == first) ? 1.f : 0.f;
 }
+__device__ __forceinline__ float max16(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
 
+// 16 lanes per row, 4 logit columns per lane (K <= 64): rows are read / written as coalesced 256-B lines.
 __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
-  __shared__ double sh[6][256];
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < a.R; r += (long)gridDim.x * blockDim.x) {
-    const float* xg = a.g_logits + r * a.ldg;
-    const float* xa = a.a_logits + r * a.lda;
-    const unsigned char* m = a.mask ? a.mask + r * a.K : nullptr;
-    float mg = -INFINITY, ma = -INFINITY;
-    for (int k = 0; k < a.K; ++k) {
-      const bool legal = !m || m[k];
-      mg = fmaxf(mg, legal ? xg[k] : FMIN);
-      ma = fmaxf(ma, legal ? xa[k] : FMIN);
+  __shared__ double sh[6][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, c4 = 4 * l16;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long nrow4 = (a.R + 3) / 4;
+  for (long base = (long)blockIdx.x * 4 + wave; base < nrow4; base += (long)gridDim.x * 4) {
+    const long r = base * 4 + (lane >> 4);
+    const bool ok = r < a.R;
+    const long rr = ok ? r : 0;
+    float xg[4], xa[4];
+    bool legal[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = c4 + j;
+      const bool in = k < a.K;
+      legal[j] = in && (!a.mask || a.mask[rr * a.K + k]);
+      xg[j] = in ? (legal[j] ? a.g_logits[rr * a.ldg + k] : FMIN) : -INFINITY;
+      xa[j] = in ? (legal[j] ? a.a_logits[rr * a.lda + k] : FMIN) : -INFINITY;
     }
+    const float mg = max16(fmaxf(fmaxf(xg[0], xg[1]), fmaxf(xg[2], xg[3])));
+    const float ma = max16(fmaxf(fmaxf(xa[0], xa[1]), fmaxf(xa[2], xa[3])));
     float sg = 0.f, sa = 0.f;
-    for (int k = 0; k < a.K; ++k) {
-      const bool legal = !m || m[k];
-      sg += expf((legal ? xg[k] : FMIN) - mg);
-      sa += expf((legal ? xa[k] : FMIN) - ma);
-    }
-    const float lseg = mg + logf(sg), lsea = ma + logf(sa);
-    const int act = a.action[r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sg += expf(xg[j] - mg); sa += expf(xa[j] - ma); }
+    const float lseg = mg + logf(sum16(sg)), lsea = ma + logf(sum16(sa));
+    const int act = a.action[rr];
+    float lpg[4], lpa[4], pg[4], pa[4];
     float ent = 0.f, kl = 0.f, g_logp = 0.f, a_logp = 0.f;
-    for (int k = 0; k < a.K; ++k) {
-      const bool legal = !m || m[k];
-      const float lpg = (legal ? xg[k] : FMIN) - lseg, lpa = (legal ? xa[k] : FMIN) - lsea;
-      const float pg = expf(lpg);
-      if (pg != 0.f) { ent -= pg * lpg; kl += pg * (lpg - lpa); }
-      if (k == act) { g_logp = lpg; a_logp = lpa; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lpg[j] = xg[j] - lseg; lpa[j] = xa[j] - lsea;
+      pg[j] = expf(lpg[j]); pa[j] = expf(lpa[j]);
+      if (pg[j] != 0.f) { ent -= pg[j] * lpg[j]; kl += pg[j] * (lpg[j] - lpa[j]); }
+      if (c4 + j == act) { g_logp = lpg[j]; a_logp = lpa[j]; }
     }
-    const float old = a.old_logp[r];
-    const float A_ = (a.adv[r] - a.adv_stats[0]) * a.adv_stats[1];
+    ent = sum16(ent); kl = sum16(kl); g_logp = sum16(g_logp); a_logp = sum16(a_logp);
+    const float old = a.old_logp[rr];
+    const float A_ = (a.adv[rr] - a.adv_stats[0]) * a.adv_stats[1];
     const float eps = a.clip_eps, ld = a.log_clip_gpo;
     // guider surrogate (rec_magpo.py:261-294)
     const float ratio = expf(g_logp - old);
@@ -211,11 +224,10 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
     const float l1 = ratio * A_, l2 = crc * A_;
     const float pgl = -fminf(l1, l2);
     const bool kmask = (d < -ld) || (d > ld);
-    const float dl1 = ratio * A_;
     const float dl2 = (cr > 1.f - eps && cr < 1.f + eps && d > -ld && d < ld) ? cr * A_ : 0.f;
-    const float c_g = -(min_grad_weight(l1, l2, true) * dl1 + min_grad_weight(l1, l2, false) * dl2);
+    const float c_g = -(min_grad_weight(l1, l2, true) * l1 + min_grad_weight(l1, l2, false) * dl2);
     // value loss (:298-303)
-    const float v = a.value[r], vo = a.old_value[r], tg = a.targets[r];
+    const float v = a.value[rr], vo = a.old_value[rr], tg = a.targets[rr];
     const float dv = v - vo;
     const float vcl = vo + fminf(fmaxf(dv, -eps), eps);
     const float e1 = (v - tg) * (v - tg), e2 = (vcl - tg) * (vcl - tg);
@@ -223,7 +235,6 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
     const float g1 = 2.f * (v - tg);
     const float g2 = (dv > -eps && dv < eps) ? 2.f * (vcl - tg) : 0.f;
     const float dvl = 0.5f * (e1 > e2 ? g1 : (e2 > e1 ? g2 : 0.5f * (g1 + g2)));
-    a.dvalue[r] = a.inv_R * a.vf_coef * dvl;
     // actor surrogate (:354-367)
     const float ra = expf(a_logp - old);
     const float rac = fminf(fmaxf(ra, 1.f - eps), 1.f + eps);
@@ -231,34 +242,38 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
     const float apl = -fminf(m1, m2);
     const float dm2 = (ra > 1.f - eps && ra < 1.f + eps) ? ra * A_ : 0.f;
     const float c_a = -(min_grad_weight(m1, m2, true) * m1 + min_grad_weight(m1, m2, false) * dm2);
-    // gradients w.r.t. the raw logits
-    float* dg = a.dg_logits + r * a.lddg;
-    float* da = a.da_logits + r * a.lddda;
     const float km = kmask ? 1.f : 0.f;
-    for (int k = 0; k < a.K; ++k) {
-      const bool legal = !m || m[k];
-      const float lpg = (legal ? xg[k] : FMIN) - lseg, lpa = (legal ? xa[k] : FMIN) - lsea;
-      const float pg = expf(lpg), pa = expf(lpa);
-      const float onehot = k == act ? 1.f : 0.f;
-      float gg = c_g * (onehot - pg);
-      if (pg != 0.f) gg += km * pg * ((lpg - lpa) - kl) + a.ent_coef * pg * (lpg + ent);
-      float ga = a.alpha * c_a * (onehot - pa) + (pa - pg);
-      if (!legal) { gg = 0.f; ga = 0.f; }
-      dg[k] = a.inv_R * gg;
-      da[k] = a.inv_R * ga;
+    if (ok) {
+      float4 og, oa;
+      float* pog = &og.x;
+      float* poa = &oa.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float onehot = (c4 + j == act) ? 1.f : 0.f;
+        float gg = c_g * (onehot - pg[j]);
+        if (pg[j] != 0.f) gg += km * pg[j] * ((lpg[j] - lpa[j]) - kl) + a.ent_coef * pg[j] * (lpg[j] + ent);
+        float ga = a.alpha * c_a * (onehot - pa[j]) + (pa[j] - pg[j]);
+        if (!legal[j]) { gg = 0.f; ga = 0.f; }
+        pog[j] = a.inv_R * gg;
+        poa[j] = a.inv_R * ga;
+      }
+      if (c4 + 3 < a.lddg) *reinterpret_cast<float4*>(a.dg_logits + r * a.lddg + c4) = og;
+      else for (int j = 0; j < 4; ++j) if (c4 + j < a.lddg) a.dg_logits[r * a.lddg + c4 + j] = pog[j];
+      if (c4 + 3 < a.lddda) *reinterpret_cast<float4*>(a.da_logits + r * a.lddda + c4) = oa;
+      else for (int j = 0; j < 4; ++j) if (c4 + j < a.lddda) a.da_logits[r * a.lddda + c4 + j] = poa[j];
+      if (l16 == 0) {
+        a.dvalue[r] = a.inv_R * a.vf_coef * dvl;
+        acc[0] += pgl; acc[1] += km * kl; acc[2] += ent; acc[3] += vl; acc[4] += apl; acc[5] += kl;
+      }
     }
-    for (long k = a.K; k < a.lddg; ++k) dg[k] = 0.f;
-    for (long k = a.K; k < a.lddda; ++k) da[k] = 0.f;
-    acc[0] += pgl; acc[1] += km * kl; acc[2] += ent; acc[3] += vl; acc[4] += apl; acc[5] += kl;
   }
-  for (int q = 0; q < 6; ++q) sh[q][threadIdx.x] = acc[q];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const float w = wave_sum(acc[q]);
+    if (lane == 0) sh[q][wave] = (double)w;
+  }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o)
-      for (int q = 0; q < 6; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x < 6) a.part[8 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0];
+  if (threadIdx.x < 6) a.part[8 * blockIdx.x + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 // out: [total, value_loss, actor_loss, guider_loss, kl_loss, entropy, actor_kl, total_guider, total_actor]
 __global__ void k_loss_final(const double* __restrict__ part, int nb, float inv_R, float ent_coef, float vf_coef, float alpha,
@@ -358,8 +373,11 @@ extern "C" int magpo_loss_fwd_bwd(const float* g_logits, long ldg, const float* 
                                   long lddg, float* da_logits, long lddda, float* dvalue, double* workspace, float* loss_out,
                                   long R, int K, float clip_eps, float clip_gpo, float ent_coef, float vf_coef, float alpha,
                                   hipStream_t st) {
-  if (K > ldg || K > lda || K > lddg || K > lddda || clip_gpo <= 0.f) { set_error("loss: bad K / strides / clip_gpo"); return MAGPO_EINVAL; }
-  int nb = (int)((R + 255) / 256);
+  if (K > 64 || K > ldg || K > lda || K > lddg || K > lddda || (lddg & 3) || (lddda & 3) || clip_gpo <= 0.f) {
+    set_error("loss: need K <= 64, K <= strides, gradient strides multiples of 4, clip_gpo > 0");
+    return MAGPO_EINVAL;
+  }
+  int nb = (int)((R + 15) / 16);
   if (nb > 1024) nb = 1024;
   LossArgs a{g_logits, a_logits, ldg, lda, mask, action, old_logp, old_value, value, adv, targets, adv_stats,
              dg_logits, da_logits, lddg, lddda, dvalue, workspace, R, K, clip_eps, logf(clip_gpo), ent_coef, vf_coef, alpha,

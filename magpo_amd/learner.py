@@ -120,7 +120,7 @@ class EnvGroup:
 
 class MagpoLearner:
     def __init__(self, env_cfg: CoordSumConfig, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
-                 decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 256, num_groups: int = 1):
+                 decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 512, num_groups: int = 1):
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
         F = A + 1  # AgentIDWrapper (observation.py:42-54), add_agent_id: True

@@ -44,7 +44,7 @@ class _Bufs:
 class SableGuider:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, embed_dim: int = 64, n_head: int = 1,
                  n_block: int = 1, decay_scaling_factor: float = 0.8, use_pe: bool = True, max_pos: int = 101,
-                 wgrad_groups: int = 256, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
+                 wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
         if embed_dim != 64 or n_head != 1 or n_block != 1:
             raise NotImplementedError("gfx950 Sable kernels: embed_dim=64, n_head=1, n_block=1 only (SURVEY 8f rank 3)")
         if obs_dim > 32 or action_dim > 32:
