@@ -80,6 +80,84 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int
   }
 }
 
+// Wave-autonomous variant for KIN in {64, 128}: every wave owns 32*NCB output columns, keeps their weight
+// fragments in VGPRs for the whole persistent loop and streams 32-row activation tiles straight from HBM
+// (each lane reads one contiguous half-row, a wave one contiguous 32 x KIN block).  No LDS, no barriers:
+// latency is hidden by several independent waves per SIMD.
+template <int KIN, int NCB>
+__global__ __launch_bounds__(256) void k_linear_w(const float* __restrict__ X, int ldx, const float* __restrict__ Wt,
+                                                  const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                  float* __restrict__ Ypre, int R, int NOUT, int act) {
+  constexpr int KH = KIN / 2;  // k values per lane half
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, h = lane >> 5;
+  const int c0 = (blockIdx.y * 4 + wave) * 32 * NCB;
+  if (c0 >= NOUT) return;
+  float4 wf[NCB][KH / 4];
+  float bv[NCB];
+#pragma unroll
+  for (int b = 0; b < NCB; ++b) {
+    const int n = c0 + 32 * b + lr;
+    const bool on = c0 + 32 * b < NOUT;  // Wt rows are padded to a multiple of 32
+    bv[b] = (bias && n < NOUT) ? bias[n] : 0.f;
+#pragma unroll
+    for (int u = 0; u < KH / 4; ++u)
+      wf[b][u] = on ? *reinterpret_cast<const float4*>(Wt + (long)n * KIN + h * KH + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int ntiles = (R + 31) >> 5;
+  float4 af[KH / 4], an[KH / 4];
+  auto fetch = [&](int tile, float4* dst) {
+    const long row = (long)tile * 32 + lr;
+    if (tile < ntiles && row < R) {
+      const float* xp = X + row * (long)ldx + h * KH;
+#pragma unroll
+      for (int u = 0; u < KH / 4; ++u) dst[u] = *reinterpret_cast<const float4*>(xp + 4 * u);
+    } else {
+#pragma unroll
+      for (int u = 0; u < KH / 4; ++u) dst[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(blockIdx.x, af);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    fetch(tile + gridDim.x, an);  // next tile's activations are in flight while this tile's MFMAs run
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int b = 0; b < NCB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KH / 4; ++u) {
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].x, wf[b][u].x, acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].y, wf[b][u].y, acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].z, wf[b][u].z, acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].w, wf[b][u].w, acc[b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < NCB; ++b) {
+      const int n = c0 + 32 * b + lr;
+      if (n < NOUT) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long gr = (long)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (gr < R) {
+            float v = acc[b][i] + bv[b];
+            if (Ypre) Ypre[gr * (long)ldy + n] = v;
+            if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == ACT_GELU) v = gelu_tanh(v);
+            else if (act == ACT_SWISH) v = swishf_(v);
+            Y[gr * (long)ldy + n] = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KH / 4; ++u) af[u] = an[u];
+  }
+}
+
 // dW slab: grid (G, ceil(NOUT / (64 NB)), KIN / 64).  Software pipeline: the next row tile is fetched
 // from HBM into registers while the MFMAs of the current tile run out of LDS.
 template <int NB>
@@ -230,6 +308,19 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
                             long R, int KIN, int NOUT, int act, hipStream_t stream) {
   if (R <= 0) return MAGPO_OK;
   if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
+  if (KIN == 64 || KIN == 128) {
+    // wave-autonomous path: 64 columns per wave, up to 4 waves (256 columns) per workgroup
+    const int cpw = KIN == 64 ? 64 : 32;  // columns per wave
+    const int ncg = (NOUT + cpw - 1) / cpw;
+    const int wpb = ncg < 4 ? ncg : 4;
+    const long ntiles = (R + 31) / 32;
+    long walkers = 2048 / wpb;  // 2 waves per SIMD on 256 CUs (register-limited)
+    if (walkers > ntiles) walkers = ntiles;
+    dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
+    if (KIN == 64) hipLaunchKernelGGL((k_linear_w<64, 2>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
+    else hipLaunchKernelGGL((k_linear_w<128, 1>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
+    return check_launch("magpo_linear");
+  }
   dim3 grid((unsigned)((R + 63) / 64)), block(256);
   size_t lds = (size_t)64 * (KIN + LDP) * sizeof(float);
 #define LAUNCH(K_)                                                                                              \
