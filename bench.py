@@ -61,8 +61,8 @@ class KernelTimer:
             byts = 4.0 * rows * 64 * (4 if fwd else 7) + 4.0 * nseq * nch * 4096
             return ("ret_chunk_fwd" if fwd else "ret_chunk_bwd"), byts, gemms * 2.0 * 64 ** 3 * nseq * nch
         if name == "magpo_retention_recurrent":
-            nenv, ntok = a[10], a[11]
-            return "ret_recurrent", 4.0 * nenv * (2 * 4096 + 4 * ntok * 64), 4.0 * nenv * ntok * 4096 + 2.0 * nenv * 4096
+            nenv, ntok, wr = a[10], a[11], a[14]
+            return "ret_recurrent", 4.0 * nenv * ((2 if wr else 1) * 4096 + 4 * ntok * 64), 4.0 * nenv * ntok * 4096 + 2.0 * nenv * 4096
         if name == "magpo_gru_scan_fwd":
             nseq, T, A = a[9], a[10], a[11]
             if T == 1:

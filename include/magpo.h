@@ -96,8 +96,8 @@ int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk
                               long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
                               int masked, float kappa, magpo_stream_t stream);
 int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
-                              long env_stride_rows, float* r, long ldr, int nenv, int ntok, float decay,
-                              magpo_stream_t stream);
+                              long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
+                              int write_state, magpo_stream_t stream);
 int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned char* done, int nenv,
                                  magpo_stream_t stream);
 

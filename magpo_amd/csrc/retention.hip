@@ -346,40 +346,64 @@ __global__ __launch_bounds__(256) void k_ret_chunk_bwd(RetBwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Recurrent form for acting (retention.py:102-115): one workgroup per env.
-//   S <- decay * S + sum_{a<ntok} k_a^T v_a ;  ret_a = q_a S        (all ntok tokens see the full update)
+//   S_eff = decay * S + sum_{a<ntok} k_a^T v_a ;  ret_a = q_a S_eff   for a in [ret_from, ntok)
+// The state is written back only when write_state != 0: the autoregressive decoder calls this once per
+// agent with the tokens decoded so far (ntok = i + 1, ret_from = i) and stores the state after the last
+// agent only, so a decoder state costs A reads + 1 write per env step instead of A reads + A writes.
 __global__ __launch_bounds__(256) void k_ret_recurrent(float* __restrict__ S, const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, long ldq, long ldk, long ldv, long env_stride_rows,
-                                                       float* __restrict__ r, long ldr, int ntok, float decay) {
-  __shared__ float qs[16][64], ks[16][64], vs[16][64];
-  __shared__ float part[4][16][64];
-  const int tid = threadIdx.x, j = tid & 63, rg = tid >> 6;
+                                                       float* __restrict__ r, long ldr, int ntok, int ret_from, float decay,
+                                                       int write_state) {
+  // thread -> 4 state columns (c4..c4+3) x 4 state rows (rw, rw+16, rw+32, rw+48): float4 accesses, a wave
+  // touches 4 consecutive 256-B rows (1 KiB contiguous) per instruction.
+  __shared__ __align__(16) float qs[16][64], ks[16][64], vs[16][64];
+  __shared__ __align__(16) float part[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c4 = 4 * (tid & 15), rw = tid >> 4;
   const long env = blockIdx.x;
   const long row0 = env * env_stride_rows;
-  for (int i = tid; i < ntok * 64; i += 256) {
-    int a = i >> 6, c = i & 63;
-    qs[a][c] = q[(row0 + a) * ldq + c];
-    ks[a][c] = k[(row0 + a) * ldk + c];
-    vs[a][c] = v[(row0 + a) * ldv + c];
+  float* Se = S + env * 4096;
+  float4 s[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = *reinterpret_cast<const float4*>(Se + (rw + 16 * i) * 64 + c4);
+  for (int i = tid; i < ntok * 16; i += 256) {
+    const int a = i >> 4, cc = 4 * (i & 15);
+    if (a >= ret_from) *reinterpret_cast<float4*>(&qs[a][cc]) = *reinterpret_cast<const float4*>(q + (row0 + a) * ldq + cc);
+    *reinterpret_cast<float4*>(&ks[a][cc]) = *reinterpret_cast<const float4*>(k + (row0 + a) * ldk + cc);
+    *reinterpret_cast<float4*>(&vs[a][cc]) = *reinterpret_cast<const float4*>(v + (row0 + a) * ldv + cc);
   }
   __syncthreads();
-  float* Se = S + env * 4096;
-  float s[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float x = decay * Se[(16 * rg + i) * 64 + j];
-    for (int a = 0; a < ntok; ++a) x += ks[a][16 * rg + i] * vs[a][j];
-    s[i] = x;
-    Se[(16 * rg + i) * 64 + j] = x;
+  for (int i = 0; i < 4; ++i) {
+    s[i].x *= decay; s[i].y *= decay; s[i].z *= decay; s[i].w *= decay;
   }
   for (int a = 0; a < ntok; ++a) {
-    float p = 0.f;
+    const float4 vv = *reinterpret_cast<const float4*>(&vs[a][c4]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) p += qs[a][16 * rg + i] * s[i];
-    part[rg][a][j] = p;
+    for (int i = 0; i < 4; ++i) {
+      const float kk = ks[a][rw + 16 * i];
+      s[i].x += kk * vv.x; s[i].y += kk * vv.y; s[i].z += kk * vv.z; s[i].w += kk * vv.w;
+    }
+  }
+  if (write_state) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Se + (rw + 16 * i) * 64 + c4) = s[i];
+  }
+  for (int a = ret_from; a < ntok; ++a) {
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float qq = qs[a][rw + 16 * i];
+      p.x += qq * s[i].x; p.y += qq * s[i].y; p.z += qq * s[i].z; p.w += qq * s[i].w;
+    }
+    // sum over the 4 row-lanes of the wave (lanes l, l^16, l^32, l^48), then over the 4 waves through LDS
+    p.x += __shfl_xor(p.x, 16, 64); p.y += __shfl_xor(p.y, 16, 64); p.z += __shfl_xor(p.z, 16, 64); p.w += __shfl_xor(p.w, 16, 64);
+    p.x += __shfl_xor(p.x, 32, 64); p.y += __shfl_xor(p.y, 32, 64); p.z += __shfl_xor(p.z, 32, 64); p.w += __shfl_xor(p.w, 32, 64);
+    if (lane < 16) *reinterpret_cast<float4*>(&part[wave][a][c4]) = p;
   }
   __syncthreads();
-  for (int i = tid; i < ntok * 64; i += 256) {
-    int a = i >> 6, c = i & 63;
+  for (int i = tid; i < (ntok - ret_from) * 64; i += 256) {
+    int a = ret_from + (i >> 6), c = i & 63;
     r[(row0 + a) * ldr + c] = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
   }
 }
@@ -435,10 +459,11 @@ extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* 
 }
 
 extern "C" int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
-                                         long env_stride_rows, float* r, long ldr, int nenv, int ntok, float decay,
-                                         hipStream_t st) {
-  if (ntok < 1 || ntok > 16) { set_error("retention_recurrent: 1 <= ntok <= 16"); return MAGPO_EINVAL; }
-  hipLaunchKernelGGL(k_ret_recurrent, dim3(nenv), dim3(256), 0, st, S, q, k, v, ldq, ldk, ldv, env_stride_rows, r, ldr, ntok, decay);
+                                         long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
+                                         int write_state, hipStream_t st) {
+  if (ntok < 1 || ntok > 16 || ret_from < 0 || ret_from >= ntok) { set_error("retention_recurrent: 1 <= ntok <= 16, 0 <= ret_from < ntok"); return MAGPO_EINVAL; }
+  hipLaunchKernelGGL(k_ret_recurrent, dim3(nenv), dim3(256), 0, st, S, q, k, v, ldq, ldk, ldv, env_stride_rows, r, ldr, ntok, ret_from,
+                     decay, write_state);
   return check_launch("magpo_retention_recurrent");
 }
 

@@ -138,8 +138,8 @@ class SableGuider:
         L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0,
                v["enc.ln.scale"], self.pe, pos_tok, 1, self.npos, None, 0, xn, E, kin, E, R, st)
         self.lin(kin, E, self.wt["qkvg"], None, qkvg, 4 * E, R, E, 4 * E)
-        L.call("magpo_retention_recurrent", s_enc, qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, r, E, N, A,
-               self.kappa, st)
+        L.call("magpo_retention_recurrent", s_enc, qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, r, E, N, A, 0,
+               self.kappa, 1, st)
         L.call("magpo_retpost_fwd", r, E, qkvg[:, 3 * E:], 4 * E, v["enc.block0.retn.gn.scale"], v["enc.block0.retn.gn.bias"],
                u, E, R, st)
         self.lin(u, E, self.wt["wo"], None, y, E, R, E, E)
@@ -152,26 +152,28 @@ class SableGuider:
             return
         # autoregressive decoder (decode.py:111-153): one token per env per iteration
         prev = b.get("a_prev", (N, A), torch.int32, zero=True)
-        xa = b.get("d_xa", (N, E)); kin1 = b.get("d_kin1", (N, E)); qkvg1 = b.get("d_qkvg1", (N, 4 * E))
-        r1 = b.get("d_r1", (N, E)); u1 = b.get("d_u1", (N, E)); y1 = b.get("d_y1", (N, E))
-        c = b.get("d_c", (N, E)); cpe = b.get("d_cpe", (N, E)); q2 = b.get("d_q2", (N, E)); kvg2 = b.get("d_kvg2", (N, 3 * E))
-        r2 = b.get("d_r2", (N, E)); u2 = b.get("d_u2", (N, E)); y2 = b.get("d_y2", (N, E)); out = b.get("d_out", (N, E))
+        # per-agent projections stay resident ([N, A, .]) so that the retention states are read once per agent and
+        # written once per step: iteration i applies the rank-1 updates of tokens 0..i on the fly
+        xa = b.get("d_xa", (N, E)); kin1 = b.get("d_kin1", (N, E)); qkvg1 = b.get("d_qkvg1", (N * A, 4 * E))
+        r1 = b.get("d_r1", (N * A, E)); u1 = b.get("d_u1", (N, E)); y1 = b.get("d_y1", (N, E))
+        c = b.get("d_c", (N, E)); cpe = b.get("d_cpe", (N, E)); q2 = b.get("d_q2", (N * A, E)); kvg2 = b.get("d_kvg2", (N * A, 3 * E))
+        r2 = b.get("d_r2", (N * A, E)); u2 = b.get("d_u2", (N, E)); y2 = b.get("d_y2", (N, E)); out = b.get("d_out", (N, E))
         hp = b.get("d_hp", (N, E)); hn = b.get("d_hn", (N, E)); logits = b.get("d_logits", (N, E), zero=True)
         for i in range(A):
-            dec = self.kappa if i == 0 else 1.0
+            last = 1 if i == A - 1 else 0
             L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev[:, i:], A, v["dec.ln.scale"], self.pe,
                    pos, 1, self.npos, None, 0, xa, E, kin1, E, N, st)
-            self.lin(kin1, E, self.wt["qkvg1"], None, qkvg1, 4 * E, N, E, 4 * E)
-            L.call("magpo_retention_recurrent", s_d1, qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, 1, r1, E, N, 1,
-                   dec, st)
-            L.call("magpo_retpost_fwd", r1, E, qkvg1[:, 3 * E:], 4 * E, v["dec.block0.retn1.gn.scale"],
+            self.lin(kin1, E, self.wt["qkvg1"], None, qkvg1[i:], A * 4 * E, N, E, 4 * E)
+            L.call("magpo_retention_recurrent", s_d1, qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, A, r1, E, N, i + 1, i,
+                   self.kappa, last, st)
+            L.call("magpo_retpost_fwd", r1[i:], A * E, qkvg1[i:, 3 * E:], A * 4 * E, v["dec.block0.retn1.gn.scale"],
                    v["dec.block0.retn1.gn.bias"], u1, E, N, st)
             self.lin(u1, E, self.wt["wo1"], None, y1, E, N, E, E)
             L.call("magpo_resnorm_fwd", xa, E, y1, E, v["dec.block0.ln1.scale"], None, self.pe, pos, 1, self.npos, c, E, cpe, E, N, st)
-            self.lin(reppe[i:], A * E, self.wt["q2"], None, q2, E, N, E, E)
-            self.lin(cpe, E, self.wt["kvg2"], None, kvg2, 3 * E, N, E, 3 * E)
-            L.call("magpo_retention_recurrent", s_d2, q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, 1, r2, E, N, 1, dec, st)
-            L.call("magpo_retpost_fwd", r2, E, kvg2[:, 2 * E:], 3 * E, v["dec.block0.retn2.gn.scale"],
+            self.lin(reppe[i:], A * E, self.wt["q2"], None, q2[i:], A * E, N, E, E)
+            self.lin(cpe, E, self.wt["kvg2"], None, kvg2[i:], A * 3 * E, N, E, 3 * E)
+            L.call("magpo_retention_recurrent", s_d2, q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, A, r2, E, N, i + 1, i, self.kappa, last, st)
+            L.call("magpo_retpost_fwd", r2[i:], A * E, kvg2[i:, 2 * E:], A * 3 * E, v["dec.block0.retn2.gn.scale"],
                    v["dec.block0.retn2.gn.bias"], u2, E, N, st)
             self.lin(u2, E, self.wt["wo2"], None, y2, E, N, E, E)
             L.call("magpo_resnorm_fwd", rep[i:], A * E, y2, E, v["dec.block0.ln2.scale"], v["dec.block0.ln3.scale"], None, None, 0, 0,

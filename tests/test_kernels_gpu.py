@@ -254,15 +254,18 @@ def test_retention_recurrent(L, stream):
     q, k, v = (torch.randn(N * A, 64, generator=g) for _ in range(3))
     Sd = dev(S)
     r = torch.zeros(N * A, 64, device=DEV)
-    L.call("magpo_retention_recurrent", Sd, dev(q), 64, dev(k), 64, dev(v), 64, A, r, 64, N, A, 0.775, stream)
+    L.call("magpo_retention_recurrent", Sd, dev(q), 64, dev(k), 64, dev(v), 64, A, r, 64, N, A, 0, 0.775, 1, stream)
     qq, kk, vv = (t.double().reshape(N, A, 64) for t in (q, k, v))
     Sn = 0.775 * S.double() + kk.transpose(1, 2) @ vv
     close(Sd, Sn, what="S"); close(r.reshape(N, A, 64), qq @ Sn, what="ret")
-    # single token (decoder iteration): token 2 of each env, no decay
+    # decoder iteration i = 2: tokens 0..2 applied on the fly, output for token 2 only, state left untouched
     S2 = dev(S)
-    L.call("magpo_retention_recurrent", S2, dev(q)[2:], 64, dev(k)[2:], 64, dev(v)[2:], 64, A, r[2:], 64, N, 1, 1.0, stream)
-    Sn = S.double() + kk[:, 2:3].transpose(1, 2) @ vv[:, 2:3]
-    close(S2, Sn, what="S1"); close(r.reshape(N, A, 64)[:, 2], (qq[:, 2:3] @ Sn)[:, 0], what="ret1")
+    r2 = torch.zeros(N * A, 64, device=DEV)
+    L.call("magpo_retention_recurrent", S2, dev(q), 64, dev(k), 64, dev(v), 64, A, r2, 64, N, 3, 2, 0.775, 0, stream)
+    Sn = 0.775 * S.double() + kk[:, :3].transpose(1, 2) @ vv[:, :3]
+    close(S2, S, 0, 0, "state must not be written")
+    close(r2.reshape(N, A, 64)[:, 2], (qq[:, 2:3] @ Sn)[:, 0], what="ret token 2")
+    assert r2.reshape(N, A, 64)[:, :2].abs().max().item() == 0 and r2.reshape(N, A, 64)[:, 3].abs().max().item() == 0
 
 
 def test_gru_scan(L, stream):
