@@ -35,10 +35,19 @@ __device__ __forceinline__ long tok_row(int rho, int t, int T, int A) {
   return ((long)seq * T + t) * A + ag;
 }
 
-__global__ __launch_bounds__(256) void k_gru_scan_fwd(GruArgs a) {
+// W_h^T fragments (3 gates x 128 k x 32 columns per wave = 192 VGPRs) stay in registers for the whole scan;
+// wave w owns hidden columns 32w..32w+31 for both 32-row halves.  One wave per SIMD (launch bound 1).
+__global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
   __shared__ __align__(16) float hbuf[2][64 * HP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int rho0 = blockIdx.x * 64;
+  const int col = 32 * wave + lr;
+  float4 wf[3][16];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wf[g][u] = *reinterpret_cast<const float4*>(a.Wht + ((long)g * H + col) * H + 64 * h + 4 * u);
+  const float bhn = a.b_hn[col];
   // initial carry (with the reset of step 0 applied)
   for (int i = tid; i < 64 * (H / 4); i += 256) {
     int r = i / (H / 4), c4 = i - r * (H / 4);
@@ -53,56 +62,59 @@ __global__ __launch_bounds__(256) void k_gru_scan_fwd(GruArgs a) {
     }
     *reinterpret_cast<float4*>(&hbuf[0][r * HP + 4 * c4]) = v;
   }
+  // per-lane row bookkeeping for the 2 x 16 accumulator rows
   __syncthreads();
   for (int t = 0; t < a.T; ++t) {
     const float* hold = hbuf[t & 1];
     float* hnew = hbuf[(t + 1) & 1];
 #pragma unroll 1
-    for (int job = 0; job < 2; ++job) {
-      const int jb = wave * 2 + job, wr = jb & 1, cb = jb >> 1;
-      const int col = 32 * cb + lr;
-      f32x16 ar, az, an;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { ar[i] = 0.f; az[i] = 0.f; an[i] = 0.f; }
-#pragma unroll 1
-      for (int kc = 0; kc < 2; ++kc) {
-        const float* ap = hold + (32 * wr + lr) * HP + kc * 64 + 32 * h;
-        const float* br = a.Wht + (long)col * H + kc * 64 + 32 * h;
-        const float* bz = br + (long)H * H;
-        const float* bn = bz + (long)H * H;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float4 av = *reinterpret_cast<const float4*>(ap + 4 * u);
-          const float4 r4 = *reinterpret_cast<const float4*>(br + 4 * u);
-          const float4 z4 = *reinterpret_cast<const float4*>(bz + 4 * u);
-          const float4 n4 = *reinterpret_cast<const float4*>(bn + 4 * u);
-          ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, r4.x, ar, 0, 0, 0);
-          az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, z4.x, az, 0, 0, 0);
-          an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, n4.x, an, 0, 0, 0);
-          ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, r4.y, ar, 0, 0, 0);
-          az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, z4.y, az, 0, 0, 0);
-          an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, n4.y, an, 0, 0, 0);
-          ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, r4.z, ar, 0, 0, 0);
-          az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, z4.z, az, 0, 0, 0);
-          an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, n4.z, an, 0, 0, 0);
-          ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, r4.w, ar, 0, 0, 0);
-          az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, z4.w, az, 0, 0, 0);
-          an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, n4.w, an, 0, 0, 0);
-        }
-      }
-      const float bhn = a.b_hn[col];
+    for (int wr = 0; wr < 2; ++wr) {
+      // issue this job's xi loads first: they are in flight under the 192 MFMAs below
+      float xr[16], xz[16], xn[16];
+      long rowi[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
         const int rho = rho0 + rl;
-        float hn_new = 0.f;
         if (rho < a.NR) {
           const long row = tok_row(rho, t, a.T, a.A);
+          rowi[i] = row;
           const float* x = a.xi + row * G3;
+          xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
+        } else {
+          rowi[i] = -1; xr[i] = 0.f; xz[i] = 0.f; xn[i] = 0.f;
+        }
+      }
+      f32x16 ar, az, an;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { ar[i] = 0.f; az[i] = 0.f; an[i] = 0.f; }
+      const float* ap = hold + (32 * wr + lr) * HP + 64 * h;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + 4 * u);
+        ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[0][u].x, ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[1][u].x, az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[2][u].x, an, 0, 0, 0);
+        ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[0][u].y, ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[1][u].y, az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[2][u].y, an, 0, 0, 0);
+        ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[0][u].z, ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[1][u].z, az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[2][u].z, an, 0, 0, 0);
+        ar = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[0][u].w, ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[1][u].w, az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[2][u].w, an, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        float hn_new = 0.f;
+        if (rowi[i] >= 0) {
+          const long row = rowi[i];
           const float hb = an[i] + bhn;
-          const float r = sigmoidf_(x[col] + ar[i]);
-          const float z = sigmoidf_(x[H + col] + az[i]);
-          const float n = tanhf(x[2 * H + col] + r * hb);
+          const float r = sigmoidf_(xr[i] + ar[i]);
+          const float z = sigmoidf_(xz[i] + az[i]);
+          const float n = tanhf(xn[i] + r * hb);
           const float hp = hold[rl * HP + col];
           hn_new = (1.0f - z) * n + z * hp;
           a.hs[row * H + col] = hn_new;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(256) void k_gru_scan_fwd(GruArgs a) {
             g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
           }
           if (a.hprev) a.hprev[row * H + col] = hp;
-          if (t + 1 < a.T && a.reset[(long)(rho / a.A) * a.T + t + 1]) hn_new = 0.f;
+          if (t + 1 < a.T && a.reset[(long)((rho0 + rl) / a.A) * a.T + t + 1]) hn_new = 0.f;
         }
         hnew[rl * HP + col] = hn_new;
       }
@@ -132,71 +144,86 @@ struct GruBwdArgs {
   int T, A, NR;
 };
 
-__global__ __launch_bounds__(256) void k_gru_scan_bwd(GruBwdArgs a) {
+__global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* dht = smem;                 // [64][HP]   dL/dh carried from step t+1 (already includes the direct z path)
   float* dhht = dht + 64 * HP;       // [64][G3P]  dhh of the current step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int rho0 = blockIdx.x * 64;
+  const int col = 32 * wave + lr;
+  // W_h (natural [H][3H]) as the B operand of dh_prev = dhh @ W_h^T: lane (col, h) holds k in [192 h, 192 h + 192)
+  float4 wf[48];
+#pragma unroll
+  for (int u = 0; u < 48; ++u) wf[u] = *reinterpret_cast<const float4*>(a.Wh + (long)col * G3 + 192 * h + 4 * u);
   for (int i = tid; i < 64 * HP; i += 256) dht[i] = 0.f;
   float bacc = 0.f;  // thread owns column (tid & 127) for rows (tid >> 7) + 2k
   __syncthreads();
+  const int c = tid & 127;
   for (int t = a.T - 1; t >= 0; --t) {
-    // ---- elementwise phase: thread handles column c = tid & 127, rows rl = (tid >> 7) + 2 k
-    const int c = tid & 127;
-    for (int rl = tid >> 7; rl < 64; rl += 2) {
-      const int rho = rho0 + rl;
-      float d_r = 0.f, d_z = 0.f, d_n = 0.f, d_hb = 0.f, carry = 0.f;
-      if (rho < a.NR) {
-        const int seq = rho / a.A;
-        const long row = tok_row(rho, t, a.T, a.A);
-        const bool rst = a.reset[(long)seq * a.T + t] != 0;
-        const float hp = a.hprev[row * H + c];
-        const float* g = a.gates + row * (4 * H);
-        const float r = g[c], z = g[H + c], n = g[2 * H + c], hb = g[3 * H + c];
-        const float dh = a.dhs[row * H + c] + dht[rl * HP + c];
-        const float dn = dh * (1.0f - z);
-        const float dz = dh * (hp - n);
-        const float dan = dn * (1.0f - n * n);
-        d_n = dan;
-        d_hb = dan * r;
-        d_r = dan * hb * r * (1.0f - r);
-        d_z = dz * z * (1.0f - z);
-        carry = rst ? 0.f : dh * z;
-        float* dx = a.dxi + row * G3;
-        dx[c] = d_r; dx[H + c] = d_z; dx[2 * H + c] = d_n;
-        float* dq = a.dhh + row * G3;
-        dq[c] = d_r; dq[H + c] = d_z; dq[2 * H + c] = d_hb;
-        bacc += d_hb;
-        if (rst) { d_r = 0.f; d_z = 0.f; d_hb = 0.f; }  // no gradient into the (zeroed) previous state
+    // ---- elementwise phase: column c, rows rl = (tid >> 7) + 2 k, in groups of 8 rows with all loads issued first
+#pragma unroll 1
+    for (int kb = 0; kb < 32; kb += 8) {
+      float gr[8], gz[8], gn[8], gh[8], hp[8], dh[8];
+      long rowv[8];
+      bool rst[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rl = (tid >> 7) + 2 * (kb + k);
+        const int rho = rho0 + rl;
+        if (rho < a.NR) {
+          const long row = tok_row(rho, t, a.T, a.A);
+          rowv[k] = row;
+          rst[k] = a.reset[(long)(rho / a.A) * a.T + t] != 0;
+          const float* g = a.gates + row * (4 * H);
+          gr[k] = g[c]; gz[k] = g[H + c]; gn[k] = g[2 * H + c]; gh[k] = g[3 * H + c];
+          hp[k] = a.hprev[row * H + c];
+          dh[k] = a.dhs[row * H + c];
+        } else {
+          rowv[k] = -1; rst[k] = false; gr[k] = gz[k] = gn[k] = gh[k] = hp[k] = dh[k] = 0.f;
+        }
       }
-      dhht[rl * G3P + c] = d_r;
-      dhht[rl * G3P + H + c] = d_z;
-      dhht[rl * G3P + 2 * H + c] = d_hb;
-      dht[rl * HP + c] = carry;  // direct path; the GEMM below adds dhh @ W_h^T
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rl = (tid >> 7) + 2 * (kb + k);
+        float d_r = 0.f, d_z = 0.f, d_hb = 0.f, carry = 0.f;
+        if (rowv[k] >= 0) {
+          const float r = gr[k], z = gz[k], n = gn[k], hb = gh[k];
+          const float dht_ = dh[k] + dht[rl * HP + c];
+          const float dn = dht_ * (1.0f - z);
+          const float dz = dht_ * (hp[k] - n);
+          const float dan = dn * (1.0f - n * n);
+          d_hb = dan * r;
+          d_r = dan * hb * r * (1.0f - r);
+          d_z = dz * z * (1.0f - z);
+          carry = rst[k] ? 0.f : dht_ * z;
+          float* dx = a.dxi + rowv[k] * G3;
+          dx[c] = d_r; dx[H + c] = d_z; dx[2 * H + c] = dan;
+          float* dq = a.dhh + rowv[k] * G3;
+          dq[c] = d_r; dq[H + c] = d_z; dq[2 * H + c] = d_hb;
+          bacc += d_hb;
+          if (rst[k]) { d_r = 0.f; d_z = 0.f; d_hb = 0.f; }  // no gradient into the (zeroed) previous state
+        }
+        dhht[rl * G3P + c] = d_r;
+        dhht[rl * G3P + H + c] = d_z;
+        dhht[rl * G3P + 2 * H + c] = d_hb;
+        dht[rl * HP + c] = carry;  // direct path; the GEMM below adds dhh @ W_h^T
+      }
     }
     __syncthreads();
-    // ---- dh_prev += dhh[64][3H] @ W_h^T  -> [64][H]; 8 quadrant jobs, 2 per wave
+    // ---- dh_prev += dhh[64][3H] @ W_h^T  -> [64][H]; wave w owns columns 32w.. for both row halves
 #pragma unroll 1
-    for (int job = 0; job < 2; ++job) {
-      const int jb = wave * 2 + job, wr = jb & 1, cb = jb >> 1;
-      const int col = 32 * cb + lr;
+    for (int wr = 0; wr < 2; ++wr) {
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 1
-      for (int kc = 0; kc < G3 / 64; ++kc) {
-        const float* ap = dhht + (32 * wr + lr) * G3P + kc * 64 + 32 * h;
-        const float* bp = a.Wh + (long)col * G3 + kc * 64 + 32 * h;
+      const float* ap = dhht + (32 * wr + lr) * G3P + 192 * h;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float4 av = *reinterpret_cast<const float4*>(ap + 4 * u);
-          const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * u);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-        }
+      for (int u = 0; u < 48; ++u) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + 4 * u);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[u].w, acc, 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
