@@ -51,6 +51,9 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// hardware exp2 / rcp based variants for the GRU gates (abs. error ~1e-7, far inside the fp32 parity tolerance)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float swish_grad(float x) {
   float s = sigmoidf_(x);

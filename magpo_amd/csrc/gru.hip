@@ -62,7 +62,14 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
     }
     *reinterpret_cast<float4*>(&hbuf[0][r * HP + 4 * c4]) = v;
   }
-  // per-lane row bookkeeping for the 2 x 16 accumulator rows
+  // per-row bookkeeping (no integer division inside the scan): token row of step 0 and sequence index
+  __shared__ long rbase[64];
+  __shared__ int rseq[64];
+  if (tid < 64) {
+    const int rho = rho0 + tid;
+    if (rho < a.NR) { rbase[tid] = tok_row(rho, 0, a.T, a.A); rseq[tid] = rho / a.A; }
+    else { rbase[tid] = -1; rseq[tid] = 0; }
+  }
   __syncthreads();
   for (int t = 0; t < a.T; ++t) {
     const float* hold = hbuf[t & 1];
@@ -75,9 +82,9 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int rho = rho0 + rl;
-        if (rho < a.NR) {
-          const long row = tok_row(rho, t, a.T, a.A);
+        const long rb = rbase[rl];
+        if (rb >= 0) {
+          const long row = rb + (long)t * a.A;
           rowi[i] = row;
           const float* x = a.xi + row * G3;
           xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
         if (rowi[i] >= 0) {
           const long row = rowi[i];
           const float hb = an[i] + bhn;
-          const float r = sigmoidf_(xr[i] + ar[i]);
-          const float z = sigmoidf_(xz[i] + az[i]);
-          const float n = tanhf(xn[i] + r * hb);
+          const float r = fast_sigmoid(xr[i] + ar[i]);
+          const float z = fast_sigmoid(xz[i] + az[i]);
+          const float n = fast_tanh(xn[i] + r * hb);
           const float hp = hold[rl * HP + col];
           hn_new = (1.0f - z) * n + z * hp;
           a.hs[row * H + col] = hn_new;
@@ -157,6 +164,13 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a) {
   for (int u = 0; u < 48; ++u) wf[u] = *reinterpret_cast<const float4*>(a.Wh + (long)col * G3 + 192 * h + 4 * u);
   for (int i = tid; i < 64 * HP; i += 256) dht[i] = 0.f;
   float bacc = 0.f;  // thread owns column (tid & 127) for rows (tid >> 7) + 2k
+  __shared__ long rbase[64];
+  __shared__ int rseq[64];
+  if (tid < 64) {
+    const int rho = rho0 + tid;
+    if (rho < a.NR) { rbase[tid] = tok_row(rho, 0, a.T, a.A); rseq[tid] = rho / a.A; }
+    else { rbase[tid] = -1; rseq[tid] = 0; }
+  }
   __syncthreads();
   const int c = tid & 127;
   for (int t = a.T - 1; t >= 0; --t) {
@@ -169,11 +183,11 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int rl = (tid >> 7) + 2 * (kb + k);
-        const int rho = rho0 + rl;
-        if (rho < a.NR) {
-          const long row = tok_row(rho, t, a.T, a.A);
+        const long rb = rbase[rl];
+        if (rb >= 0) {
+          const long row = rb + (long)t * a.A;
           rowv[k] = row;
-          rst[k] = a.reset[(long)(rho / a.A) * a.T + t] != 0;
+          rst[k] = a.reset[(long)rseq[rl] * a.T + t] != 0;
           const float* g = a.gates + row * (4 * H);
           gr[k] = g[c]; gz[k] = g[H + c]; gn[k] = g[2 * H + c]; gh[k] = g[3 * H + c];
           hp[k] = a.hprev[row * H + c];

@@ -51,6 +51,32 @@ __device__ __forceinline__ void store_state(float* __restrict__ dst, const float
   }
 }
 
+// register staging of a 64x64 tile (4 float4 per thread): fetch from HBM now, stash into LDS one chunk later
+struct TileRegs { float4 v[4]; };
+__device__ __forceinline__ void fetch_tile(TileRegs& t, const float* __restrict__ src, long ld, int nvalid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int r = i >> 4, c4 = i & 15;
+    t.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nvalid) t.v[j] = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
+  }
+}
+__device__ __forceinline__ void fetch_state(TileRegs& t, const float* __restrict__ src) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    t.v[j] = *reinterpret_cast<const float4*>(src + (i >> 4) * 64 + 4 * (i & 15));
+  }
+}
+__device__ __forceinline__ void stash_tile(float* __restrict__ dst, const TileRegs& t) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    *reinterpret_cast<float4*>(&dst[(i >> 4) * TL + 4 * (i & 15)]) = t.v[j];
+  }
+}
+
 // fragment of 32 k-values for a row-per-lane operand: T[row][32h .. 32h+31]
 struct Frag { float4 v[8]; };
 __device__ __forceinline__ Frag load_rowfrag(const float* __restrict__ tile, int row, int h) {
@@ -155,7 +181,7 @@ struct RetArgs {
   int T, A, masked; float kappa;
 };
 
-__global__ __launch_bounds__(256) void k_ret_chunk_fwd(RetArgs a) {
+__global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* Qs = smem;             // later P
   float* Ks = Qs + 64 * TL;
@@ -170,16 +196,30 @@ __global__ __launch_bounds__(256) void k_ret_chunk_fwd(RetArgs a) {
   const long row_base = (long)seq * a.T * a.A;
   const float* s0 = a.s0 ? a.s0 + (long)(a.seq_env ? a.seq_env[seq] : seq) * 4096 : nullptr;
   load_state(Ss, s0);
+  TileRegs pq, pk, pv;
+  {
+    const int nv0 = min(Lt, a.T) * a.A;
+    fetch_tile(pq, a.q + row_base * a.ldq, a.ldq, nv0);
+    fetch_tile(pk, a.k + row_base * a.ldk, a.ldk, nv0);
+    fetch_tile(pv, a.v + row_base * a.ldv, a.ldv, nv0);
+  }
   for (int c = 0; c < nch; ++c) {
     const int t0 = c * Lt;
     const int ltc = min(Lt, a.T - t0);
     const int nvalid = ltc * a.A;
     const long r0 = row_base + (long)c * L;
     __syncthreads();  // previous chunk finished with Qs/Ks/Vs, Ss updated
-    load_tile(Qs, a.q + r0 * a.ldq, a.ldq, nvalid);
-    load_tile(Ks, a.k + r0 * a.ldk, a.ldk, nvalid);
-    load_tile(Vs, a.v + r0 * a.ldv, a.ldv, nvalid);
+    stash_tile(Qs, pq);
+    stash_tile(Ks, pk);
+    stash_tile(Vs, pv);
     build_meta(meta, a.dones + (long)seq * a.T, t0, ltc, a.A, a.kappa);  // contains __syncthreads
+    if (c + 1 < nch) {  // next chunk's tiles are in flight while this chunk's GEMMs run
+      const int nvn = min(Lt, a.T - (t0 + Lt)) * a.A;
+      const long rn = r0 + L;
+      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn);
+      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn);
+      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn);
+    }
     if (a.states) store_state(a.states + ((long)seq * nch + c) * 4096, Ss);
 
     f32x16 sc, o;
@@ -235,7 +275,7 @@ struct RetBwdArgs {
   int T, A, masked; float kappa;
 };
 
-__global__ __launch_bounds__(256) void k_ret_chunk_bwd(RetBwdArgs a) {
+__global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* Qs = smem;
   float* Ks = Qs + 64 * TL;
@@ -253,18 +293,37 @@ __global__ __launch_bounds__(256) void k_ret_chunk_bwd(RetBwdArgs a) {
   const int nch = (a.T + Lt - 1) / Lt;
   const long row_base = (long)seq * a.T * a.A;
   load_state(Gs, nullptr);
+  TileRegs pq, pk, pv, pd, ps;
+  {
+    const int cl = nch - 1;
+    const int nvl = min(Lt, a.T - cl * Lt) * a.A;
+    const long rl = row_base + (long)cl * L;
+    fetch_tile(pq, a.q + rl * a.ldq, a.ldq, nvl);
+    fetch_tile(pk, a.k + rl * a.ldk, a.ldk, nvl);
+    fetch_tile(pv, a.v + rl * a.ldv, a.ldv, nvl);
+    fetch_tile(pd, a.dr + rl * a.lddr, a.lddr, nvl);
+    fetch_state(ps, a.states + ((long)seq * nch + cl) * 4096);
+  }
   for (int c = nch - 1; c >= 0; --c) {
     const int t0 = c * Lt;
     const int ltc = min(Lt, a.T - t0);
     const int nvalid = ltc * a.A;
     const long r0 = row_base + (long)c * L;
     __syncthreads();
-    load_tile(Qs, a.q + r0 * a.ldq, a.ldq, nvalid);
-    load_tile(Ks, a.k + r0 * a.ldk, a.ldk, nvalid);
-    load_tile(Vs, a.v + r0 * a.ldv, a.ldv, nvalid);
-    load_tile(Ds, a.dr + r0 * a.lddr, a.lddr, nvalid);
-    load_state(Ss, a.states + ((long)seq * nch + c) * 4096);
+    stash_tile(Qs, pq);
+    stash_tile(Ks, pk);
+    stash_tile(Vs, pv);
+    stash_tile(Ds, pd);
+    stash_tile(Ss, ps);
     build_meta(meta, a.dones + (long)seq * a.T, t0, ltc, a.A, a.kappa);
+    if (c > 0) {  // previous chunk (next in the reverse sweep): loads in flight during the 9 GEMMs below
+      const long rn = r0 - L;
+      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, L);
+      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, L);
+      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, L);
+      fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, L);
+      fetch_state(ps, a.states + ((long)seq * nch + c - 1) * 4096);
+    }
 
     // P = (Q K^T) * w ; dP = (dO V^T) * w
     Frag doa = load_rowfrag(Ds, 32 * wr + lr, h);
