@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to rehearse ranks on one GPU)")
+    ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
 
     from magpo_amd import distributed as mdist
@@ -169,7 +171,9 @@ def main():
     from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
     import torch.distributed as dist
 
-    rank, world, local = mdist.init_from_env()
+    rank, world, local = mdist.init_from_env(args.backend)
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)
     if world != args.gpus:
         if args.gpus != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -188,6 +192,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_max(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def log(msg):
         if rank == 0:
@@ -209,10 +220,11 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     lib().timer = None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max(elapsed)
+    if args.check_replicas and world > 1:
+        cs = float(learner.guider.P.flat.double().sum().item() + learner.actor.P.flat.double().abs().sum().item())
+        assert reduce_max(cs) == -reduce_max(-cs), "parameters diverged across ranks"
+        log(f"replica check ok (checksum {cs:.9f}); env targets differ per rank: {int(learner.env.target.sum().item())}")
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     if rank == 0:
         timer.collect()

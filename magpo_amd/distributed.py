@@ -19,6 +19,8 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))  # before RCCL creates its communicator
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
@@ -30,8 +32,16 @@ def make_grad_sync(world: int) -> Optional[Callable]:
     if world <= 1:
         return None
 
+    staged = dist.get_backend() == "gloo"  # CPU rehearsal / tests: stage through host memory
+
     def grad_sync(learner) -> float:
-        dist.all_reduce(learner.grad_all, op=dist.ReduceOp.SUM)
+        g = learner.grad_all
+        if staged and g.is_cuda:
+            h = g.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            g.copy_(h)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
         return 1.0 / world
 
     return grad_sync
