@@ -158,6 +158,66 @@ __global__ __launch_bounds__(256) void k_linear_w(const float* __restrict__ X, i
   }
 }
 
+// Wide-input variant (KIN = 192 / 256 / 384, the dX GEMMs of the fused projections and of the GRU input
+// layer): a wave owns 32 output columns and keeps ALL their weight fragments in VGPRs (KIN/2 registers);
+// activations stream in 64-wide k-chunks (one contiguous 128-B piece per lane and chunk).
+template <int KIN>
+__global__ __launch_bounds__(256) void k_linear_wk(const float* __restrict__ X, int ldx, const float* __restrict__ Wt,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                   int R, int NOUT, int act) {
+  constexpr int NKC = KIN / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, h = lane >> 5;
+  const int c0 = (blockIdx.y * 4 + wave) * 32;
+  if (c0 >= NOUT) return;
+  const int n = c0 + lr;
+  float4 wf[NKC][8];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wf[kc][u] = *reinterpret_cast<const float4*>(Wt + (long)n * KIN + kc * 64 + 32 * h + 4 * u);
+  const float bv = (bias && n < NOUT) ? bias[n] : 0.f;
+  const int ntiles = (R + 31) >> 5;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long row = (long)tile * 32 + lr;
+    const bool ok = row < R;
+    const float* xp = X + (ok ? row : 0) * (long)ldx + 32 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 af[2][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) af[0][u] = ok ? *reinterpret_cast<const float4*>(xp + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (kc + 1 < NKC) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          af[(kc + 1) & 1][u] = ok ? *reinterpret_cast<const float4*>(xp + (kc + 1) * 64 + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][u].x, wf[kc][u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][u].y, wf[kc][u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][u].z, wf[kc][u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][u].w, wf[kc][u].w, acc, 0, 0, 0);
+      }
+    }
+    if (n < NOUT) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const long gr = (long)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (gr < R) {
+          float v = acc[i] + bv;
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_GELU) v = gelu_tanh(v);
+          else if (act == ACT_SWISH) v = swishf_(v);
+          Y[gr * (long)ldy + n] = v;
+        }
+      }
+    }
+  }
+}
+
 // dW slab: grid (G, ceil(NOUT / (64 NB)), KIN / 64).  Software pipeline: the next row tile is fetched
 // from HBM into registers while the MFMAs of the current tile run out of LDS.
 template <int NB>
@@ -319,6 +379,18 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
     dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
     if (KIN == 64) hipLaunchKernelGGL((k_linear_w<64, 2>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
     else hipLaunchKernelGGL((k_linear_w<128, 1>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
+    return check_launch("magpo_linear");
+  }
+  if ((KIN == 192 || KIN == 256 || KIN == 384) && !Ypre) {
+    const int ncg = (NOUT + 31) / 32;
+    const int wpb = ncg < 4 ? ncg : 4;
+    const long ntiles = (R + 31) / 32;
+    long walkers = 2048 / wpb;
+    if (walkers > ntiles) walkers = ntiles;
+    dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
+    if (KIN == 192) hipLaunchKernelGGL((k_linear_wk<192>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
+    else if (KIN == 256) hipLaunchKernelGGL((k_linear_wk<256>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
+    else hipLaunchKernelGGL((k_linear_wk<384>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
     return check_launch("magpo_linear");
   }
   dim3 grid((unsigned)((R + 63) / 64)), block(256);
