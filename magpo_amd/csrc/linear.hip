@@ -368,6 +368,19 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
                             long R, int KIN, int NOUT, int act, hipStream_t stream) {
   if (R <= 0) return MAGPO_OK;
   if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
+  if ((KIN == 128 || KIN == 192 || KIN == 256 || KIN == 384) && !Ypre) {
+    const int ncg = (NOUT + 31) / 32;
+    const int wpb = ncg < 4 ? ncg : 4;
+    const long ntiles = (R + 31) / 32;
+    long walkers = 2048 / wpb;
+    if (walkers > ntiles) walkers = ntiles;
+    dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
+    if (KIN == 128) hipLaunchKernelGGL((k_linear_wk<128>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
+    else if (KIN == 192) hipLaunchKernelGGL((k_linear_wk<192>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
+    else if (KIN == 256) hipLaunchKernelGGL((k_linear_wk<256>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
+    else hipLaunchKernelGGL((k_linear_wk<384>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
+    return check_launch("magpo_linear");
+  }
   if (KIN == 64 || KIN == 128) {
     // wave-autonomous path: 64 columns per wave, up to 4 waves (256 columns) per workgroup
     const int cpw = KIN == 64 ? 64 : 32;  // columns per wave
@@ -379,18 +392,6 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
     dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
     if (KIN == 64) hipLaunchKernelGGL((k_linear_w<64, 2>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
     else hipLaunchKernelGGL((k_linear_w<128, 1>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
-    return check_launch("magpo_linear");
-  }
-  if ((KIN == 192 || KIN == 256 || KIN == 384) && !Ypre) {
-    const int ncg = (NOUT + 31) / 32;
-    const int wpb = ncg < 4 ? ncg : 4;
-    const long ntiles = (R + 31) / 32;
-    long walkers = 2048 / wpb;
-    if (walkers > ntiles) walkers = ntiles;
-    dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
-    if (KIN == 192) hipLaunchKernelGGL((k_linear_wk<192>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
-    else if (KIN == 256) hipLaunchKernelGGL((k_linear_wk<256>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
-    else hipLaunchKernelGGL((k_linear_wk<384>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
     return check_launch("magpo_linear");
   }
   dim3 grid((unsigned)((R + 63) / 64)), block(256);
@@ -426,6 +427,14 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   float* slab = workspace;
   float* bslab = db ? workspace + (long)G * KIN * NOUT : nullptr;
   int nb = NOUT >= 128 ? 2 : 1;
+  // fill the chip in whole waves of workgroups: 3 (NB=2) / 4 (NB=1) resident workgroups per CU x 256 CUs
+  {
+    const int per_g = ((NOUT + 64 * nb - 1) / (64 * nb)) * (KIN / 64);
+    const int resident = 256 * (nb == 2 ? 3 : 4);
+    int g_fit = resident / per_g;
+    if (g_fit < 1) g_fit = 1;
+    if (G > g_fit) G = g_fit;
+  }
   dim3 grid(G, (NOUT + 64 * nb - 1) / (64 * nb), KIN / 64), block(256);
   if (nb == 2) hipLaunchKernelGGL(k_wgrad<2>, grid, block, 0, stream, X, ldx, dY, ldy, (int)R, KIN, NOUT, slab, bslab);
   else hipLaunchKernelGGL(k_wgrad<1>, grid, block, 0, stream, X, ldx, dY, ldy, (int)R, KIN, NOUT, slab, bslab);
