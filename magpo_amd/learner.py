@@ -151,6 +151,9 @@ class MagpoLearner:
         self.gnorm = f32(2)
         self.adv_stats = f32(2)
         self._mb: Dict[str, torch.Tensor] = {}
+        # the actor's forward / backward run on a second HIP stream next to the guider's (independent until the loss)
+        self.overlap_actor = True
+        self._actor_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
     # group-0 shortcuts (single-group callers and the parity tests)
     env = property(lambda self: self.groups[0].env)
@@ -269,15 +272,31 @@ class MagpoLearner:
         g = self.groups[group]
         m = self._gather(g, env_idx, agent_perm)
         mb, R = env_idx.numel(), m["R"]
+        side = self._actor_stream if self.overlap_actor else None
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)  # minibatch gather (and the previous optimiser step) are complete for the actor
+            with torch.cuda.stream(side):
+                a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T)
         g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], g.prev_sable_hs, env_idx, mb, T)
-        a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T)
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T)
         st = self._st()
         self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
         self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, None, m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],
                     self.adv_stats, m["dg"], 64, m["da"], 64, m["dv"], self.ws64, self.loss_out, R, K, s.clip_eps, s.clip_gpo,
                     s.ent_coef, s.vf_coef, s.alpha, st)
+        if side is not None:
+            side.wait_stream(main)  # loss gradients are ready
+            with torch.cuda.stream(side):
+                self.actor.seq_bwd(m["da"])
         self.guider.train_bwd(m["dg"], m["dv"])
-        self.actor.seq_bwd(m["da"])
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            self.actor.seq_bwd(m["da"])
 
     def apply_grads(self, grad_scale: float = 1.0):
         """optax clip_by_global_norm + adam + apply_updates on both flat buffers (rec_magpo.py:412-420)."""
