@@ -111,7 +111,7 @@ int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned ch
 
 /* ---- K2 sampling, K5 GAE, K6 shuffle/layout, K9 losses (decode.py:128-149; multistep.py:24-68; rec_magpo.py:222-370,439-462) ---- */
 int magpo_sample_categorical(const float* logits, long ld, const unsigned char* mask, long mask_stride,
-                             uint32_t k0, uint32_t k1, int* action, long act_stride, float* logp,
+                             uint32_t k0, uint32_t k1, const uint32_t* key_dev, int* action, long act_stride, float* logp,
                              long logp_stride, int* next_idx, long next_stride, float* lp_all, long lp_ld, int N,
                              int K, magpo_stream_t stream);
 int magpo_gae(const float* reward, const float* value, const unsigned char* done, const float* last_val,

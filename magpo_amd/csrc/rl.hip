@@ -33,7 +33,7 @@ __global__ void k_random_bits(const uint32_t* __restrict__ key, uint32_t* __rest
 // The double log keeps the gumbel value correctly rounded so that the oracle and the device agree.
 struct SampleArgs {
   const float* logits; long ld; const unsigned char* mask; long mask_stride;
-  uint32_t k0, k1;
+  uint32_t k0, k1; const uint32_t* key_dev;  // key_dev (device, 2 words) overrides k0/k1: static arguments for graph replay
   int* action; long act_stride; float* logp; long logp_stride; int* next_idx; long next_stride;
   float* lp_all; long lp_ld;  // optional normalised log-probs out
   int N, K;
@@ -41,6 +41,7 @@ struct SampleArgs {
 __global__ void k_sample(SampleArgs a) {
   long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= a.N) return;
+  const uint32_t k0 = a.key_dev ? a.key_dev[0] : a.k0, k1 = a.key_dev ? a.key_dev[1] : a.k1;
   const float* x = a.logits + n * a.ld;
   const unsigned char* m = a.mask ? a.mask + n * a.mask_stride : nullptr;
   float mx = -INFINITY;
@@ -54,7 +55,7 @@ __global__ void k_sample(SampleArgs a) {
   for (int k = 0; k < a.K; ++k) {
     const float lp = ((m && !m[k]) ? FMIN : x[k]) - lse;
     if (a.lp_all) a.lp_all[n * a.lp_ld + k] = lp;
-    const uint32_t bits = random_bits32(a.k0, a.k1, (uint32_t)(n * a.K + k));
+    const uint32_t bits = random_bits32(k0, k1, (uint32_t)(n * a.K + k));
     const float f = __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f;
     const float u = fmaxf(1.17549435e-38f, f + 1.17549435e-38f);
     const float gmb = (float)(-log(-log((double)u)));
@@ -326,11 +327,11 @@ extern "C" int magpo_random_bits_host(const uint32_t* key, int num, uint32_t* ou
 }
 
 extern "C" int magpo_sample_categorical(const float* logits, long ld, const unsigned char* mask, long mask_stride,
-                                        uint32_t k0, uint32_t k1, int* action, long act_stride, float* logp,
+                                        uint32_t k0, uint32_t k1, const uint32_t* key_dev, int* action, long act_stride, float* logp,
                                         long logp_stride, int* next_idx, long next_stride, float* lp_all, long lp_ld, int N,
                                         int K, hipStream_t st) {
   if ((long)N * K >= (1L << 32)) { set_error("sample: N*K must be < 2^32"); return MAGPO_EINVAL; }
-  SampleArgs a{logits, ld, mask, mask_stride, k0, k1, action, act_stride, logp, logp_stride, next_idx, next_stride, lp_all, lp_ld, N, K};
+  SampleArgs a{logits, ld, mask, mask_stride, k0, k1, key_dev, action, act_stride, logp, logp_stride, next_idx, next_stride, lp_all, lp_ld, N, K};
   hipLaunchKernelGGL(k_sample, dim3((N + 127) / 128), dim3(128), 0, st, a);
   return check_launch("magpo_sample_categorical");
 }

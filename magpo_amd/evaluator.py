@@ -48,7 +48,7 @@ def make_rec_eval_act_fn(actor: GruActor, config) -> Callable:
             action.copy_(logits[:, :actor.K].argmax(-1).view(N, A))
         else:
             logp = torch.empty(N * A, device=obs.device)
-            L.call("magpo_sample_categorical", logits, 64, None, 0, int(key[0]), int(key[1]), action, 1, logp, 1, None, 0, None, 0,
+            L.call("magpo_sample_categorical", logits, 64, None, 0, int(key[0]), int(key[1]), None, action, 1, logp, 1, None, 0, None, 0,
                    N * A, actor.K, torch.cuda.current_stream().cuda_stream)
         return action, {"hidden_state": h_out, "_spare": h_in}
 

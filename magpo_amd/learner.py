@@ -116,6 +116,10 @@ class EnvGroup:
         self.last_val = f32(N, A)
         self.key = prng_key(0)
         self.cur = 0
+        self.skeys_host = np.zeros((T, A, 2), np.uint32)
+        self.skeys_dev = torch.zeros(T, A, 2, dtype=torch.int32, device=device)
+        self.graph = None
+        self.graph_failed = False
 
 
 class MagpoLearner:
@@ -195,34 +199,76 @@ class MagpoLearner:
             g.cur = 0
 
     # ------------------------------------------------------------------ rollout (rec_magpo.py:126-212)
+    use_graph = True  # replay the whole rollout as one HIP graph (removes ~11K host launches per rollout)
+
     def rollout(self):
         for g in self.groups:
-            self._rollout_group(g)
+            self._rollout_keys(g)
+            if not self.use_graph or g.graph_failed:
+                self._rollout_body(g, g.skeys_host)            # eager: keys by value
+            elif g.graph is not None:
+                self._upload_keys(g)
+                g.graph.replay()
+            elif not getattr(g, "warmed", False):
+                self._rollout_body(g, g.skeys_host)            # first call allocates every workspace eagerly
+                g.warmed = True
+            else:
+                self._upload_keys(g)
+                self._capture(g)
 
-    def _rollout_group(self, g: EnvGroup):
+    def _upload_keys(self, g: EnvGroup):
+        # pageable source: the runtime stages the 8 KB immediately, so the host table can be reused right away
+        g.skeys_dev.copy_(torch.from_numpy(g.skeys_host.view(np.int32).copy()))
+
+    def _capture(self, g: EnvGroup):
+        cur0 = g.cur
+        try:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._rollout_body(g, g.skeys_dev)
+            g.graph = graph
+            graph.replay()
+        except Exception as e:  # capture is an optimisation: never let it change results
+            import warnings
+            warnings.warn(f"HIP graph capture of the rollout failed ({e!r}); running eagerly")
+            g.graph, g.graph_failed, g.cur = None, True, cur0
+            torch.cuda.synchronize()
+            self._rollout_body(g, g.skeys_host)
+
+    def _rollout_keys(self, g: EnvGroup):
+        """Host key chain of one rollout (pure function of the carried key): key, policy_key = split(key) per env
+        step (rec_magpo.py:135); inside get_actions key, sample_key = split(key) per agent (decode.py:141); one
+        more split for the bootstrap value (:202).  The A sample keys per step go to a device table."""
+        T, A = self.T, self.A
+        tab = g.skeys_host
+        key = g.key
+        for t in range(T):
+            ks = host_split(key, 2)
+            key, k = ks[0], ks[1]
+            for i in range(A):
+                kk = host_split(k, 2)
+                k, tab[t, i] = kk[0], kk[1]
+        g.key = host_split(key, 2)[0]
+
+    def _rollout_body(self, g: EnvGroup, skeys):
         L, st, T, N, A = self.L, self._st(), self.T, self.N, self.A
         tr = g.traj
         for d, s in zip(g.prev_sable_hs, g.sable_hs):
             d.copy_(s)
         g.policy_h0.copy_(g.policy_h[g.cur])
-        # host key chain: key, policy_key = split(key); inside get_actions key, sample_key = split(key) per agent
         for t in range(T):
-            ks = host_split(g.key, 2)
-            g.key, k = ks[0], ks[1]
-            skeys = np.empty((A, 2), np.uint32)
-            for i in range(A):
-                kk = host_split(k, 2)
-                k, skeys[i] = kk[0], kk[1]
             obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
-            self.guider.act(obs, pos, g.sable_hs, skeys, tr["action"][t], tr["log_prob"][t], tr["value"][t])
+            self.guider.act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t])
             h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
             self.actor.step(obs, h_in, done_prev, h_out)
             g.cur = 1 - g.cur
             g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
                        g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t])
             L.call("magpo_zero_states_where_done", *g.sable_hs, tr["done"][t + 1], N, st)
-        ks = host_split(g.key, 2)
-        g.key = ks[0]  # last_val_key = ks[1]: the sampled actions are discarded (rec_magpo.py:202-208)
+        if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
+            g.policy_h[0].copy_(g.policy_h[1])
+            g.cur = 0
         self.guider.act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
         L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], g.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
                self.sys.gamma, self.sys.gae_lambda, st)

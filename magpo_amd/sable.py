@@ -181,9 +181,12 @@ class SableGuider:
             self.lin(out, E, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, N, E, E)
             L.call("magpo_headmid_fwd", hp, E, v["dec.head.norm.scale"], hn, E, None, None, None, 0, N, st)
             self.lin(hn, E, self.wt["h1"], v["dec.head.dense1.bias"], logits, E, N, E, K)
-            k0, k1 = int(sample_keys[i][0]), int(sample_keys[i][1])
+            if torch.is_tensor(sample_keys):   # device key table [A, 2] (static arguments: HIP-graph replay)
+                k0, k1, kdev = 0, 0, sample_keys[i]
+            else:
+                k0, k1, kdev = int(sample_keys[i][0]), int(sample_keys[i][1]), None
             L.call("magpo_sample_categorical", logits, E, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
-                   k0, k1, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
+                   k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
 
     # ------------------------------------------------------------------ training forward (chunkwise form)
     def train_fwd(self, obs, prev_idx, pos, dones, s0, seq_env, nseq: int, T: int):

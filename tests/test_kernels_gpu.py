@@ -333,7 +333,7 @@ def test_sample_categorical(L, stream):
     key = oprng.split(oprng.prng_key(7), 3)[2]
     act = torch.zeros(N, A, dtype=torch.int32, device=DEV); lp = torch.zeros(N, A, device=DEV)
     nxt = torch.zeros(N, A, dtype=torch.int32, device=DEV); lpall = torch.zeros(N, 32, device=DEV)
-    L.call("magpo_sample_categorical", dev(logits), 32, None, 0, int(key[0]), int(key[1]), act[:, 1:], A, lp[:, 1:], A,
+    L.call("magpo_sample_categorical", dev(logits), 32, None, 0, int(key[0]), int(key[1]), None, act[:, 1:], A, lp[:, 1:], A,
            nxt[:, 2:], A, lpall, 32, N, K, stream)
     lpd = lpall[:, :K].cpu()
     ref_lp = torch.log_softmax(logits[:, :K].double(), -1)

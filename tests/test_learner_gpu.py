@@ -99,3 +99,24 @@ def test_rollout_and_update_parity(A, K, TL, maxval, N, T):
     dl._carry_over()
     dl.update_step()
     assert torch.isfinite(dl.guider.P.flat).all() and torch.isfinite(dl.actor.P.flat).all()
+
+
+def test_graph_replay_equals_eager_rollout():
+    """The HIP-graph replay of the rollout must reproduce the eager rollout bit for bit (same kernels, same order)."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    sysc = SystemConfig(rollout_length=9, ppo_epochs=1, num_minibatches=1)   # odd T: exercises the buffer-role fix-up
+    key = host_split(prng_key(5), 4)[0]
+    ls = []
+    for use_graph in (False, True):
+        l = MagpoLearner(CoordSumConfig(3, 10, 7, 30), 8, sysc, "cuda", net_seed=4, wgrad_groups=4)
+        l.use_graph = use_graph
+        l.setup(key)
+        ls.append(l)
+    for it in range(4):
+        for l in ls:
+            l.update_step()
+        assert ls[1].groups[0].graph is not None or it < 1, "rollout should be captured from the second call on"
+        for k in ("action", "value", "log_prob", "reward", "adv"):
+            assert torch.equal(ls[0].traj[k], ls[1].traj[k]), (it, k)
+        assert torch.equal(ls[0].guider.P.flat, ls[1].guider.P.flat) and np.array_equal(ls[0].key, ls[1].key)
+    assert not ls[1].groups[0].graph_failed
