@@ -63,8 +63,10 @@ int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const float* s_o
                     long R, magpo_stream_t stream);
 int magpo_embed_bwd(int mode, const float* z, int ldz, const float* d0, int ldd0, const float* d1, int ldd1,
                     const float* d2, int ldd2, const float* s_ln, float* dz, int lddz, float* slab_sln,
-                    const float* obs, int ldo, int F, const float* s_obs, const float* W, float* slab_sobs,
-                    long R, magpo_stream_t stream);
+                    float* slab_w, int nrows, const float* obs, int ldo, int F, const float* s_obs, const float* W,
+                    float* slab_sobs, const int* idx, int idx_stride, long R, magpo_stream_t stream);
+int magpo_small_relu_wgrad(const float* X, int ldx, int F, const float* Yact, const float* dY, float* slab_w, long R,
+                           magpo_stream_t stream);
 int magpo_small_operand(int mode, const float* obs, int ldo, int F, const float* s_obs, const int* idx,
                         int idx_stride, float* out, long R, magpo_stream_t stream);
 int magpo_retpost_fwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,

@@ -23,8 +23,8 @@ class GruActor:
                  seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
         if hidden != 128:
             raise NotImplementedError("gfx950 GRU kernels: hidden_state_dim = 128 only")
-        if obs_dim > 64 or action_dim > 32:
-            raise NotImplementedError("obs_dim <= 64 and action_dim <= 32 required")
+        if obs_dim > 32 or action_dim > 32:
+            raise NotImplementedError("obs_dim <= 32 and action_dim <= 32 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
         self.dev = device
         self.L = lib()
@@ -129,7 +129,8 @@ class GruActor:
         self.wgrad(t("hprev"), H, dhh, 3 * H, R, H, 3 * H, gv["gru.wh"])
         demb = dy
         self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H)
-        L.call("magpo_relu_bwd", t("emb"), demb, demb, R * H, st)
-        op = b.get("g_op", (R, 64))
-        L.call("magpo_small_operand", 2, obs, F, F, None, None, 0, op, R, st)
-        self.wgrad(op, 64, demb, H, R, 64, H, gv["pre.kernel"], gv["pre.bias"], krows=F)
+        grid = L.call("magpo_row_grid", R)
+        sw = b.get("g_slabw", (grid, 33 * H))
+        L.call("magpo_small_relu_wgrad", obs, F, F, t("emb"), demb, sw, R, st)
+        L.call("magpo_reduce_slabs", sw, gv["pre.kernel"], grid, F * H, 33 * H, 1.0, 0, st)
+        L.call("magpo_reduce_slabs", sw[:, 32 * H:], gv["pre.bias"], grid, H, 33 * H, 1.0, 0, st)

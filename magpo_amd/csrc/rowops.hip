@@ -114,28 +114,38 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
   }
 }
 
-// Backward of the embedding rows: d(xn) = d0 + d1 (+ d2) -> dz; slabs: ds_ln[64] (+ ds_obs[F] for mode 0)
+// Backward of the embedding rows: d(xn) = d0 + d1 (+ d2) -> dz; slabs: ds_ln[64], the small weight gradient
+// dW[rows <= 32][64] (mode 0: rows = obs features, dW_obs = o^T dz; mode 1: rows = action slots, dW_act[idx] += dz)
+// and, for mode 0, ds_obs[F].  The weight gradient is accumulated per lane (compile-time indexed registers).
 struct EmbedBwdArgs {
   const float* z; int ldz;
   const float* d0; const float* d1; const float* d2; int ldd0, ldd1, ldd2;
   const float* s_ln;
   float* dz; int lddz;
   float* slab_sln;   // [grid][64]
+  float* slab_w;     // [grid][32][64]
+  int nrows;         // rows of the small weight (F or K+1), <= 32
   // mode 0 extras
   const float* obs; int ldo; int F; const float* s_obs; const float* W; float* slab_sobs;  // [grid][32]
+  // mode 1 extras
+  const int* idx; int idx_stride;
   long R;
 };
 
-__global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a, int mode) {
+template <int MODE, int NR>  // NR = compile-time bound on the rows of the small weight (register accumulators)
+__global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
   __shared__ float lds[4 * 64];
   __shared__ float sobs_acc[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
   const float4 sln = ld4(a.s_ln + c4);
   float4 dsln = f4zero();
-  float dsobs[32];
-  if (mode == 0) {
+  float4 wacc[NR];
 #pragma unroll
-    for (int f = 0; f < 32; ++f) dsobs[f] = 0.f;
+  for (int f = 0; f < NR; ++f) wacc[f] = f4zero();
+  float dsobs[MODE == 0 ? NR : 1];
+  if (MODE == 0) {
+#pragma unroll
+    for (int f = 0; f < NR; ++f) dsobs[f] = 0.f;
   }
   for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < a.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
     const long row = base + wave * 4 + (lane >> 4);
@@ -152,28 +162,43 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a, int mode) {
     float4 dx0 = rms_bwd(d, n, sln, dsln);
     float4 dz = make_float4(dx0.x * gelu_tanh_grad(z.x), dx0.y * gelu_tanh_grad(z.y), dx0.z * gelu_tanh_grad(z.z),
                             dx0.w * gelu_tanh_grad(z.w));
+    if (!ok) dz = f4zero();
     if (ok) st4(a.dz + row * a.lddz + c4, dz);
-    if (mode == 0) {
-      // d(s_obs)[f] += (dz . W[f,:]) * obs[f] * rstd   (the obs themselves need no gradient)
+    if (MODE == 0) {
+      // dW_obs[f] += o[f] * dz ; d(s_obs)[f] += (dz . W[f,:]) * obs[f] * rstd   (the obs need no gradient)
       const float* o = a.obs + (ok ? row : 0) * a.ldo;
       float ms = 0.f;
       for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
       const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
 #pragma unroll
-      for (int f = 0; f < 32; ++f) {
+      for (int f = 0; f < NR; ++f) {
         if (f < a.F) {
+          const float of = o[f] * rstd;
+          const float on = of * a.s_obs[f];
+          wacc[f].x += on * dz.x; wacc[f].y += on * dz.y; wacc[f].z += on * dz.z; wacc[f].w += on * dz.w;
           const float4 w = ld4(a.W + f * 64 + c4);
           float dof = sum16(f4sum(f4mul(dz, w)));
-          if (ok && (lane & 15) == 0) dsobs[f] += dof * o[f] * rstd;
+          if ((lane & 15) == 0) dsobs[f] += dof * of;
         }
+      }
+    } else {
+      const int id = ok ? a.idx[row * a.idx_stride] : -1;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        if (k < a.nrows && id == k) { wacc[k].x += dz.x; wacc[k].y += dz.y; wacc[k].z += dz.z; wacc[k].w += dz.w; }
       }
     }
   }
   block_store_colsum(dsln, a.slab_sln + (long)blockIdx.x * 64, lds);
-  if (mode == 0) {
+#pragma unroll
+  for (int f = 0; f < NR; ++f)
+    if (f < a.nrows) block_store_colsum(wacc[f], a.slab_w + ((long)blockIdx.x * 32 + f) * 64, lds);
+  if (MODE == 0) {
+    if (threadIdx.x < 32) sobs_acc[0][threadIdx.x] = sobs_acc[1][threadIdx.x] = sobs_acc[2][threadIdx.x] = sobs_acc[3][threadIdx.x] = 0.f;
+    __syncthreads();
     // lanes 0,16,32,48 of each wave hold partial sums
 #pragma unroll
-    for (int f = 0; f < 32; ++f) {
+    for (int f = 0; f < NR; ++f) {
       float v = dsobs[f];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
@@ -183,6 +208,45 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a, int mode) {
     if (threadIdx.x < 32)
       a.slab_sobs[(long)blockIdx.x * 32 + threadIdx.x] =
           (sobs_acc[0][threadIdx.x] + sobs_acc[1][threadIdx.x]) + (sobs_acc[2][threadIdx.x] + sobs_acc[3][threadIdx.x]);
+  }
+}
+
+// Backward of a small-input ReLU layer Y = relu(X[R,F] @ W + b), F <= 32, N = 128 (actor pre-torso, torsos.py:36-47):
+// dW[F][128] = X^T (dY * [Y > 0]), db = colsum(dY * [Y > 0]); 32 lanes x float4 per row.
+template <int NF>
+__global__ __launch_bounds__(256) void k_small_relu_wgrad(const float* __restrict__ X, int ldx, int F, const float* __restrict__ Yact,
+                                                          const float* __restrict__ dY, float* __restrict__ slab_w /*[grid][33][128]*/, long R) {
+  __shared__ float lds[4 * 128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 31);
+  float4 wacc[NF + 1];  // [NF] = bias
+#pragma unroll
+  for (int f = 0; f <= NF; ++f) wacc[f] = f4zero();
+  for (long base = (long)blockIdx.x * 8; base < R; base += (long)gridDim.x * 8) {
+    const long row = base + wave * 2 + (lane >> 5);
+    if (row < R) {
+      const float4 y = ld4(Yact + row * 128 + c4), d = ld4(dY + row * 128 + c4);
+      const float4 g = make_float4(y.x > 0.f ? d.x : 0.f, y.y > 0.f ? d.y : 0.f, y.z > 0.f ? d.z : 0.f, y.w > 0.f ? d.w : 0.f);
+      const float* x = X + row * ldx;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f < F) { const float xv = x[f]; wacc[f].x += xv * g.x; wacc[f].y += xv * g.y; wacc[f].z += xv * g.z; wacc[f].w += xv * g.w; }
+      }
+      wacc[NF] = f4add(wacc[NF], g);
+    }
+  }
+#pragma unroll
+  for (int ff = 0; ff <= NF; ++ff) {
+    const int f = ff == NF ? 32 : ff;   // slab row 32 holds the bias gradient
+    if (ff < F || ff == NF) {
+      float4 v = wacc[ff];
+      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+      __syncthreads();
+      if (lane < 32) st4(&lds[wave * 128 + c4], v);
+      __syncthreads();
+      if (threadIdx.x < 128)
+        slab_w[((long)blockIdx.x * 33 + f) * 128 + threadIdx.x] =
+            (lds[threadIdx.x] + lds[128 + threadIdx.x]) + (lds[256 + threadIdx.x] + lds[384 + threadIdx.x]);
+    }
   }
 }
 
@@ -441,15 +505,29 @@ extern "C" int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const
   return check_launch("magpo_embed_fwd");
 }
 
-// slab_sln: [grid][64], slab_sobs: [grid][32]; grid = magpo_row_grid(R)
+// slab_sln: [grid][64], slab_w: [grid][32][64], slab_sobs: [grid][32]; grid = magpo_row_grid(R).
+// nrows = F (mode 0) or K+1 (mode 1), <= 32: rows of the small weight whose gradient slab is produced.
 extern "C" int magpo_embed_bwd(int mode, const float* z, int ldz, const float* d0, int ldd0, const float* d1, int ldd1,
                                const float* d2, int ldd2, const float* s_ln, float* dz, int lddz, float* slab_sln,
-                               const float* obs, int ldo, int F, const float* s_obs, const float* W, float* slab_sobs,
-                               long R, hipStream_t st) {
-  if (mode == 0 && F > 32) { set_error("magpo_embed_bwd: F > 32 not supported"); return MAGPO_EINVAL; }
-  EmbedBwdArgs a{z, ldz, d0, d1, d2, ldd0, ldd1, ldd2, s_ln, dz, lddz, slab_sln, obs, ldo, F, s_obs, W, slab_sobs, R};
-  hipLaunchKernelGGL(k_embed_bwd, dim3(row_grid(R)), dim3(256), 0, st, a, mode);
+                               float* slab_w, int nrows, const float* obs, int ldo, int F, const float* s_obs, const float* W,
+                               float* slab_sobs, const int* idx, int idx_stride, long R, hipStream_t st) {
+  if (nrows < 1 || nrows > 32 || (mode == 0 && F != nrows)) { set_error("magpo_embed_bwd: 1 <= nrows <= 32 (F or K+1)"); return MAGPO_EINVAL; }
+  EmbedBwdArgs a{z, ldz, d0, d1, d2, ldd0, ldd1, ldd2, s_ln, dz, lddz, slab_sln, slab_w, nrows, obs, ldo, F, s_obs, W, slab_sobs, idx, idx_stride, R};
+#define EB(M_, N_) hipLaunchKernelGGL((k_embed_bwd<M_, N_>), dim3(row_grid(R)), dim3(256), 0, st, a)
+  if (mode == 0) { if (nrows <= 8) EB(0, 8); else if (nrows <= 16) EB(0, 16); else EB(0, 32); }
+  else { if (nrows <= 8) EB(1, 8); else if (nrows <= 16) EB(1, 16); else if (nrows <= 24) EB(1, 24); else EB(1, 32); }
+#undef EB
   return check_launch("magpo_embed_bwd");
+}
+
+// slab_w: [grid][33][128] (rows 0..F-1 = dW, row 32 = db); grid = magpo_row_grid(R)
+extern "C" int magpo_small_relu_wgrad(const float* X, int ldx, int F, const float* Yact, const float* dY, float* slab_w, long R,
+                                      hipStream_t st) {
+  if (F < 1 || F > 32) { set_error("magpo_small_relu_wgrad: 1 <= F <= 32"); return MAGPO_EINVAL; }
+  if (F <= 8) hipLaunchKernelGGL(k_small_relu_wgrad<8>, dim3(row_grid(R)), dim3(256), 0, st, X, ldx, F, Yact, dY, slab_w, R);
+  else if (F <= 16) hipLaunchKernelGGL(k_small_relu_wgrad<16>, dim3(row_grid(R)), dim3(256), 0, st, X, ldx, F, Yact, dY, slab_w, R);
+  else hipLaunchKernelGGL(k_small_relu_wgrad<32>, dim3(row_grid(R)), dim3(256), 0, st, X, ldx, F, Yact, dY, slab_w, R);
+  return check_launch("magpo_small_relu_wgrad");
 }
 
 extern "C" int magpo_small_operand(int mode, const float* obs, int ldo, int F, const float* s_obs, const int* idx,

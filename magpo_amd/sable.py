@@ -47,8 +47,8 @@ class SableGuider:
                  wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
         if embed_dim != 64 or n_head != 1 or n_block != 1:
             raise NotImplementedError("gfx950 Sable kernels: embed_dim=64, n_head=1, n_block=1 only (SURVEY 8f rank 3)")
-        if obs_dim > 32 or action_dim > 32:
-            raise NotImplementedError("obs_dim and action_dim must be <= 32")
+        if obs_dim > 32 or action_dim > 31:
+            raise NotImplementedError("obs_dim <= 32 and action_dim <= 31 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
         self.dev = device
         self.L = lib()
@@ -298,12 +298,10 @@ class SableGuider:
         dkin1 = g("dkin")
         self.lin(dqkvg1, 4 * E, v["dec.block0.retn1.w_qkvg"], None, dkin1, E, R, 4 * E, E)
         dza = g("dz")
-        L.call("magpo_embed_bwd", 1, t("za"), E, dsum1, E, dkin1, E, None, 0, v["dec.ln.scale"], dza, E, slab("a"), None, 0, 0, None,
-               None, None, R, st)
+        L.call("magpo_embed_bwd", 1, t("za"), E, dsum1, E, dkin1, E, None, 0, v["dec.ln.scale"], dza, E, slab("a"), slab("w", 32 * E),
+               K + 1, None, 0, 0, None, None, None, prev_idx, 1, R, st)
         self.reduce(slab("a"), gv["dec.ln.scale"])
-        op = g("op")
-        L.call("magpo_small_operand", 1, None, 0, 0, None, prev_idx, 1, op, R, st)
-        self.wgrad(op, E, dza, E, R, E, E, gv["dec.act.kernel"], None, krows=K + 1)
+        self.reduce(slab("w", 32 * E), gv["dec.act.kernel"], P=(K + 1) * E, stride=32 * E)
         # ---- value head
         dhv = g("dhp")
         L.call("magpo_headmid_bwd", t("hv"), E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], dvalue, 1, dhv, E,
@@ -332,9 +330,8 @@ class SableGuider:
         dkin = g("dkin")
         self.lin(dqkvg, 4 * E, v["enc.block0.retn.w_qkvg"], None, dkin, E, R, 4 * E, E)
         dz = g("dz")
-        L.call("magpo_embed_bwd", 0, t("z"), E, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], dz, E, slab("a"), obs, F, F,
-               v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), R, st)
+        L.call("magpo_embed_bwd", 0, t("z"), E, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], dz, E, slab("a"), slab("w", 32 * E), F,
+               obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, st)
         self.reduce(slab("a"), gv["enc.ln.scale"])
         self.reduce(slab("d", 32), gv["enc.obs.norm.scale"], P=F, stride=32)
-        L.call("magpo_small_operand", 0, obs, F, F, v["enc.obs.norm.scale"], None, 0, op, R, st)
-        self.wgrad(op, E, dz, E, R, E, E, gv["enc.obs.dense.kernel"], None, krows=F)
+        self.reduce(slab("w", 32 * E), gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)

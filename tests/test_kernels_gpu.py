@@ -121,17 +121,13 @@ def test_embed_fwd_bwd(L, stream, mode):
     grid = L.call("magpo_row_grid", R)
     dz = torch.empty(R, 64, device=DEV)
     slab_sln = torch.zeros(grid, 64, device=DEV); slab_sobs = torch.zeros(grid, 32, device=DEV)
-    L.call("magpo_embed_bwd", mode, z, 64, dev(d0), 64, dev(d1), 64, None, 0, dev(s_ln), dz, 64, slab_sln,
-           dev(obs), F, F, dev(s_obs), dev(W), slab_sobs, R, stream)
-    close(_slabsum(slab_sln), sl.grad, 1e-4, 1e-5, "ds_ln")
-    # dW through the small-operand + wgrad path
-    op = torch.empty(R, 64, device=DEV)
-    L.call("magpo_small_operand", mode, dev(obs), F, F, dev(s_obs), dev(idx), 1, op, R, stream)
+    slab_w = torch.zeros(grid, 32 * 64, device=DEV)
     rows = F if mode == 0 else K + 1
-    G = 5
-    ws = torch.empty(L.call("magpo_wgrad_workspace_floats", 64, 64, G), device=DEV)
+    L.call("magpo_embed_bwd", mode, z, 64, dev(d0), 64, dev(d1), 64, None, 0, dev(s_ln), dz, 64, slab_sln, slab_w, rows,
+           dev(obs), F, F, dev(s_obs), dev(W), slab_sobs, dev(idx), 1, R, stream)
+    close(_slabsum(slab_sln), sl.grad, 1e-4, 1e-5, "ds_ln")
     dW = torch.zeros(rows, 64, device=DEV)
-    L.call("magpo_wgrad", op, 64, dz, 64, R, 64, rows, 64, dW, None, ws, G, 1.0, 0, stream)
+    L.call("magpo_reduce_slabs", slab_w, dW, grid, rows * 64, 32 * 64, 1.0, 0, stream)
     close(dW, Wd.grad, 1e-4, 1e-5, "dW")
     if mode == 0:
         close(_slabsum(slab_sobs)[:F], so.grad, 1e-4, 1e-5, "ds_obs")
