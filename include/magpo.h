@@ -45,6 +45,11 @@ int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key
 /* ---- dense layers on fp32 MFMA (flax nn.Dense / retention projections) ---- */
 int magpo_linear(const float* X, int ldx, const float* Wt, const float* bias, float* Y, int ldy, float* Ypre,
                  long R, int KIN, int NOUT, int act, magpo_stream_t stream);
+int magpo_linear_pro(int pro, const float* a, long lda, const float* y, long ldy_in, const float* s1, const float* s2,
+                     const float* pe, const int* pos, long pos_stride, int npos, int use_pe, const float* W,
+                     const int* idx, long idx_stride, const float* s_obs, int F, float* out, long ldout,
+                     float* outpe, long ldoutpe, const float* Wt, const float* bias, float* Y, long ldy, long R,
+                     int NOUT, magpo_stream_t stream);
 long magpo_wgrad_workspace_floats(int KIN, int NOUT, int G);
 int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, long R, int KIN, int krows, int NOUT, float* dW,
                 float* db, float* workspace, int G, float scale, int accumulate, magpo_stream_t stream);
@@ -99,7 +104,8 @@ int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk
                               int masked, float kappa, magpo_stream_t stream);
 int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
-                              int write_state, magpo_stream_t stream);
+                              int write_state, const float* gp, long ldg, const float* gamma, const float* beta,
+                              magpo_stream_t stream);
 int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned char* done, int nenv,
                                  magpo_stream_t stream);
 

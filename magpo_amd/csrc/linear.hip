@@ -158,6 +158,165 @@ __global__ __launch_bounds__(256) void k_linear_w(const float* __restrict__ X, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Prologue-fused skinny GEMM for acting (64 -> NOUT): the row-wise op that precedes a dense layer in the
+// Sable blocks is evaluated on the activation fragment itself.  In this kernel a lane holds one half
+// (32 consecutive features) of one row, so a row statistic is a 32-term local sum plus one shuffle
+// with the partner lane (lane ^ 32).  Side outputs (normalised rows needed later) are stored from here.
+//   PRO_EMBED_ACT : z = W_act[idx] -> gelu -> rmsnorm*s1 (=xa, stored) -> +pe          (sable_network.py:306-307)
+//   PRO_EMBED_OBS : z = (rmsnorm_F(obs)*s_obs) @ W_obs -> gelu -> rmsnorm*s1 (=xn, stored) -> +pe   (:93-101,132)
+//   PRO_RESNORM   : x = rmsnorm(a + y)*s1 [-> rmsnorm*s2] (stored) [-> +pe (stored)]     (:69-70, 203, 214-215)
+//   PRO_HEADMID   : h = rmsnorm(gelu(hpre))*s1                                            (:102-109, 277-284)
+enum { PRO_EMBED_ACT = 1, PRO_EMBED_OBS = 2, PRO_RESNORM = 3, PRO_HEADMID = 4 };
+struct ProArgs {
+  const float* a; long lda;          // primary input rows (RESNORM: a, HEADMID: hpre, EMBED_OBS: obs [ld = lda, F features])
+  const float* y; long ldy_;         // RESNORM: second addend
+  const float* s1; const float* s2;  // norm scales (s2 optional)
+  const float* pe; const int* pos; long pos_stride; int npos; int use_pe;   // A operand gets + pe[pos[row]] when use_pe
+  const float* W; const int* idx; long idx_stride;   // EMBED_ACT: W_act [K+1][64]; EMBED_OBS: W_obs [F][64]
+  const float* s_obs; int F;
+  float* out; long ldout;            // normalised row (before pe), nullable
+  float* outpe; long ldoutpe;        // row + pe, nullable
+};
+
+__device__ __forceinline__ float half_row_mean_sq(const float4* v) {
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+  s += __shfl_xor(s, 32, 64);
+  return s * (1.0f / 64.0f);
+}
+__device__ __forceinline__ void rms_inplace(float4* v, const float* __restrict__ scale, int h) {
+  const float rstd = rsqrtf(half_row_mean_sq(v) + 1e-6f);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float4 sc = *reinterpret_cast<const float4*>(scale + 32 * h + 4 * u);
+    v[u].x *= rstd * sc.x; v[u].y *= rstd * sc.y; v[u].z *= rstd * sc.z; v[u].w *= rstd * sc.w;
+  }
+}
+__device__ __forceinline__ void gelu_inplace(float4* v) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { v[u].x = gelu_tanh(v[u].x); v[u].y = gelu_tanh(v[u].y); v[u].z = gelu_tanh(v[u].z); v[u].w = gelu_tanh(v[u].w); }
+}
+
+template <int PRO, int NCB>
+__global__ __launch_bounds__(256) void k_linear_pro(ProArgs p, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                    float* __restrict__ Y, long ldy, int R, int NOUT) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, h = lane >> 5;
+  const int c0 = (blockIdx.y * 4 + wave) * 32 * NCB;
+  if (c0 >= NOUT) return;
+  const bool writer = c0 == 0;  // exactly one wave per row tile stores the side outputs
+  float4 wf[NCB][8];
+  float bv[NCB];
+#pragma unroll
+  for (int b = 0; b < NCB; ++b) {
+    const int n = c0 + 32 * b + lr;
+    const bool on = c0 + 32 * b < NOUT;
+    bv[b] = (bias && n < NOUT) ? bias[n] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      wf[b][u] = on ? *reinterpret_cast<const float4*>(Wt + (long)n * 64 + 32 * h + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int ntiles = (R + 31) >> 5;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long row = (long)tile * 32 + lr;
+    const bool ok = row < R;
+    const long rr = ok ? row : 0;
+    float4 af[8];
+    if (PRO == PRO_EMBED_ACT) {
+      const float* wp = p.W + (long)p.idx[rr * p.idx_stride] * 64 + 32 * h;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) af[u] = *reinterpret_cast<const float4*>(wp + 4 * u);
+      gelu_inplace(af);
+      rms_inplace(af, p.s1, h);
+    } else if (PRO == PRO_EMBED_OBS) {
+      const float* o = p.a + rr * p.lda;
+      float ms = 0.f;
+      for (int f = 0; f < p.F; ++f) ms += o[f] * o[f];
+      const float rstd = rsqrtf(ms / (float)p.F + 1e-6f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) af[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int f = 0; f < p.F; ++f) {
+        const float of = o[f] * rstd * p.s_obs[f];
+        const float* wp = p.W + (long)f * 64 + 32 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float4 w = *reinterpret_cast<const float4*>(wp + 4 * u);
+          af[u].x += of * w.x; af[u].y += of * w.y; af[u].z += of * w.z; af[u].w += of * w.w;
+        }
+      }
+      gelu_inplace(af);
+      rms_inplace(af, p.s1, h);
+    } else if (PRO == PRO_RESNORM) {
+      const float* ap = p.a + rr * p.lda + 32 * h;
+      const float* yp = p.y + rr * p.ldy_ + 32 * h;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 x = *reinterpret_cast<const float4*>(ap + 4 * u), y = *reinterpret_cast<const float4*>(yp + 4 * u);
+        af[u] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      }
+      rms_inplace(af, p.s1, h);
+      if (p.s2) rms_inplace(af, p.s2, h);
+    } else {  // PRO_HEADMID
+      const float* ap = p.a + rr * p.lda + 32 * h;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) af[u] = *reinterpret_cast<const float4*>(ap + 4 * u);
+      gelu_inplace(af);
+      rms_inplace(af, p.s1, h);
+    }
+    if (writer && ok && p.out) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(p.out + row * p.ldout + 32 * h + 4 * u) = af[u];
+    }
+    if (p.use_pe || p.outpe) {
+      int ps = p.pos[rr * p.pos_stride];
+      ps = ps < 0 ? 0 : (ps >= p.npos ? p.npos - 1 : ps);
+      const float* pp = p.pe + (long)ps * 64 + 32 * h;
+      float4 ape[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 e = *reinterpret_cast<const float4*>(pp + 4 * u);
+        ape[u] = make_float4(af[u].x + e.x, af[u].y + e.y, af[u].z + e.z, af[u].w + e.w);
+      }
+      if (writer && ok && p.outpe) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(p.outpe + row * p.ldoutpe + 32 * h + 4 * u) = ape[u];
+      }
+      if (p.use_pe) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) af[u] = ape[u];
+      }
+    }
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int b = 0; b < NCB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].x, wf[b][u].x, acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].y, wf[b][u].y, acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].z, wf[b][u].z, acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].w, wf[b][u].w, acc[b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < NCB; ++b) {
+      const int n = c0 + 32 * b + lr;
+      if (n < NOUT) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long gr = (long)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (gr < R) Y[gr * ldy + n] = acc[b][i] + bv[b];
+        }
+      }
+    }
+  }
+}
+
 // Wide-input variant (KIN = 192 / 256 / 384, the dX GEMMs of the fused projections and of the GRU input
 // layer): a wave owns 32 output columns and keeps ALL their weight fragments in VGPRs (KIN/2 registers);
 // activations stream in 64-wide k-chunks (one contiguous 128-B piece per lane and chunk).
@@ -415,6 +574,32 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
   }
 #undef LAUNCH
   return check_launch("magpo_linear");
+}
+
+// Prologue-fused 64 -> NOUT dense layer (see k_linear_pro).  pro: 1 embed-action, 2 embed-observation, 3 residual+norm, 4 gelu+norm.
+extern "C" int magpo_linear_pro(int pro, const float* a, long lda, const float* y, long ldy_in, const float* s1, const float* s2,
+                                const float* pe, const int* pos, long pos_stride, int npos, int use_pe, const float* W,
+                                const int* idx, long idx_stride, const float* s_obs, int F, float* out, long ldout,
+                                float* outpe, long ldoutpe, const float* Wt, const float* bias, float* Y, long ldy, long R,
+                                int NOUT, hipStream_t stream) {
+  if (R <= 0) return MAGPO_OK;
+  if (pro < 1 || pro > 4 || NOUT <= 0) { set_error("magpo_linear_pro: bad prologue id / NOUT"); return MAGPO_EINVAL; }
+  ProArgs p{a, lda, y, ldy_in, s1, s2, pe, pos, pos_stride, npos, use_pe, W, idx, idx_stride, s_obs, F, out, ldout, outpe, ldoutpe};
+  const int ncg = (NOUT + 63) / 64;
+  const int wpb = ncg < 4 ? ncg : 4;
+  const long ntiles = (R + 31) / 32;
+  long walkers = 2048 / wpb;
+  if (walkers > ntiles) walkers = ntiles;
+  dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
+#define LP(P_) hipLaunchKernelGGL((k_linear_pro<P_, 2>), grid, block, 0, stream, p, Wt, bias, Y, ldy, (int)R, NOUT)
+  switch (pro) {
+    case PRO_EMBED_ACT: LP(PRO_EMBED_ACT); break;
+    case PRO_EMBED_OBS: LP(PRO_EMBED_OBS); break;
+    case PRO_RESNORM: LP(PRO_RESNORM); break;
+    default: LP(PRO_HEADMID); break;
+  }
+#undef LP
+  return check_launch("magpo_linear_pro");
 }
 
 extern "C" long magpo_wgrad_workspace_floats(int KIN, int NOUT, int G) { return (long)G * ((long)KIN * NOUT + NOUT); }

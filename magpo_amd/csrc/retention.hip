@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
 __global__ __launch_bounds__(256) void k_ret_recurrent(float* __restrict__ S, const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, long ldq, long ldk, long ldv, long env_stride_rows,
                                                        float* __restrict__ r, long ldr, int ntok, int ret_from, float decay,
-                                                       int write_state) {
+                                                       int write_state, const float* __restrict__ gp, long ldg,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta) {
   // thread -> 4 state columns (c4..c4+3) x 4 state rows (rw, rw+16, rw+32, rw+48): float4 accesses, a wave
   // touches 4 consecutive 256-B rows (1 KiB contiguous) per instruction.
   __shared__ __align__(16) float qs[16][64], ks[16][64], vs[16][64];
@@ -461,9 +462,21 @@ __global__ __launch_bounds__(256) void k_ret_recurrent(float* __restrict__ S, co
     if (lane < 16) *reinterpret_cast<float4*>(&part[wave][a][c4]) = p;
   }
   __syncthreads();
-  for (int i = tid; i < (ntok - ret_from) * 64; i += 256) {
-    int a = ret_from + (i >> 6), c = i & 63;
-    r[(row0 + a) * ldr + c] = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
+  if (!gp) {
+    for (int i = tid; i < (ntok - ret_from) * 64; i += 256) {
+      int a = ret_from + (i >> 6), c = i & 63;
+      r[(row0 + a) * ldr + c] = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
+    }
+  } else {
+    // fused retention epilogue (retention.py:289-294): u = swish(gpre) * GroupNorm(ret); one wave per token
+    for (int a = ret_from + wave; a < ntok; a += 4) {
+      const float x = (part[0][a][lane] + part[1][a][lane]) + (part[2][a][lane] + part[3][a][lane]);
+      const float mu = wave_sum(x) * (1.0f / 64.0f);
+      const float m2 = wave_sum(x * x) * (1.0f / 64.0f);
+      const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + 1e-6f);
+      const float rn = (x - mu) * rstd * gamma[lane] + beta[lane];
+      r[(row0 + a) * ldr + lane] = swishf_(gp[(row0 + a) * ldg + lane]) * rn;
+    }
   }
 }
 
@@ -519,10 +532,11 @@ extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* 
 
 extern "C" int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
-                                         int write_state, hipStream_t st) {
+                                         int write_state, const float* gp, long ldg, const float* gamma, const float* beta,
+                                         hipStream_t st) {
   if (ntok < 1 || ntok > 16 || ret_from < 0 || ret_from >= ntok) { set_error("retention_recurrent: 1 <= ntok <= 16, 0 <= ret_from < ntok"); return MAGPO_EINVAL; }
   hipLaunchKernelGGL(k_ret_recurrent, dim3(nenv), dim3(256), 0, st, S, q, k, v, ldq, ldk, ldv, env_stride_rows, r, ldr, ntok, ret_from,
-                     decay, write_state);
+                     decay, write_state, gp, ldg, gamma, beta);
   return check_launch("magpo_retention_recurrent");
 }
 

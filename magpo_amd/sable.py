@@ -118,69 +118,65 @@ class SableGuider:
         self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P, stride or slab.shape[1], 1.0, 0, self._st())
 
     # ------------------------------------------------------------------ acting (recurrent form)
+    def _pro(self, pro, a, lda, y, ldy_in, s1, s2, use_pe, pos, pos_stride, W, idx, idx_stride, out, ldout, outpe, ldoutpe,
+             Wt, bias, Y, ldy, R, NOUT):
+        """Dense layer with the preceding row-wise op fused into its prologue (csrc/linear.hip: k_linear_pro)."""
+        self.L.call("magpo_linear_pro", pro, a, lda, y, ldy_in, s1, s2, self.pe, pos, pos_stride, self.npos, 1 if use_pe else 0,
+                    W, idx, idx_stride, self.v["enc.obs.norm.scale"], self.F, out, ldout, outpe, ldoutpe, Wt, bias, Y, ldy, R, NOUT,
+                    self._st())
+
     def act(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False):
-        """One env step for N envs.  obs [N,A,F] f32, pos [N] i32 (step_count), states = (S_enc, S_d1, S_d2)
-        each [N,64,64] updated in place, sample_keys = host uint32 array [A,2].
-        Writes action [N,A] i32, logp [N,A], value [N,A] (tensors / views with row stride A)."""
+        """One env step for N envs (SableNetwork.get_actions, sable_network.py:443-482).  obs [N,A,F] f32, pos [N] i32
+        (step_count), states = (S_enc, S_d1, S_d2) each [N,64,64] updated in place, sample_keys = [A,2] uint32 (host
+        array: keys by value; device tensor: static arguments for graph replay).
+        Writes action [N,A] i32, logp [N,A], value [N,A].  Row-wise ops are fused into the prologue of the dense layer
+        that follows them and the GroupNorm + swish gate into the recurrent retention kernel: 6 + 9*A launches."""
         L, st, A, K, F = self.L, self._st(), self.A, self.K, self.F
         N = obs.shape[0]
         R = N * A
         v, b = self.v, self.b
-        xn = b.get("a_xn", (R, E)); kin = b.get("a_kin", (R, E)); qkvg = b.get("a_qkvg", (R, 4 * E))
-        r = b.get("a_r", (R, E)); u = b.get("a_u", (R, E)); y = b.get("a_y", (R, E))
+        xn = b.get("a_xn", (R, E)); qkvg = b.get("a_qkvg", (R, 4 * E)); u = b.get("a_u", (R, E)); y = b.get("a_y", (R, E))
         rep = b.get("a_rep", (R, E)); reppe = b.get("a_reppe", (R, E)); hv = b.get("a_hv", (R, E))
         s_enc, s_d1, s_d2 = states
         if value_only:  # bootstrap value (rec_magpo.py:202-208): states must not change
             s_enc = b.get("a_senc_tmp", tuple(s_enc.shape)).copy_(s_enc)
-        # pos is per env: expand to per token with a stride trick (row -> env = row // A) via a small index buffer
         pos_tok = b.get("a_pos", (R,), torch.int32)
         pos_tok.view(N, A).copy_(pos.view(N, 1).expand(N, A))
-        L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0,
-               v["enc.ln.scale"], self.pe, pos_tok, 1, self.npos, None, 0, xn, E, kin, E, R, st)
-        self.lin(kin, E, self.wt["qkvg"], None, qkvg, 4 * E, R, E, 4 * E)
-        L.call("magpo_retention_recurrent", s_enc, qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, r, E, N, A, 0,
-               self.kappa, 1, st)
-        L.call("magpo_retpost_fwd", r, E, qkvg[:, 3 * E:], 4 * E, v["enc.block0.retn.gn.scale"], v["enc.block0.retn.gn.bias"],
-               u, E, R, st)
+        # encoder over the A tokens of this timestep (act_encoder_fn, encode.py:58-84)
+        self._pro(2, obs, F, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, v["enc.obs.dense.kernel"], None, 0, xn, E, None, 0,
+                  self.wt["qkvg"], None, qkvg, 4 * E, R, 4 * E)
+        L.call("magpo_retention_recurrent", s_enc, qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, u, E, N, A, 0,
+               self.kappa, 1, qkvg[:, 3 * E:], 4 * E, v["enc.block0.retn.gn.scale"], v["enc.block0.retn.gn.bias"], st)
         self.lin(u, E, self.wt["wo"], None, y, E, R, E, E)
-        L.call("magpo_resnorm_fwd", xn, E, y, E, v["enc.block0.ln1.scale"], v["enc.block0.ln2.scale"], self.pe, pos_tok, 1,
-               self.npos, rep, E, reppe, E, R, st)
-        self.lin(rep, E, self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E, E)
+        self._pro(3, xn, E, y, E, v["enc.block0.ln1.scale"], v["enc.block0.ln2.scale"], False, pos_tok, 1, None, None, 0, rep, E, reppe, E,
+                  self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E)
         L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"],
                v["enc.head.dense1.bias"], value_out, 1, R, st)
         if value_only:
             return
-        # autoregressive decoder (decode.py:111-153): one token per env per iteration
+        # autoregressive decoder (decode.py:111-153): one token per env per iteration.  Per-agent projections stay
+        # resident ([N, A, .]) so that a retention state is read once per agent and written once per step.
         prev = b.get("a_prev", (N, A), torch.int32, zero=True)
-        # per-agent projections stay resident ([N, A, .]) so that the retention states are read once per agent and
-        # written once per step: iteration i applies the rank-1 updates of tokens 0..i on the fly
-        xa = b.get("d_xa", (N, E)); kin1 = b.get("d_kin1", (N, E)); qkvg1 = b.get("d_qkvg1", (N * A, 4 * E))
-        r1 = b.get("d_r1", (N * A, E)); u1 = b.get("d_u1", (N, E)); y1 = b.get("d_y1", (N, E))
-        c = b.get("d_c", (N, E)); cpe = b.get("d_cpe", (N, E)); q2 = b.get("d_q2", (N * A, E)); kvg2 = b.get("d_kvg2", (N * A, 3 * E))
-        r2 = b.get("d_r2", (N * A, E)); u2 = b.get("d_u2", (N, E)); y2 = b.get("d_y2", (N, E)); out = b.get("d_out", (N, E))
-        hp = b.get("d_hp", (N, E)); hn = b.get("d_hn", (N, E)); logits = b.get("d_logits", (N, E), zero=True)
+        xa = b.get("d_xa", (N, E)); qkvg1 = b.get("d_qkvg1", (R, 4 * E)); u1 = b.get("d_u1", (R, E)); y1 = b.get("d_y1", (N, E))
+        q2 = b.get("d_q2", (R, E)); kvg2 = b.get("d_kvg2", (R, 3 * E)); u2 = b.get("d_u2", (R, E)); y2 = b.get("d_y2", (N, E))
+        hp = b.get("d_hp", (N, E)); logits = b.get("d_logits", (N, E), zero=True)
+        self.lin(reppe, E, self.wt["q2"], None, q2, E, R, E, E)   # cross-retention queries of all agents at once
         for i in range(A):
             last = 1 if i == A - 1 else 0
-            L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev[:, i:], A, v["dec.ln.scale"], self.pe,
-                   pos, 1, self.npos, None, 0, xa, E, kin1, E, N, st)
-            self.lin(kin1, E, self.wt["qkvg1"], None, qkvg1[i:], A * 4 * E, N, E, 4 * E)
-            L.call("magpo_retention_recurrent", s_d1, qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, A, r1, E, N, i + 1, i,
-                   self.kappa, last, st)
-            L.call("magpo_retpost_fwd", r1[i:], A * E, qkvg1[i:, 3 * E:], A * 4 * E, v["dec.block0.retn1.gn.scale"],
-                   v["dec.block0.retn1.gn.bias"], u1, E, N, st)
-            self.lin(u1, E, self.wt["wo1"], None, y1, E, N, E, E)
-            L.call("magpo_resnorm_fwd", xa, E, y1, E, v["dec.block0.ln1.scale"], None, self.pe, pos, 1, self.npos, c, E, cpe, E, N, st)
-            self.lin(reppe[i:], A * E, self.wt["q2"], None, q2[i:], A * E, N, E, E)
-            self.lin(cpe, E, self.wt["kvg2"], None, kvg2[i:], A * 3 * E, N, E, 3 * E)
-            L.call("magpo_retention_recurrent", s_d2, q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, A, r2, E, N, i + 1, i, self.kappa, last, st)
-            L.call("magpo_retpost_fwd", r2[i:], A * E, kvg2[i:, 2 * E:], A * 3 * E, v["dec.block0.retn2.gn.scale"],
-                   v["dec.block0.retn2.gn.bias"], u2, E, N, st)
-            self.lin(u2, E, self.wt["wo2"], None, y2, E, N, E, E)
-            L.call("magpo_resnorm_fwd", rep[i:], A * E, y2, E, v["dec.block0.ln2.scale"], v["dec.block0.ln3.scale"], None, None, 0, 0,
-                   out, E, None, 0, N, st)
-            self.lin(out, E, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, N, E, E)
-            L.call("magpo_headmid_fwd", hp, E, v["dec.head.norm.scale"], hn, E, None, None, None, 0, N, st)
-            self.lin(hn, E, self.wt["h1"], v["dec.head.dense1.bias"], logits, E, N, E, K)
+            self._pro(1, None, 0, None, 0, v["dec.ln.scale"], None, True, pos, 1, v["dec.act.kernel"], prev[:, i:], A, xa, E, None, 0,
+                      self.wt["qkvg1"], None, qkvg1[i:], A * 4 * E, N, 4 * E)
+            L.call("magpo_retention_recurrent", s_d1, qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, A, u1, E, N, i + 1, i,
+                   self.kappa, last, qkvg1[:, 3 * E:], 4 * E, v["dec.block0.retn1.gn.scale"], v["dec.block0.retn1.gn.bias"], st)
+            self.lin(u1[i:], A * E, self.wt["wo1"], None, y1, E, N, E, E)
+            self._pro(3, xa, E, y1, E, v["dec.block0.ln1.scale"], None, True, pos, 1, None, None, 0, None, 0, None, 0,
+                      self.wt["kvg2"], None, kvg2[i:], A * 3 * E, N, 3 * E)
+            L.call("magpo_retention_recurrent", s_d2, q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, A, u2, E, N, i + 1, i, self.kappa, last,
+                   kvg2[:, 2 * E:], 3 * E, v["dec.block0.retn2.gn.scale"], v["dec.block0.retn2.gn.bias"], st)
+            self.lin(u2[i:], A * E, self.wt["wo2"], None, y2, E, N, E, E)
+            self._pro(3, rep[i:], A * E, y2, E, v["dec.block0.ln2.scale"], v["dec.block0.ln3.scale"], False, pos, 1, None, None, 0,
+                      None, 0, None, 0, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, N, E)
+            self._pro(4, hp, E, None, 0, v["dec.head.norm.scale"], None, False, pos, 1, None, None, 0, None, 0, None, 0,
+                      self.wt["h1"], v["dec.head.dense1.bias"], logits, E, N, K)
             if torch.is_tensor(sample_keys):   # device key table [A, 2] (static arguments: HIP-graph replay)
                 k0, k1, kdev = 0, 0, sample_keys[i]
             else:

@@ -250,14 +250,14 @@ def test_retention_recurrent(L, stream):
     q, k, v = (torch.randn(N * A, 64, generator=g) for _ in range(3))
     Sd = dev(S)
     r = torch.zeros(N * A, 64, device=DEV)
-    L.call("magpo_retention_recurrent", Sd, dev(q), 64, dev(k), 64, dev(v), 64, A, r, 64, N, A, 0, 0.775, 1, stream)
+    L.call("magpo_retention_recurrent", Sd, dev(q), 64, dev(k), 64, dev(v), 64, A, r, 64, N, A, 0, 0.775, 1, None, 0, None, None, stream)
     qq, kk, vv = (t.double().reshape(N, A, 64) for t in (q, k, v))
     Sn = 0.775 * S.double() + kk.transpose(1, 2) @ vv
     close(Sd, Sn, what="S"); close(r.reshape(N, A, 64), qq @ Sn, what="ret")
     # decoder iteration i = 2: tokens 0..2 applied on the fly, output for token 2 only, state left untouched
     S2 = dev(S)
     r2 = torch.zeros(N * A, 64, device=DEV)
-    L.call("magpo_retention_recurrent", S2, dev(q), 64, dev(k), 64, dev(v), 64, A, r2, 64, N, 3, 2, 0.775, 0, stream)
+    L.call("magpo_retention_recurrent", S2, dev(q), 64, dev(k), 64, dev(v), 64, A, r2, 64, N, 3, 2, 0.775, 0, None, 0, None, None, stream)
     Sn = 0.775 * S.double() + kk[:, :3].transpose(1, 2) @ vv[:, :3]
     close(S2, S, 0, 0, "state must not be written")
     close(r2.reshape(N, A, 64)[:, 2], (qq[:, 2:3] @ Sn)[:, 0], what="ret token 2")
