@@ -79,7 +79,7 @@ class KernelTimer:
         return None
 
     def begin(self, name, args):
-        if not self.enabled:
+        if not self.enabled or torch.cuda.is_current_stream_capturing():
             return None
         m = self._model(name, args)
         if m is None:
@@ -204,6 +204,12 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    # setup (untimed, not part of W): the first update step allocates every workspace, the second one captures the
+    # 128-step rollout into a HIP graph; from then on every step does identical work
+    for i in range(2):
+        learner.update_step(grad_sync)
+    torch.cuda.synchronize()
+    log("setup done (workspaces allocated, rollout graph captured)")
     for i in range(args.warmup):
         learner.update_step(grad_sync)
         torch.cuda.synchronize()
