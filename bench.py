@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (+3 %%; kernel timings then include contention)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
@@ -185,6 +186,9 @@ def main():
     learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0)  # same seed => replicated parameters on every rank
     key = host_split(prng_key(42), 4)[0]
     learner.setup(key, n_groups=world, group=rank)
+    if args.overlap:
+        learner.overlap_actor = True
+        learner.guider.overlap_wgrad = learner.actor.overlap_wgrad = True
     grad_sync = mdist.make_grad_sync(world)
 
     def barrier():

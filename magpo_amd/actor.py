@@ -40,6 +40,8 @@ class GruActor:
             init_actor(self.named, seed)
         self.wt: Dict[str, torch.Tensor] = {}
         self.b = _Bufs(device)
+        self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.overlap_wgrad = False  # opt-in (bench.py --overlap): ~0.5 %, but per-kernel timings then include contention
         self.wg_ws = torch.empty(self.L.call("magpo_wgrad_workspace_floats", H, 3 * H, self.G), device=device)
         self.refresh()
 
@@ -72,7 +74,14 @@ class GruActor:
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, None, R, KIN, NOUT, act, self._st())
 
     def wgrad(self, X, ldx, dY, ldy, R, KIN, NOUT, dW, db=None, krows=None):
-        self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+        """dW = X^T dY, queued on the side stream (off the critical path of the backward chain)."""
+        side = self.wgrad_stream if self.overlap_wgrad else None
+        if side is None:
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
 
     # one step for N envs: returns new hidden [N*A,128]; logits [N*A,64] if want_logits
     def step(self, obs, h_in, reset_env, h_out, want_logits: bool = False):
@@ -127,10 +136,12 @@ class GruActor:
         L.call("magpo_reduce_slabs", slab, gv["gru.hn.bias"], nblk, H, H, 1.0, 0, st)
         self.wgrad(t("emb"), H, dxi, 3 * H, R, H, 3 * H, gv["gru.wi"], gv["gru.bi"])
         self.wgrad(t("hprev"), H, dhh, 3 * H, R, H, 3 * H, gv["gru.wh"])
-        demb = dy
+        demb = b.get("g_demb", (R, H))
         self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H)
         grid = L.call("magpo_row_grid", R)
         sw = b.get("g_slabw", (grid, 33 * H))
         L.call("magpo_small_relu_wgrad", obs, F, F, t("emb"), demb, sw, R, st)
         L.call("magpo_reduce_slabs", sw, gv["pre.kernel"], grid, F * H, 33 * H, 1.0, 0, st)
         L.call("magpo_reduce_slabs", sw[:, 32 * H:], gv["pre.bias"], grid, H, 33 * H, 1.0, 0, st)
+        if self.overlap_wgrad and self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)

@@ -156,7 +156,7 @@ class MagpoLearner:
         self.adv_stats = f32(2)
         self._mb: Dict[str, torch.Tensor] = {}
         # the actor's forward / backward run on a second HIP stream next to the guider's (independent until the loss)
-        self.overlap_actor = True
+        self.overlap_actor = False  # opt-in (bench.py --overlap): ~3 %, but per-kernel timings then include contention
         self._actor_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
     # group-0 shortcuts (single-group callers and the parity tests)

@@ -69,6 +69,9 @@ class SableGuider:
             self.L.call("magpo_pe_table", self.pe, max_pos, E, self._st())
         self.wt: Dict[str, torch.Tensor] = {}
         self.b = _Bufs(device)
+        # weight-gradient GEMMs run on a side stream: they are off the critical path of the backward chain
+        self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.overlap_wgrad = False  # opt-in (bench.py --overlap): ~0.5 %, but per-kernel timings then include contention
         self.wg_ws = torch.empty(self.L.call("magpo_wgrad_workspace_floats", E, 4 * E, self.G), device=device)
         self.refresh()
 
@@ -112,7 +115,15 @@ class SableGuider:
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self._st())
 
     def wgrad(self, X, ldx, dY, ldy, R, KIN, NOUT, dW, db=None, krows=None):
-        self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+        """dW = X^T dY.  With overlap_wgrad the GEMM is queued on the side stream behind everything the calling stream
+        has queued so far (so X and dY are complete); the caller must not overwrite dY before train_bwd joins."""
+        side = self.wgrad_stream if self.overlap_wgrad else None
+        if side is None:
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
 
     def reduce(self, slab, out, P=64, stride=None):
         self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P, stride or slab.shape[1], 1.0, 0, self._st())
@@ -249,7 +260,7 @@ class SableGuider:
         self.wgrad(t("hn"), E, dlogits, E, R, E, K, gv["dec.head.dense1.kernel"], gv["dec.head.dense1.bias"])
         dhn = g("dhn")
         self.lin(dlogits, E, self.wt["h1_nat_pad"], None, dhn, E, R, E, E)
-        dhp = g("dhp")
+        dhp = g("dhp_l")
         L.call("magpo_headmid_bwd", t("hp"), E, v["dec.head.norm.scale"], dhn, E, None, None, 0, dhp, E, slab("a"), None, None, R, st)
         self.reduce(slab("a"), gv["dec.head.norm.scale"])
         self.wgrad(t("out"), E, dhp, E, R, E, E, gv["dec.head.dense0.kernel"], gv["dec.head.dense0.bias"])
@@ -283,7 +294,7 @@ class SableGuider:
         self.wgrad(t("u1"), E, dsum1, E, R, E, E, gv["dec.block0.retn1.w_o"])
         du1 = g("du")
         self.lin(dsum1, E, v["dec.block0.retn1.w_o"], None, du1, E, R, E, E)
-        dr1 = g("dr"); dqkvg1 = g("dqkvg", 4 * E)
+        dr1 = g("dr"); dqkvg1 = g("dqkvg1", 4 * E)
         qkvg1 = t("qkvg1")
         L.call("magpo_retpost_bwd", t("r1"), E, qkvg1[:, 3 * E:], 4 * E, v["dec.block0.retn1.gn.scale"], v["dec.block0.retn1.gn.bias"],
                du1, E, dr1, E, dqkvg1[:, 3 * E:], 4 * E, slab("a"), slab("b"), R, st)
@@ -299,7 +310,7 @@ class SableGuider:
         self.reduce(slab("a"), gv["dec.ln.scale"])
         self.reduce(slab("w", 32 * E), gv["dec.act.kernel"], P=(K + 1) * E, stride=32 * E)
         # ---- value head
-        dhv = g("dhp")
+        dhv = g("dhv")
         L.call("magpo_headmid_bwd", t("hv"), E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], dvalue, 1, dhv, E,
                slab("a"), slab("b"), slab("c", 1), R, st)
         self.reduce(slab("a"), gv["enc.head.norm.scale"]); self.reduce(slab("b"), gv["enc.head.dense1.kernel"])
@@ -308,7 +319,7 @@ class SableGuider:
         drep_v = g("dout")
         self.lin(dhv, E, v["enc.head.dense0.kernel"], None, drep_v, E, R, E, E)
         # ---- encoder block: rep = rms(rms(xn + y) * ln1) * ln2 ; d(rep) = value head + cross-retention query + decoder residual
-        dsum0 = g("dsum1")
+        dsum0 = g("dsum0")
         L.call("magpo_resnorm_bwd", t("xn"), E, t("y"), E, v["enc.block0.ln1.scale"], v["enc.block0.ln2.scale"], drep_v, E, dreppe, E,
                dsum2, E, dsum0, E, slab("a"), slab("b"), R, st)
         self.reduce(slab("a"), gv["enc.block0.ln1.scale"]); self.reduce(slab("b"), gv["enc.block0.ln2.scale"])
@@ -331,3 +342,5 @@ class SableGuider:
         self.reduce(slab("a"), gv["enc.ln.scale"])
         self.reduce(slab("d", 32), gv["enc.obs.norm.scale"], P=F, stride=32)
         self.reduce(slab("w", 32 * E), gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)
+        if self.overlap_wgrad and self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
