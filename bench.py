@@ -50,7 +50,7 @@ class KernelTimer:
             R, KIN, NOUT = a[4], a[5], a[7]
             if R < self.min_rows:
                 return None
-            return "wgrad", 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
+            return ("wgrad<2>" if NOUT >= 128 else "wgrad<1>"), 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
         if name in ("magpo_retention_chunk_fwd", "magpo_retention_chunk_bwd"):
             fwd = name.endswith("fwd")
             nseq, T, A = (a[13], a[14], a[15]) if fwd else (a[16], a[17], a[18])
