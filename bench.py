@@ -117,7 +117,19 @@ class KernelTimer:
             roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
         else:
             roof = dict(bound="mfma", achieved=round(tfs, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(tfs / PEAK_F32_MFMA_TF, 4))
-        roof.update(kernel=key, avg_us=round(avg_s * 1e6, 1), calls=r["calls"], traffic=None)
+        roof.update(kernel=key, avg_us=round(avg_s * 1e6, 1), calls=r["calls"], traffic=None,
+                    algorithmic_bytes_per_launch=round(r["bytes"] / r["calls"]))
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; same
+        # workload, profiles/r01_pmc_hbm_traffic.json).  Only attached when the kernel family matches.
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                pmc = json.load(f)
+            name = {"wgrad<2>": "k_wgrad<2>", "wgrad<1>": "k_wgrad<1>", "ret_chunk_bwd": "k_ret_chunk_bwd", "ret_chunk_fwd": "k_ret_chunk_fwd",
+                    "gru_scan_fwd": "k_gru_scan_fwd", "gru_scan_bwd": "k_gru_scan_bwd"}.get(key)
+            if name in pmc:
+                roof["traffic"] = round(pmc[name]["total"])
+        except (OSError, ValueError):
+            pass
         table = {k: dict(calls=v["calls"], ms=round(v["ms"], 2), gbs=round(v["bytes"] / v["ms"] / 1e6, 1),
                          tflops=round(v["flops"] / v["ms"] / 1e9, 2)) for k, v in sorted(self.rec.items(), key=lambda kv: -kv[1]["ms"])}
         return roof, table
