@@ -91,6 +91,7 @@ int magpo_headmid_bwd(const float* hpre, int ldh, const float* s, const float* d
                       const float* dvalue, int dvalue_stride, float* dhpre, int lddh, float* slab_s,
                       float* slab_w, float* slab_b, long R, magpo_stream_t stream);
 int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, magpo_stream_t stream);
+int magpo_add_inplace(float* dst, const float* src, long n, magpo_stream_t stream);
 
 /* ---- K2/K7 retention (retention.py:66-115 chunkwise + recurrent, :117-213 decay matrix / xi) ---- */
 int magpo_retention_num_chunks(int T, int A);

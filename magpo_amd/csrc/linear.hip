@@ -249,11 +249,15 @@ __global__ __launch_bounds__(256) void k_linear_pro(ProArgs p, const float* __re
       rms_inplace(af, p.s1, h);
     } else if (PRO == PRO_RESNORM) {
       const float* ap = p.a + rr * p.lda + 32 * h;
-      const float* yp = p.y + rr * p.ldy_ + 32 * h;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float4 x = *reinterpret_cast<const float4*>(ap + 4 * u), y = *reinterpret_cast<const float4*>(yp + 4 * u);
-        af[u] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      for (int u = 0; u < 8; ++u) af[u] = *reinterpret_cast<const float4*>(ap + 4 * u);
+      if (p.y) {  // null addend = plain norm (input of encoder blocks > 0)
+        const float* yp = p.y + rr * p.ldy_ + 32 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float4 y = *reinterpret_cast<const float4*>(yp + 4 * u);
+          af[u].x += y.x; af[u].y += y.y; af[u].z += y.z; af[u].w += y.w;
+        }
       }
       rms_inplace(af, p.s1, h);
       if (p.s2) rms_inplace(af, p.s2, h);

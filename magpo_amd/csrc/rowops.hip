@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void k_resnorm_fwd(ResNormArgs p) {
     const long row = base + wave * 4 + (lane >> 4);
     const bool ok = row < p.R;
     float4 x = f4zero();
-    if (ok) x = f4add(ld4(p.a + row * p.lda + c4), ld4(p.y + row * p.ldy + c4));
+    if (ok) {
+      x = ld4(p.a + row * p.lda + c4);
+      if (p.y) x = f4add(x, ld4(p.y + row * p.ldy + c4));
+    }
     float4 o = rms_fwd(x, s1).y;
     if (p.s2) o = rms_fwd(o, s2).y;
     if (ok) {
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(256) void k_resnorm_bwd(ResNormBwdArgs p) {
     const bool ok = row < p.R;
     float4 x = f4zero(), d = f4zero();
     if (ok) {
-      x = f4add(ld4(p.a + row * p.lda + c4), ld4(p.y + row * p.ldy + c4));
+      x = ld4(p.a + row * p.lda + c4);
+      if (p.y) x = f4add(x, ld4(p.y + row * p.ldy + c4));
       d = ld4(p.d0 + row * p.ldd0 + c4);
       if (p.d1) d = f4add(d, ld4(p.d1 + row * p.ldd1 + c4));
       if (p.d2) d = f4add(d, ld4(p.d2 + row * p.ldd2 + c4));
@@ -470,6 +474,13 @@ __global__ __launch_bounds__(256) void k_headmid_bwd(const float* __restrict__ h
 }
 
 // generic elementwise helpers -------------------------------------------------------------------
+// dst[i] += src[i]
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = ld4(dst + i), b = ld4(src + i);
+  st4(dst + i, f4add(a, b));
+}
 // y = relu'(act) * dy  (act is the post-relu activation), in place allowed
 __global__ void k_relu_bwd(const float* __restrict__ act, const float* __restrict__ dy, float* __restrict__ dx, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -580,6 +591,12 @@ extern "C" int magpo_headmid_bwd(const float* hpre, int ldh, const float* s, con
   hipLaunchKernelGGL(k_headmid_bwd, dim3(row_grid(R)), dim3(256), 0, st, hpre, ldh, s, dhn, lddhn, w, dvalue, dvalue_stride,
                      dhpre, lddh, slab_s, slab_w, slab_b, R);
   return check_launch("magpo_headmid_bwd");
+}
+
+extern "C" int magpo_add_inplace(float* dst, const float* src, long n, hipStream_t st) {
+  if (n & 3) { set_error("magpo_add_inplace: n must be a multiple of 4"); return MAGPO_EINVAL; }
+  hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dst, src, n);
+  return check_launch("magpo_add_inplace");
 }
 
 extern "C" int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, hipStream_t st) {

@@ -42,7 +42,7 @@ class FlatParams:
         return {n: self.view_of(flat, n) for n in self.shapes}
 
 
-def guider_layout(E: int, F: int, K: int) -> "OrderedDict[str, Tuple[int, ...]]":
+def guider_layout(E: int, F: int, K: int, nb: int = 1) -> "OrderedDict[str, Tuple[int, ...]]":
     assert E == 64, "the gfx950 kernels are specialised for embed_dim = 64"
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     s["enc.ln.scale"] = (E,)
@@ -53,14 +53,16 @@ def guider_layout(E: int, F: int, K: int) -> "OrderedDict[str, Tuple[int, ...]]"
     s["enc.head.norm.scale"] = (E,)
     s["enc.head.dense1.kernel"] = (E, 1)
     s["enc.head.dense1.bias"] = (1,)
-    s["enc.block0.ln1.scale"] = (E,)
-    s["enc.block0.ln2.scale"] = (E,)
-    s["enc.block0.retn.w_qkvg"] = (E, 4 * E)
-    s["enc.block0.retn.w_o"] = (E, E)
-    s["enc.block0.retn.gn.scale"] = (E,)
-    s["enc.block0.retn.gn.bias"] = (E,)
-    for w in ("W_linear", "W_gate", "W_output"):
-        s[f"enc.block0.ffn.{w}"] = (E, E)
+    for b in range(nb):
+        p = f"enc.block{b}."
+        s[p + "ln1.scale"] = (E,)
+        s[p + "ln2.scale"] = (E,)
+        s[p + "retn.w_qkvg"] = (E, 4 * E)
+        s[p + "retn.w_o"] = (E, E)
+        s[p + "retn.gn.scale"] = (E,)
+        s[p + "retn.gn.bias"] = (E,)
+        for w in ("W_linear", "W_gate", "W_output"):
+            s[p + f"ffn.{w}"] = (E, E)
     s["dec.ln.scale"] = (E,)
     s["dec.act.kernel"] = (K + 1, E)
     s["dec.head.dense0.kernel"] = (E, E)
@@ -68,19 +70,21 @@ def guider_layout(E: int, F: int, K: int) -> "OrderedDict[str, Tuple[int, ...]]"
     s["dec.head.norm.scale"] = (E,)
     s["dec.head.dense1.kernel"] = (E, K)
     s["dec.head.dense1.bias"] = (K,)
-    for n in ("ln1", "ln2", "ln3"):
-        s[f"dec.block0.{n}.scale"] = (E,)
-    s["dec.block0.retn1.w_qkvg"] = (E, 4 * E)
-    s["dec.block0.retn1.w_o"] = (E, E)
-    s["dec.block0.retn1.gn.scale"] = (E,)
-    s["dec.block0.retn1.gn.bias"] = (E,)
-    s["dec.block0.retn2.w_q"] = (E, E)
-    s["dec.block0.retn2.w_kvg"] = (E, 3 * E)
-    s["dec.block0.retn2.w_o"] = (E, E)
-    s["dec.block0.retn2.gn.scale"] = (E,)
-    s["dec.block0.retn2.gn.bias"] = (E,)
-    for w in ("W_linear", "W_gate", "W_output"):
-        s[f"dec.block0.ffn.{w}"] = (E, E)
+    for b in range(nb):
+        p = f"dec.block{b}."
+        for n in ("ln1", "ln2", "ln3"):
+            s[p + f"{n}.scale"] = (E,)
+        s[p + "retn1.w_qkvg"] = (E, 4 * E)
+        s[p + "retn1.w_o"] = (E, E)
+        s[p + "retn1.gn.scale"] = (E,)
+        s[p + "retn1.gn.bias"] = (E,)
+        s[p + "retn2.w_q"] = (E, E)
+        s[p + "retn2.w_kvg"] = (E, 3 * E)
+        s[p + "retn2.w_o"] = (E, E)
+        s[p + "retn2.gn.scale"] = (E,)
+        s[p + "retn2.gn.bias"] = (E,)
+        for w in ("W_linear", "W_gate", "W_output"):
+            s[p + f"ffn.{w}"] = (E, E)
     return s
 
 

@@ -45,8 +45,9 @@ class SableGuider:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, embed_dim: int = 64, n_head: int = 1,
                  n_block: int = 1, decay_scaling_factor: float = 0.8, use_pe: bool = True, max_pos: int = 101,
                  wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
-        if embed_dim != 64 or n_head != 1 or n_block != 1:
-            raise NotImplementedError("gfx950 Sable kernels: embed_dim=64, n_head=1, n_block=1 only (SURVEY 8f rank 3)")
+        if embed_dim != 64 or n_head != 1 or n_block < 1:
+            raise NotImplementedError("gfx950 Sable kernels: embed_dim=64, n_head=1 only (SURVEY 8f rank 3)")
+        self.nb = int(n_block)
         if obs_dim > 32 or action_dim > 31:
             raise NotImplementedError("obs_dim <= 32 and action_dim <= 31 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
@@ -54,7 +55,7 @@ class SableGuider:
         self.L = lib()
         self.kappa = decay_kappa(1, decay_scaling_factor)
         self.G = wgrad_groups
-        self.P = FlatParams(guider_layout(E, obs_dim, action_dim), device)
+        self.P = FlatParams(guider_layout(E, obs_dim, action_dim, self.nb), device)
         self.grads = torch.zeros_like(self.P.flat) if grads is None else grads
         assert self.grads.numel() == self.P.numel
         self.v = self.P.views()
@@ -104,10 +105,14 @@ class SableGuider:
     def refresh(self):
         """Rebuild the transposed (forward-GEMM) weight copies after a parameter update."""
         v = self.v
-        for key, name in [("qkvg", "enc.block0.retn.w_qkvg"), ("wo", "enc.block0.retn.w_o"), ("vh0", "enc.head.dense0.kernel"),
-                          ("qkvg1", "dec.block0.retn1.w_qkvg"), ("wo1", "dec.block0.retn1.w_o"), ("q2", "dec.block0.retn2.w_q"),
-                          ("kvg2", "dec.block0.retn2.w_kvg"), ("wo2", "dec.block0.retn2.w_o"), ("h0", "dec.head.dense0.kernel")]:
-            self._tp(key, v[name])
+        self._tp("vh0", v["enc.head.dense0.kernel"])
+        self._tp("h0", v["dec.head.dense0.kernel"])
+        for b in range(self.nb):
+            e, d = f"enc.block{b}.", f"dec.block{b}."
+            for key, name in [(f"qkvg{b}", e + "retn.w_qkvg"), (f"wo{b}", e + "retn.w_o"), (f"qkvg1{b}", d + "retn1.w_qkvg"),
+                              (f"wo1{b}", d + "retn1.w_o"), (f"q2{b}", d + "retn2.w_q"), (f"kvg2{b}", d + "retn2.w_kvg"),
+                              (f"wo2{b}", d + "retn2.w_o")]:
+                self._tp(key, v[name])
         h1t = self._tp("h1", v["dec.head.dense1.kernel"], 64)        # [64 (K padded)][64]
         self._tp("h1_nat_pad", h1t, E)                                # [64][64]: natural W padded to 64 columns
 
@@ -117,7 +122,8 @@ class SableGuider:
     def wgrad(self, X, ldx, dY, ldy, R, KIN, NOUT, dW, db=None, krows=None):
         """dW = X^T dY.  With overlap_wgrad the GEMM is queued on the side stream behind everything the calling stream
         has queued so far (so X and dY are complete); the caller must not overwrite dY before train_bwd joins."""
-        side = self.wgrad_stream if self.overlap_wgrad else None
+        # (with n_block > 1 the d(obs_rep) sums are accumulated in place, so the side stream is not used)
+        side = self.wgrad_stream if (self.overlap_wgrad and self.nb == 1) else None
         if side is None:
             self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
             return
@@ -125,8 +131,11 @@ class SableGuider:
         with torch.cuda.stream(side):
             self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
 
-    def reduce(self, slab, out, P=64, stride=None):
-        self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P, stride or slab.shape[1], 1.0, 0, self._st())
+    def reduce(self, slab, out, P=64, stride=None, accumulate=False):
+        self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P, stride or slab.shape[1], 1.0, 1 if accumulate else 0, self._st())
+
+    def add_(self, dst, src):
+        self.L.call("magpo_add_inplace", dst, src, dst.numel(), self._st())
 
     # ------------------------------------------------------------------ acting (recurrent form)
     def _pro(self, pro, a, lda, y, ldy_in, s1, s2, use_pe, pos, pos_stride, W, idx, idx_stride, out, ldout, outpe, ldoutpe,
@@ -138,11 +147,11 @@ class SableGuider:
 
     def act(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False):
         """One env step for N envs (SableNetwork.get_actions, sable_network.py:443-482).  obs [N,A,F] f32, pos [N] i32
-        (step_count), states = (S_enc, S_d1, S_d2) each [N,64,64] updated in place, sample_keys = [A,2] uint32 (host
-        array: keys by value; device tensor: static arguments for graph replay).
+        (step_count), states = (S_enc, S_d1, S_d2) each [n_block, N, 64, 64] updated in place, sample_keys = [A,2]
+        uint32 (host array: keys by value; device tensor: static arguments for graph replay).
         Writes action [N,A] i32, logp [N,A], value [N,A].  Row-wise ops are fused into the prologue of the dense layer
-        that follows them and the GroupNorm + swish gate into the recurrent retention kernel: 6 + 9*A launches."""
-        L, st, A, K, F = self.L, self._st(), self.A, self.K, self.F
+        that follows them and the GroupNorm + swish gate into the recurrent retention kernel."""
+        L, st, A, K, F, nb = self.L, self._st(), self.A, self.K, self.F, self.nb
         N = obs.shape[0]
         R = N * A
         v, b = self.v, self.b
@@ -154,13 +163,22 @@ class SableGuider:
         pos_tok = b.get("a_pos", (R,), torch.int32)
         pos_tok.view(N, A).copy_(pos.view(N, 1).expand(N, A))
         # encoder over the A tokens of this timestep (act_encoder_fn, encode.py:58-84)
-        self._pro(2, obs, F, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, v["enc.obs.dense.kernel"], None, 0, xn, E, None, 0,
-                  self.wt["qkvg"], None, qkvg, 4 * E, R, 4 * E)
-        L.call("magpo_retention_recurrent", s_enc, qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, u, E, N, A, 0,
-               self.kappa, 1, qkvg[:, 3 * E:], 4 * E, v["enc.block0.retn.gn.scale"], v["enc.block0.retn.gn.bias"], st)
-        self.lin(u, E, self.wt["wo"], None, y, E, R, E, E)
-        self._pro(3, xn, E, y, E, v["enc.block0.ln1.scale"], v["enc.block0.ln2.scale"], False, pos_tok, 1, None, None, 0, rep, E, reppe, E,
-                  self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E)
+        for blk in range(nb):
+            e = f"enc.block{blk}."
+            if blk == 0:
+                self._pro(2, obs, F, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, v["enc.obs.dense.kernel"], None, 0, xn, E, None, 0,
+                          self.wt["qkvg0"], None, qkvg, 4 * E, R, 4 * E)
+            else:  # x = ln(rep of the previous block) (shared self.ln, sable_network.py:150)
+                self._pro(3, rep, E, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, None, None, 0, xn, E, None, 0,
+                          self.wt[f"qkvg{blk}"], None, qkvg, 4 * E, R, 4 * E)
+            L.call("magpo_retention_recurrent", s_enc[blk], qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, u, E, N, A, 0,
+                   self.kappa, 1, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], st)
+            self.lin(u, E, self.wt[f"wo{blk}"], None, y, E, R, E, E)
+            if blk == nb - 1:
+                self._pro(3, xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], False, pos_tok, 1, None, None, 0, rep, E, reppe, E,
+                          self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E)
+            else:
+                L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], None, None, 0, 0, rep, E, None, 0, R, st)
         L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"],
                v["enc.head.dense1.bias"], value_out, 1, R, st)
         if value_only:
@@ -168,24 +186,40 @@ class SableGuider:
         # autoregressive decoder (decode.py:111-153): one token per env per iteration.  Per-agent projections stay
         # resident ([N, A, .]) so that a retention state is read once per agent and written once per step.
         prev = b.get("a_prev", (N, A), torch.int32, zero=True)
-        xa = b.get("d_xa", (N, E)); qkvg1 = b.get("d_qkvg1", (R, 4 * E)); u1 = b.get("d_u1", (R, E)); y1 = b.get("d_y1", (N, E))
-        q2 = b.get("d_q2", (R, E)); kvg2 = b.get("d_kvg2", (R, 3 * E)); u2 = b.get("d_u2", (R, E)); y2 = b.get("d_y2", (N, E))
+        xa = b.get("d_xa", (N, E)); y1 = b.get("d_y1", (N, E)); y2 = b.get("d_y2", (N, E)); xo = b.get("d_xo", (N, E))
+        xope = b.get("d_xope", (N, E))
         hp = b.get("d_hp", (N, E)); logits = b.get("d_logits", (N, E), zero=True)
-        self.lin(reppe, E, self.wt["q2"], None, q2, E, R, E, E)   # cross-retention queries of all agents at once
+        qkvg1 = [b.get(f"d_qkvg1_{k}", (R, 4 * E)) for k in range(nb)]
+        q2 = [b.get(f"d_q2_{k}", (R, E)) for k in range(nb)]
+        kvg2 = [b.get(f"d_kvg2_{k}", (R, 3 * E)) for k in range(nb)]
+        u1 = b.get("d_u1", (R, E)); u2 = b.get("d_u2", (R, E))
+        for blk in range(nb):   # cross-retention queries of all agents at once
+            self.lin(reppe, E, self.wt[f"q2{blk}"], None, q2[blk], E, R, E, E)
         for i in range(A):
             last = 1 if i == A - 1 else 0
-            self._pro(1, None, 0, None, 0, v["dec.ln.scale"], None, True, pos, 1, v["dec.act.kernel"], prev[:, i:], A, xa, E, None, 0,
-                      self.wt["qkvg1"], None, qkvg1[i:], A * 4 * E, N, 4 * E)
-            L.call("magpo_retention_recurrent", s_d1, qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, A, u1, E, N, i + 1, i,
-                   self.kappa, last, qkvg1[:, 3 * E:], 4 * E, v["dec.block0.retn1.gn.scale"], v["dec.block0.retn1.gn.bias"], st)
-            self.lin(u1[i:], A * E, self.wt["wo1"], None, y1, E, N, E, E)
-            self._pro(3, xa, E, y1, E, v["dec.block0.ln1.scale"], None, True, pos, 1, None, None, 0, None, 0, None, 0,
-                      self.wt["kvg2"], None, kvg2[i:], A * 3 * E, N, 3 * E)
-            L.call("magpo_retention_recurrent", s_d2, q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, A, u2, E, N, i + 1, i, self.kappa, last,
-                   kvg2[:, 2 * E:], 3 * E, v["dec.block0.retn2.gn.scale"], v["dec.block0.retn2.gn.bias"], st)
-            self.lin(u2[i:], A * E, self.wt["wo2"], None, y2, E, N, E, E)
-            self._pro(3, rep[i:], A * E, y2, E, v["dec.block0.ln2.scale"], v["dec.block0.ln3.scale"], False, pos, 1, None, None, 0,
-                      None, 0, None, 0, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, N, E)
+            for blk in range(nb):
+                d = f"dec.block{blk}."
+                if blk == 0:
+                    self._pro(1, None, 0, None, 0, v["dec.ln.scale"], None, True, pos, 1, v["dec.act.kernel"], prev[:, i:], A, xa, E, None, 0,
+                              self.wt["qkvg10"], None, qkvg1[0][i:], A * 4 * E, N, 4 * E)
+                    xin = xa
+                else:  # block input = previous block's output x (xo); key = query = value = x + pe (xope)
+                    self.lin(xope, E, self.wt[f"qkvg1{blk}"], None, qkvg1[blk][i:], A * 4 * E, N, E, 4 * E)
+                    xin = xo
+                L.call("magpo_retention_recurrent", s_d1[blk], qkvg1[blk], 4 * E, qkvg1[blk][:, E:], 4 * E, qkvg1[blk][:, 2 * E:], 4 * E, A, u1, E,
+                       N, i + 1, i, self.kappa, last, qkvg1[blk][:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], st)
+                self.lin(u1[i:], A * E, self.wt[f"wo1{blk}"], None, y1, E, N, E, E)
+                self._pro(3, xin, E, y1, E, v[d + "ln1.scale"], None, True, pos, 1, None, None, 0, None, 0, None, 0,
+                          self.wt[f"kvg2{blk}"], None, kvg2[blk][i:], A * 3 * E, N, 3 * E)
+                L.call("magpo_retention_recurrent", s_d2[blk], q2[blk], E, kvg2[blk], 3 * E, kvg2[blk][:, E:], 3 * E, A, u2, E, N, i + 1, i,
+                       self.kappa, last, kvg2[blk][:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], st)
+                self.lin(u2[i:], A * E, self.wt[f"wo2{blk}"], None, y2, E, N, E, E)
+                if blk == nb - 1:
+                    self._pro(3, rep[i:], A * E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], False, pos, 1, None, None, 0,
+                              None, 0, None, 0, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, N, E)
+                else:
+                    L.call("magpo_resnorm_fwd", rep[i:], A * E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], self.pe, pos, 1, self.npos,
+                           xo, E, xope, E, N, st)
             self._pro(4, hp, E, None, 0, v["dec.head.norm.scale"], None, False, pos, 1, None, None, 0, None, 0, None, 0,
                       self.wt["h1"], v["dec.head.dense1.bias"], logits, E, N, K)
             if torch.is_tensor(sample_keys):   # device key table [A, 2] (static arguments: HIP-graph replay)
@@ -198,61 +232,79 @@ class SableGuider:
     # ------------------------------------------------------------------ training forward (chunkwise form)
     def train_fwd(self, obs, prev_idx, pos, dones, s0, seq_env, nseq: int, T: int):
         """obs [R,F], prev_idx [R] (0 = start token, a+1 otherwise), pos [R] step counts, dones [nseq,T] u8,
-        s0 = three [N,64,64] rollout-start states indexed through seq_env [nseq].
+        s0 = three [n_block, N, 64, 64] rollout-start states indexed through seq_env [nseq].
         Returns (logits [R,64] raw with K valid columns, value [R])."""
-        L, st, A, K, F, v, b = self.L, self._st(), self.A, self.K, self.F, self.v, self.b
+        L, st, A, K, F, v, b, nb = self.L, self._st(), self.A, self.K, self.F, self.v, self.b, self.nb
         R = nseq * T * A
         nch = L.call("magpo_retention_num_chunks", T, A)
         g = lambda n, w=E: b.get("t_" + n, (R, w))
-        z, xn, kin, qkvg, r, u, y = g("z"), g("xn"), g("kin"), g("qkvg", 4 * E), g("r"), g("u"), g("y")
-        rep, reppe, hv, value = g("rep"), g("reppe"), g("hv"), b.get("t_value", (R,))
-        za, xa, kin1, qkvg1, r1, u1, y1 = g("za"), g("xa"), g("kin1"), g("qkvg1", 4 * E), g("r1"), g("u1"), g("y1")
-        c, cpe, q2, kvg2, r2, u2, y2 = g("c"), g("cpe"), g("q2"), g("kvg2", 3 * E), g("r2"), g("u2"), g("y2")
-        out, hp, hn = g("out"), g("hp"), g("hn")
-        logits = b.get("t_logits", (R, E), zero=True)
-        st_e = b.get("t_st_e", (nseq, nch, E, E)); st_1 = b.get("t_st_1", (nseq, nch, E, E)); st_2 = b.get("t_st_2", (nseq, nch, E, E))
+        stt = lambda n: b.get("t_" + n, (nseq, nch, E, E))
         self._saved = dict(obs=obs, prev_idx=prev_idx, pos=pos, dones=dones, nseq=nseq, T=T, R=R)
+        rep, reppe, hv, value = g("rep"), g("reppe"), g("hv"), b.get("t_value", (R,))
+        logits = b.get("t_logits", (R, E), zero=True)
+        # ---- encoder
         L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
-               self.pe, pos, 1, self.npos, z, E, xn, E, kin, E, R, st)
-        self.lin(kin, E, self.wt["qkvg"], None, qkvg, 4 * E, R, E, 4 * E)
-        L.call("magpo_retention_chunk_fwd", qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, E, s0[0], seq_env, dones,
-               st_e, None, nseq, T, A, 0, self.kappa, st)
-        L.call("magpo_retpost_fwd", r, E, qkvg[:, 3 * E:], 4 * E, v["enc.block0.retn.gn.scale"], v["enc.block0.retn.gn.bias"], u, E, R, st)
-        self.lin(u, E, self.wt["wo"], None, y, E, R, E, E)
-        L.call("magpo_resnorm_fwd", xn, E, y, E, v["enc.block0.ln1.scale"], v["enc.block0.ln2.scale"], self.pe, pos, 1, self.npos,
-               rep, E, reppe, E, R, st)
+               self.pe, pos, 1, self.npos, g("z"), E, g("xn0"), E, g("kin0"), E, R, st)
+        for k in range(nb):
+            e = f"enc.block{k}."
+            xn, kin, qkvg, r, u, y = g(f"xn{k}"), g(f"kin{k}"), g(f"qkvg{k}", 4 * E), g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
+            self.lin(kin, E, self.wt[f"qkvg{k}"], None, qkvg, 4 * E, R, E, 4 * E)
+            L.call("magpo_retention_chunk_fwd", qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, E, s0[0][k], seq_env, dones,
+                   stt(f"st_e{k}"), None, nseq, T, A, 0, self.kappa, st)
+            L.call("magpo_retpost_fwd", r, E, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], u, E, R, st)
+            self.lin(u, E, self.wt[f"wo{k}"], None, y, E, R, E, E)
+            if k == nb - 1:
+                L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], self.pe, pos, 1, self.npos,
+                       rep, E, reppe, E, R, st)
+            else:
+                repb = g(f"repb{k}")
+                L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], None, None, 0, 0, repb, E, None, 0, R, st)
+                L.call("magpo_resnorm_fwd", repb, E, None, 0, v["enc.ln.scale"], None, self.pe, pos, 1, self.npos,
+                       g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, st)
         self.lin(rep, E, self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E, E)
         L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
                value, 1, R, st)
+        # ---- decoder
         L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_idx, 1, v["dec.ln.scale"], self.pe, pos, 1, self.npos,
-               za, E, xa, E, kin1, E, R, st)
-        self.lin(kin1, E, self.wt["qkvg1"], None, qkvg1, 4 * E, R, E, 4 * E)
-        L.call("magpo_retention_chunk_fwd", qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, E, s0[1], seq_env, dones,
-               st_1, None, nseq, T, A, 1, self.kappa, st)
-        L.call("magpo_retpost_fwd", r1, E, qkvg1[:, 3 * E:], 4 * E, v["dec.block0.retn1.gn.scale"], v["dec.block0.retn1.gn.bias"], u1, E, R, st)
-        self.lin(u1, E, self.wt["wo1"], None, y1, E, R, E, E)
-        L.call("magpo_resnorm_fwd", xa, E, y1, E, v["dec.block0.ln1.scale"], None, self.pe, pos, 1, self.npos, c, E, cpe, E, R, st)
-        self.lin(reppe, E, self.wt["q2"], None, q2, E, R, E, E)
-        self.lin(cpe, E, self.wt["kvg2"], None, kvg2, 3 * E, R, E, 3 * E)
-        L.call("magpo_retention_chunk_fwd", q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, E, s0[2], seq_env, dones, st_2, None,
-               nseq, T, A, 1, self.kappa, st)
-        L.call("magpo_retpost_fwd", r2, E, kvg2[:, 2 * E:], 3 * E, v["dec.block0.retn2.gn.scale"], v["dec.block0.retn2.gn.bias"], u2, E, R, st)
-        self.lin(u2, E, self.wt["wo2"], None, y2, E, R, E, E)
-        L.call("magpo_resnorm_fwd", rep, E, y2, E, v["dec.block0.ln2.scale"], v["dec.block0.ln3.scale"], None, None, 0, 0, out, E,
-               None, 0, R, st)
-        self.lin(out, E, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, R, E, E)
+               g("za"), E, g("x0"), E, g("xpe0"), E, R, st)
+        for k in range(nb):
+            d = f"dec.block{k}."
+            x, xpe = g(f"x{k}"), g(f"xpe{k}")
+            qkvg1, r1, u1, y1 = g(f"qkvg1{k}", 4 * E), g(f"r1{k}"), g(f"u1{k}"), g(f"y1{k}")
+            c, cpe, q2, kvg2, r2, u2, y2 = g(f"c{k}"), g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
+            self.lin(xpe, E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
+            L.call("magpo_retention_chunk_fwd", qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, E, s0[1][k], seq_env, dones,
+                   stt(f"st_1{k}"), None, nseq, T, A, 1, self.kappa, st)
+            L.call("magpo_retpost_fwd", r1, E, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], u1, E, R, st)
+            self.lin(u1, E, self.wt[f"wo1{k}"], None, y1, E, R, E, E)
+            L.call("magpo_resnorm_fwd", x, E, y1, E, v[d + "ln1.scale"], None, self.pe, pos, 1, self.npos, c, E, cpe, E, R, st)
+            self.lin(reppe, E, self.wt[f"q2{k}"], None, q2, E, R, E, E)
+            self.lin(cpe, E, self.wt[f"kvg2{k}"], None, kvg2, 3 * E, R, E, 3 * E)
+            L.call("magpo_retention_chunk_fwd", q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, E, s0[2][k], seq_env, dones, stt(f"st_2{k}"), None,
+                   nseq, T, A, 1, self.kappa, st)
+            L.call("magpo_retpost_fwd", r2, E, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], u2, E, R, st)
+            self.lin(u2, E, self.wt[f"wo2{k}"], None, y2, E, R, E, E)
+            if k == nb - 1:
+                L.call("magpo_resnorm_fwd", rep, E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], None, None, 0, 0, g(f"x{nb}"), E,
+                       None, 0, R, st)
+            else:
+                L.call("magpo_resnorm_fwd", rep, E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], self.pe, pos, 1, self.npos,
+                       g(f"x{k + 1}"), E, g(f"xpe{k + 1}"), E, R, st)
+        hp, hn = g("hp"), g("hn")
+        self.lin(g(f"x{nb}"), E, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, R, E, E)
         L.call("magpo_headmid_fwd", hp, E, v["dec.head.norm.scale"], hn, E, None, None, None, 0, R, st)
         self.lin(hn, E, self.wt["h1"], v["dec.head.dense1.bias"], logits, E, R, E, K)
         return logits, value
 
     # ------------------------------------------------------------------ training backward
     def train_bwd(self, dlogits, dvalue):
-        """dlogits [R,64] (columns >= K zero), dvalue [R]; fills self.grads (every entry written once)."""
-        L, st, A, K, F, v, gv, b = self.L, self._st(), self.A, self.K, self.F, self.v, self.gv, self.b
+        """dlogits [R,64] (columns >= K zero), dvalue [R]; fills self.grads (every entry written exactly once, the
+        shared encoder ln scale accumulates over blocks)."""
+        L, st, A, K, F, v, gv, b, nb = self.L, self._st(), self.A, self.K, self.F, self.v, self.gv, self.b, self.nb
         sv = self._saved
         R, nseq, T = sv["R"], sv["nseq"], sv["T"]
         obs, prev_idx, pos, dones = sv["obs"], sv["prev_idx"], sv["pos"], sv["dones"]
-        t = lambda n, w=E: b.t["t_" + n]
+        t = lambda n: b.t["t_" + n]
         g = lambda n, w=E: b.get("g_" + n, (R, w))
         grid = L.call("magpo_row_grid", R)
         slab = lambda n, w=64: b.get("s_" + n, (grid, w))
@@ -263,49 +315,59 @@ class SableGuider:
         dhp = g("dhp_l")
         L.call("magpo_headmid_bwd", t("hp"), E, v["dec.head.norm.scale"], dhn, E, None, None, 0, dhp, E, slab("a"), None, None, R, st)
         self.reduce(slab("a"), gv["dec.head.norm.scale"])
-        self.wgrad(t("out"), E, dhp, E, R, E, E, gv["dec.head.dense0.kernel"], gv["dec.head.dense0.bias"])
+        self.wgrad(t(f"x{nb}"), E, dhp, E, R, E, E, gv["dec.head.dense0.kernel"], gv["dec.head.dense0.bias"])
         dout = g("dout")
         self.lin(dhp, E, v["dec.head.dense0.kernel"], None, dout, E, R, E, E)
-        # ---- decoder block tail: out = rms(rms(rep + y2) * ln2) * ln3
-        dsum2 = g("dsum2")
-        L.call("magpo_resnorm_bwd", t("rep"), E, t("y2"), E, v["dec.block0.ln2.scale"], v["dec.block0.ln3.scale"], dout, E, None, 0,
-               None, 0, dsum2, E, slab("a"), slab("b"), R, st)
-        self.reduce(slab("a"), gv["dec.block0.ln2.scale"]); self.reduce(slab("b"), gv["dec.block0.ln3.scale"])
-        self.wgrad(t("u2"), E, dsum2, E, R, E, E, gv["dec.block0.retn2.w_o"])
-        du2 = g("du")
-        self.lin(dsum2, E, v["dec.block0.retn2.w_o"], None, du2, E, R, E, E)
-        dr2 = g("dr"); dq2 = g("dq2"); dkvg2 = g("dkvg2", 3 * E)
-        L.call("magpo_retpost_bwd", t("r2"), E, t("kvg2")[:, 2 * E:], 3 * E, v["dec.block0.retn2.gn.scale"], v["dec.block0.retn2.gn.bias"],
-               du2, E, dr2, E, dkvg2[:, 2 * E:], 3 * E, slab("a"), slab("b"), R, st)
-        self.reduce(slab("a"), gv["dec.block0.retn2.gn.scale"]); self.reduce(slab("b"), gv["dec.block0.retn2.gn.bias"])
-        kvg2 = t("kvg2")
-        L.call("magpo_retention_chunk_bwd", t("q2"), E, kvg2, 3 * E, kvg2[:, E:], 3 * E, dr2, E, dq2, E, dkvg2, 3 * E, dkvg2[:, E:], 3 * E,
-               dones, b.t["t_st_2"], nseq, T, A, 1, self.kappa, st)
-        self.wgrad(t("reppe"), E, dq2, E, R, E, E, gv["dec.block0.retn2.w_q"])
-        self.wgrad(t("cpe"), E, dkvg2, 3 * E, R, E, 3 * E, gv["dec.block0.retn2.w_kvg"])
-        dreppe = g("dreppe"); dcpe = g("dcpe")
-        self.lin(dq2, E, v["dec.block0.retn2.w_q"], None, dreppe, E, R, E, E)
-        self.lin(dkvg2, 3 * E, v["dec.block0.retn2.w_kvg"], None, dcpe, E, R, 3 * E, E)
-        # ---- decoder self-retention: c = rms(xa + y1) * ln1
-        dsum1 = g("dsum1")
-        L.call("magpo_resnorm_bwd", t("xa"), E, t("y1"), E, v["dec.block0.ln1.scale"], None, dcpe, E, None, 0, None, 0, dsum1, E,
-               slab("a"), None, R, st)
-        self.reduce(slab("a"), gv["dec.block0.ln1.scale"])
-        self.wgrad(t("u1"), E, dsum1, E, R, E, E, gv["dec.block0.retn1.w_o"])
-        du1 = g("du")
-        self.lin(dsum1, E, v["dec.block0.retn1.w_o"], None, du1, E, R, E, E)
-        dr1 = g("dr"); dqkvg1 = g("dqkvg1", 4 * E)
-        qkvg1 = t("qkvg1")
-        L.call("magpo_retpost_bwd", t("r1"), E, qkvg1[:, 3 * E:], 4 * E, v["dec.block0.retn1.gn.scale"], v["dec.block0.retn1.gn.bias"],
-               du1, E, dr1, E, dqkvg1[:, 3 * E:], 4 * E, slab("a"), slab("b"), R, st)
-        self.reduce(slab("a"), gv["dec.block0.retn1.gn.scale"]); self.reduce(slab("b"), gv["dec.block0.retn1.gn.bias"])
-        L.call("magpo_retention_chunk_bwd", qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, dr1, E, dqkvg1, 4 * E,
-               dqkvg1[:, E:], 4 * E, dqkvg1[:, 2 * E:], 4 * E, dones, b.t["t_st_1"], nseq, T, A, 1, self.kappa, st)
-        self.wgrad(t("kin1"), E, dqkvg1, 4 * E, R, E, 4 * E, gv["dec.block0.retn1.w_qkvg"])
-        dkin1 = g("dkin")
-        self.lin(dqkvg1, 4 * E, v["dec.block0.retn1.w_qkvg"], None, dkin1, E, R, 4 * E, E)
+        # ---- decoder blocks, last to first.  incoming gradient of block k's output x_{k+1}: (din0 [+ din1])
+        din0, din1 = dout, None
+        drep_q, drep_r = None, None      # running sums of d(obs_rep): cross-retention query path / residual path
+        for k in reversed(range(nb)):
+            d = f"dec.block{k}."
+            dsum2 = g(f"dsum2_{k}")
+            L.call("magpo_resnorm_bwd", t("rep"), E, t(f"y2{k}"), E, v[d + "ln2.scale"], v[d + "ln3.scale"], din0, E, din1, E if din1 is not None else 0,
+                   None, 0, dsum2, E, slab("a"), slab("b"), R, st)
+            self.reduce(slab("a"), gv[d + "ln2.scale"]); self.reduce(slab("b"), gv[d + "ln3.scale"])
+            self.wgrad(t(f"u2{k}"), E, dsum2, E, R, E, E, gv[d + "retn2.w_o"])
+            du2 = g("du")
+            self.lin(dsum2, E, v[d + "retn2.w_o"], None, du2, E, R, E, E)
+            dr2 = g("dr"); dq2 = g(f"dq2_{k}"); dkvg2 = g(f"dkvg2_{k}", 3 * E)
+            kvg2 = t(f"kvg2{k}")
+            L.call("magpo_retpost_bwd", t(f"r2{k}"), E, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
+                   du2, E, dr2, E, dkvg2[:, 2 * E:], 3 * E, slab("a"), slab("b"), R, st)
+            self.reduce(slab("a"), gv[d + "retn2.gn.scale"]); self.reduce(slab("b"), gv[d + "retn2.gn.bias"])
+            L.call("magpo_retention_chunk_bwd", t(f"q2{k}"), E, kvg2, 3 * E, kvg2[:, E:], 3 * E, dr2, E, dq2, E, dkvg2, 3 * E, dkvg2[:, E:], 3 * E,
+                   dones, b.t[f"t_st_2{k}"], nseq, T, A, 1, self.kappa, st)
+            self.wgrad(t("reppe"), E, dq2, E, R, E, E, gv[d + "retn2.w_q"])
+            self.wgrad(t(f"cpe{k}"), E, dkvg2, 3 * E, R, E, 3 * E, gv[d + "retn2.w_kvg"])
+            dreppe = g(f"dreppe_{k}"); dcpe = g("dcpe")
+            self.lin(dq2, E, v[d + "retn2.w_q"], None, dreppe, E, R, E, E)
+            self.lin(dkvg2, 3 * E, v[d + "retn2.w_kvg"], None, dcpe, E, R, 3 * E, E)
+            if drep_q is None:
+                drep_q, drep_r = dreppe, dsum2
+            else:
+                self.add_(drep_q, dreppe); self.add_(drep_r, dsum2)
+            # self-retention: c = rms(x_k + y1) * ln1
+            dsum1 = g(f"dsum1_{k}")
+            L.call("magpo_resnorm_bwd", t(f"x{k}"), E, t(f"y1{k}"), E, v[d + "ln1.scale"], None, dcpe, E, None, 0, None, 0, dsum1, E,
+                   slab("a"), None, R, st)
+            self.reduce(slab("a"), gv[d + "ln1.scale"])
+            self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
+            du1 = g("du")
+            self.lin(dsum1, E, v[d + "retn1.w_o"], None, du1, E, R, E, E)
+            dr1 = g("dr"); dqkvg1 = g(f"dqkvg1_{k}", 4 * E)
+            qkvg1 = t(f"qkvg1{k}")
+            L.call("magpo_retpost_bwd", t(f"r1{k}"), E, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"],
+                   du1, E, dr1, E, dqkvg1[:, 3 * E:], 4 * E, slab("a"), slab("b"), R, st)
+            self.reduce(slab("a"), gv[d + "retn1.gn.scale"]); self.reduce(slab("b"), gv[d + "retn1.gn.bias"])
+            L.call("magpo_retention_chunk_bwd", qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, dr1, E, dqkvg1, 4 * E,
+                   dqkvg1[:, E:], 4 * E, dqkvg1[:, 2 * E:], 4 * E, dones, b.t[f"t_st_1{k}"], nseq, T, A, 1, self.kappa, st)
+            self.wgrad(t(f"xpe{k}"), E, dqkvg1, 4 * E, R, E, 4 * E, gv[d + "retn1.w_qkvg"])
+            dkin1 = g(f"dkin1_{k}")
+            self.lin(dqkvg1, 4 * E, v[d + "retn1.w_qkvg"], None, dkin1, E, R, 4 * E, E)
+            din0, din1 = dsum1, dkin1      # gradient of x_k (block input): residual path + key/query/value path
         dza = g("dz")
-        L.call("magpo_embed_bwd", 1, t("za"), E, dsum1, E, dkin1, E, None, 0, v["dec.ln.scale"], dza, E, slab("a"), slab("w", 32 * E),
+        za = t("za")
+        L.call("magpo_embed_bwd", 1, za, E, din0, E, din1, E, None, 0, v["dec.ln.scale"], dza, E, slab("a"), slab("w", 32 * E),
                K + 1, None, 0, 0, None, None, None, prev_idx, 1, R, st)
         self.reduce(slab("a"), gv["dec.ln.scale"])
         self.reduce(slab("w", 32 * E), gv["dec.act.kernel"], P=(K + 1) * E, stride=32 * E)
@@ -318,29 +380,42 @@ class SableGuider:
         self.wgrad(t("rep"), E, dhv, E, R, E, E, gv["enc.head.dense0.kernel"], gv["enc.head.dense0.bias"])
         drep_v = g("dout")
         self.lin(dhv, E, v["enc.head.dense0.kernel"], None, drep_v, E, R, E, E)
-        # ---- encoder block: rep = rms(rms(xn + y) * ln1) * ln2 ; d(rep) = value head + cross-retention query + decoder residual
-        dsum0 = g("dsum0")
-        L.call("magpo_resnorm_bwd", t("xn"), E, t("y"), E, v["enc.block0.ln1.scale"], v["enc.block0.ln2.scale"], drep_v, E, dreppe, E,
-               dsum2, E, dsum0, E, slab("a"), slab("b"), R, st)
-        self.reduce(slab("a"), gv["enc.block0.ln1.scale"]); self.reduce(slab("b"), gv["enc.block0.ln2.scale"])
-        self.wgrad(t("u"), E, dsum0, E, R, E, E, gv["enc.block0.retn.w_o"])
-        du = g("du")
-        self.lin(dsum0, E, v["enc.block0.retn.w_o"], None, du, E, R, E, E)
-        dr = g("dr"); dqkvg = g("dqkvg", 4 * E)
-        qkvg = t("qkvg")
-        L.call("magpo_retpost_bwd", t("r"), E, qkvg[:, 3 * E:], 4 * E, v["enc.block0.retn.gn.scale"], v["enc.block0.retn.gn.bias"], du, E,
-               dr, E, dqkvg[:, 3 * E:], 4 * E, slab("a"), slab("b"), R, st)
-        self.reduce(slab("a"), gv["enc.block0.retn.gn.scale"]); self.reduce(slab("b"), gv["enc.block0.retn.gn.bias"])
-        L.call("magpo_retention_chunk_bwd", qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, dr, E, dqkvg, 4 * E, dqkvg[:, E:], 4 * E,
-               dqkvg[:, 2 * E:], 4 * E, dones, b.t["t_st_e"], nseq, T, A, 0, self.kappa, st)
-        self.wgrad(t("kin"), E, dqkvg, 4 * E, R, E, 4 * E, gv["enc.block0.retn.w_qkvg"])
-        dkin = g("dkin")
-        self.lin(dqkvg, 4 * E, v["enc.block0.retn.w_qkvg"], None, dkin, E, R, 4 * E, E)
-        dz = g("dz")
-        L.call("magpo_embed_bwd", 0, t("z"), E, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], dz, E, slab("a"), slab("w", 32 * E), F,
-               obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, st)
-        self.reduce(slab("a"), gv["enc.ln.scale"])
-        self.reduce(slab("d", 32), gv["enc.obs.norm.scale"], P=F, stride=32)
-        self.reduce(slab("w", 32 * E), gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)
+        # ---- encoder blocks, last to first; d(rep) = value head + cross-retention queries + decoder residuals
+        e0, e1, e2 = drep_v, drep_q, drep_r
+        first_ln = True
+        for k in reversed(range(nb)):
+            e = f"enc.block{k}."
+            dsum0 = g(f"dsum0_{k}")
+            L.call("magpo_resnorm_bwd", t(f"xn{k}"), E, t(f"y{k}"), E, v[e + "ln1.scale"], v[e + "ln2.scale"], e0, E, e1, E if e1 is not None else 0,
+                   e2, E if e2 is not None else 0, dsum0, E, slab("a"), slab("b"), R, st)
+            self.reduce(slab("a"), gv[e + "ln1.scale"]); self.reduce(slab("b"), gv[e + "ln2.scale"])
+            self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
+            du = g("du")
+            self.lin(dsum0, E, v[e + "retn.w_o"], None, du, E, R, E, E)
+            dr = g("dr"); dqkvg = g(f"dqkvg_{k}", 4 * E)
+            qkvg = t(f"qkvg{k}")
+            L.call("magpo_retpost_bwd", t(f"r{k}"), E, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], du, E,
+                   dr, E, dqkvg[:, 3 * E:], 4 * E, slab("a"), slab("b"), R, st)
+            self.reduce(slab("a"), gv[e + "retn.gn.scale"]); self.reduce(slab("b"), gv[e + "retn.gn.bias"])
+            L.call("magpo_retention_chunk_bwd", qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, dr, E, dqkvg, 4 * E, dqkvg[:, E:], 4 * E,
+                   dqkvg[:, 2 * E:], 4 * E, dones, b.t[f"t_st_e{k}"], nseq, T, A, 0, self.kappa, st)
+            self.wgrad(t(f"kin{k}"), E, dqkvg, 4 * E, R, E, 4 * E, gv[e + "retn.w_qkvg"])
+            dkin = g(f"dkin_{k}")
+            self.lin(dqkvg, 4 * E, v[e + "retn.w_qkvg"], None, dkin, E, R, 4 * E, E)
+            if k > 0:  # xn_k = rms(rep_{k-1}) * enc.ln (shared scale): d(rep_{k-1})
+                drepb = g(f"drepb_{k}")
+                L.call("magpo_resnorm_bwd", t(f"repb{k - 1}"), E, None, 0, v["enc.ln.scale"], None, dsum0, E, dkin, E, None, 0, drepb, E,
+                       slab("a"), None, R, st)
+                self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
+                first_ln = False
+                e0, e1, e2 = drepb, None, None
+            else:
+                dz = g("dz")
+                z = t("z")
+                L.call("magpo_embed_bwd", 0, z, E, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], dz, E, slab("a"), slab("w", 32 * E), F,
+                       obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, st)
+                self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
+                self.reduce(slab("d", 32), gv["enc.obs.norm.scale"], P=F, stride=32)
+                self.reduce(slab("w", 32 * E), gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)
         if self.overlap_wgrad and self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
