@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (weak scaling)")
+    ap.add_argument("--workload", default="coordsum-4ag", choices=["coordsum-4ag", "coordsum-8x15"],
+                    help="coordsum-4ag = BASELINE.json configs[1] (headline); coordsum-8x15 = configs[4] per GPU (registered 8x15-100, n_block=2, 8 minibatches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (+3 %%; kernel timings then include contention)")
@@ -192,10 +194,16 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    sysc = SystemConfig()  # reference defaults (configs/system/gpo/rec_magpo.yaml)
-    env_cfg = CoordSumConfig(num_agents=4, num_actions=20, time_limit=100, maxval=60)
     N = args.num_envs
-    learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0)  # same seed => replicated parameters on every rank
+    if args.workload == "coordsum-8x15":
+        sysc = SystemConfig(num_minibatches=8)  # 8 agents: 8 minibatches (as the tuned run) keep R = mb*T*A at 2.1 M rows
+        env_cfg = CoordSumConfig(num_agents=8, num_actions=15, time_limit=100, maxval=100)
+        n_block = 2
+    else:
+        sysc = SystemConfig()  # reference defaults (configs/system/gpo/rec_magpo.yaml)
+        env_cfg = CoordSumConfig(num_agents=4, num_actions=20, time_limit=100, maxval=60)
+        n_block = 1
+    learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0, n_block=n_block)  # same seed => replicated parameters on every rank
     key = host_split(prng_key(42), 4)[0]
     learner.setup(key, n_groups=world, group=rank)
     if args.overlap:
@@ -253,7 +261,7 @@ def main():
         roof, table = timer.dominant()
         env_steps = world * N * sysc.rollout_length * args.steps
         out = {
-            "metric": "env-steps/sec (all agents stepping jointly), CoordSum-4ag, full MAGPO update loop",
+            "metric": f"env-steps/sec (all agents stepping jointly), CoordSum-{env_cfg.num_agents}ag, full MAGPO update loop",
             "value": round(env_steps / elapsed, 1),
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -265,8 +273,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (fixed-seed CoordSum episodes, random-init networks)",
-            "config": {"workload": f"CoordSum 4-agent (num_actions=20, maxval=60, time_limit=100), {N} envs/GPU x {world} GPU, "
-                                   "rollout_length=128, ppo_epochs=4, num_minibatches=2, Sable embed 64 / 1 head / 1 block, GRU 128",
+            "config": {"workload": f"CoordSum {env_cfg.num_agents}-agent (num_actions={env_cfg.num_actions}, maxval={env_cfg.maxval}, "
+                                   f"time_limit=100), {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
+                                   f"num_minibatches={sysc.num_minibatches}, Sable embed 64 / 1 head / {n_block} block, GRU 128",
                        "agent_steps_per_s": round(env_steps * env_cfg.num_agents / elapsed, 1),
                        "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},
             "roofline": roof,

@@ -29,6 +29,7 @@ from magpo_amd.evaluator import get_eval_fn, get_num_eval_envs, make_rec_eval_ac
 from magpo_amd.learner import MagpoLearner, SystemConfig, host_split, prng_key
 from magpo_amd.types import ExperimentOutput, GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
 from magpo_amd.utils import make_env as environments
+from magpo_amd.utils.checkpointing import Checkpointer
 from magpo_amd.utils.config import check_total_timesteps
 from magpo_amd.utils.logger import LogEvent, MavaLogger
 
@@ -92,10 +93,14 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
     key, actor_net_key, net_key = keys
     config.system.num_agents = env.num_agents
     nc, mc = config.network.net_config, config.network.memory_config
+    # memory_config.timestep_chunk_size only changes HOW the reference evaluates the chunkwise retention (smaller chunks with a
+    # carried state, rec_magpo.py:552-557); the function is the same for every chunk size (recurrent == chunkwise, tested in
+    # tests/test_oracle_networks.py).  The HIP kernel always walks 64-token tiles with the state on chip, so the key is honoured
+    # as a pure memory/speed knob with no effect here.
     if mc.timestep_chunk_size:
-        raise NotImplementedError("timestep_chunk_size: the HIP path evaluates the rollout as one chunk (chunked state hand-off "
-                                  "inside the kernel); set memory_config.timestep_chunk_size=~")
-    mc.chunk_size = config.system.rollout_length * env.num_agents
+        mc.chunk_size = int(mc.timestep_chunk_size) * env.num_agents
+    else:
+        mc.chunk_size = config.system.rollout_length * env.num_agents
     if mc.type != "rec_sable":
         raise NotImplementedError("memory_config.type must be rec_sable")
     if int(nc.embed_dim) != 64 or int(nc.n_head) != 1 or int(config.network.hidden_state_dim) != 128:
@@ -137,6 +142,10 @@ def run_experiment(_config) -> float:
     steps_per_rollout = (n_devices * config.system.num_updates_per_eval * config.system.rollout_length
                          * config.system.update_batch_size * config.arch.num_envs)
     logger = MavaLogger(config) if rank == 0 else None
+    save_checkpoint = bool(config.logger.checkpointing.save_model) and rank == 0
+    if save_checkpoint:
+        checkpointer = Checkpointer(metadata=config.to_container(), model_name=config.logger.system_name,
+                                    base_path=config.logger.base_exp_path, **config.logger.checkpointing.save_args.to_container())
     eval_batch = get_num_eval_envs(config, absolute_metric=False, n_devices=n_devices)
     eval_hs = {"hidden_state": torch.zeros(eval_batch * env.num_agents, 128, device=device)}
 
@@ -166,6 +175,8 @@ def run_experiment(_config) -> float:
         if logger:
             logger.log(eval_metrics, t, eval_step, LogEvent.EVAL)
         episode_return = float(np.mean(eval_metrics["episode_return"]))
+        if save_checkpoint:  # rec_magpo.py:779-785
+            checkpointer.save(timestep=t, unreplicated_learner_state=learner_output.learner_state, episode_return=episode_return)
         if config.arch.absolute_metric and max_episode_return <= episode_return:
             best_params = {k: v.clone() for k, v in trained_params.items()}
             max_episode_return = episode_return

@@ -15,13 +15,18 @@ def test_run_experiment_small(tmp_path):
     cfg = compose("rec_magpo", ["env=coordsum", "env/scenario=3x10-30", "arch.num_envs=8", "arch.num_evaluation=2",
                                 "arch.num_eval_episodes=8", "arch.num_absolute_metric_eval_episodes=16", "system.total_timesteps=~",
                                 "system.num_updates=4", "system.rollout_length=16", "system.ppo_epochs=2", "env.kwargs.time_limit=10",
-                                "logger.loggers.json.enabled=True", f"logger.base_exp_path={tmp_path}/", "logger.loggers.json.path=run"])
+                                "logger.loggers.json.enabled=True", f"logger.base_exp_path={tmp_path}/", "logger.loggers.json.path=run",
+                                "logger.checkpointing.save_model=True", "network.memory_config.timestep_chunk_size=4",
+                                "network.net_config.n_block=2"])
     perf = rec_magpo.run_experiment(cfg)
     assert np.isfinite(perf) and 0.0 <= perf <= 20.0
     data = json.load(open(os.path.join(tmp_path, "json", "run", "metrics.json")))
     run = data["CoordSum"]["3x10-30-v0"]["rec_magpo"]["seed_42"]
     assert "step_0" in run and "step_1" in run and "absolute_metrics" in run
     assert "mean_episode_return" in run["step_0"] and "steps_per_second" in run["step_0"]
+    ckdir = os.path.join(tmp_path, "checkpoints", "rec_magpo")
+    pts = [f for d in os.listdir(ckdir) for f in os.listdir(os.path.join(ckdir, d)) if f.endswith(".pt")]
+    assert len(pts) == 1  # max_to_keep: 1
 
 
 def test_two_groups_share_parameters_and_average_gradients():

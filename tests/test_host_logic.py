@@ -125,3 +125,20 @@ def test_grad_sync_world2_gloo():
 def test_make_grad_sync_single_group_is_none():
     from magpo_amd import distributed as mdist
     assert mdist.make_grad_sync(1) is None
+
+
+def test_checkpointer_keeps_best(tmp_path):
+    from magpo_amd.types import GPOLearnerState, OptStates, Params
+    from magpo_amd.utils.checkpointing import Checkpointer
+    ck = Checkpointer("rec_magpo", metadata={"a": 1}, base_path=str(tmp_path), max_to_keep=1, checkpoint_uid="u")
+    mk = lambda v: GPOLearnerState(Params({"w": torch.full((3,), float(v))}, {"k": torch.zeros(2)}),
+                                   OptStates(dict(count=1, mu=torch.zeros(3), nu=torch.zeros(3)), dict(count=1, mu=torch.zeros(2), nu=torch.zeros(2))),
+                                   np.array([1, 2], np.uint32), [], [], torch.zeros(1), None)
+    ck.save(100, mk(1), episode_return=5.0)
+    ck.save(200, mk(2), episode_return=9.0)
+    ck.save(300, mk(3), episode_return=7.0)
+    files = sorted(f for f in os.listdir(os.path.join(tmp_path, "checkpoints", "rec_magpo", "u")) if f.endswith(".pt"))
+    assert files == ["200.pt"]
+    st = torch.load(os.path.join(tmp_path, "checkpoints", "rec_magpo", "u", "200.pt"), weights_only=False)
+    assert st["episode_return"] == 9.0 and float(st["learner_state"]["params"]["guider_params"]["w"][0]) == 2.0
+    assert json.load(open(os.path.join(tmp_path, "checkpoints", "rec_magpo", "u", "metadata.json")))["checkpointer_version"] == 2.0
