@@ -126,7 +126,7 @@ class KernelTimer:
                 pmc = json.load(f)
             name = {"wgrad<2>": "k_wgrad<2>", "wgrad<1>": "k_wgrad<1>", "ret_chunk_bwd": "k_ret_chunk_bwd", "ret_chunk_fwd": "k_ret_chunk_fwd",
                     "gru_scan_fwd": "k_gru_scan_fwd", "gru_scan_bwd": "k_gru_scan_bwd"}.get(key)
-            if name in pmc:
+            if name in pmc and getattr(self, "attach_traffic", True):
                 roof["traffic"] = round(pmc[name]["total"])
         except (OSError, ValueError):
             pass
@@ -239,6 +239,7 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
     timer = KernelTimer(min_rows=1 << 16)
+    timer.attach_traffic = args.workload == "coordsum-4ag" and N == 16384  # the PMC passes were taken on that workload
     if not args.no_kernel_timing and rank == 0:
         lib().timer = timer
         timer.enabled = True

@@ -75,10 +75,10 @@ int magpo_small_relu_wgrad(const float* X, int ldx, int F, const float* Yact, co
 int magpo_small_operand(int mode, const float* obs, int ldo, int F, const float* s_obs, const int* idx,
                         int idx_stride, float* out, long R, magpo_stream_t stream);
 int magpo_retpost_fwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
-                      float* u, int ldu, long R, magpo_stream_t stream);
+                      float* u, int ldu, long R, int hs, int gs, magpo_stream_t stream);
 int magpo_retpost_bwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
                       const float* du, int lddu, float* dr, int lddr, float* dgp, int lddg, float* slab_gamma,
-                      float* slab_beta, long R, magpo_stream_t stream);
+                      float* slab_beta, long R, int hs, int gs, magpo_stream_t stream);
 int magpo_resnorm_fwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
                       const float* pe, const int* pos, int pos_stride, int npos, float* out, int ldout,
                       float* outpe, int ldoutpe, long R, magpo_stream_t stream);
@@ -98,15 +98,15 @@ int magpo_retention_num_chunks(int T, int A);
 int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               float* r, long ldr, const float* s0, const int* seq_env,
                               const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
-                              int masked, float kappa, magpo_stream_t stream);
+                              int masked, float kappa, int hs, magpo_stream_t stream);
 int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
                               long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
-                              int masked, float kappa, magpo_stream_t stream);
+                              int masked, float kappa, int hs, magpo_stream_t stream);
 int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
                               int write_state, const float* gp, long ldg, const float* gamma, const float* beta,
-                              magpo_stream_t stream);
+                              int hs, int gs, magpo_stream_t stream);
 int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned char* done, int nenv,
                                  magpo_stream_t stream);
 

@@ -28,12 +28,12 @@ struct ChunkMeta {      // per-chunk decay bookkeeping in LDS
   float gamma;          // state carry factor
 };
 
-__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, long ld, int nvalid) {
-  // 64 rows x 64 floats, rows >= nvalid zero-filled
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, long ld, int nvalid, int w4 = 16) {
+  // 64 rows x 64 floats, rows >= nvalid and columns >= 4*w4 (head width) zero-filled
   for (int i = threadIdx.x; i < 64 * 16; i += 256) {
     int r = i >> 4, c4 = i & 15;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
+    if (r < nvalid && c4 < w4) v = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
     *reinterpret_cast<float4*>(&dst[r * TL + 4 * c4]) = v;
   }
 }
@@ -53,13 +53,13 @@ __device__ __forceinline__ void store_state(float* __restrict__ dst, const float
 
 // register staging of a 64x64 tile (4 float4 per thread): fetch from HBM now, stash into LDS one chunk later
 struct TileRegs { float4 v[4]; };
-__device__ __forceinline__ void fetch_tile(TileRegs& t, const float* __restrict__ src, long ld, int nvalid) {
+__device__ __forceinline__ void fetch_tile(TileRegs& t, const float* __restrict__ src, long ld, int nvalid, int w4) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = threadIdx.x + 256 * j;
     const int r = i >> 4, c4 = i & 15;
     t.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nvalid) t.v[j] = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
+    if (r < nvalid && c4 < w4) t.v[j] = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
   }
 }
 __device__ __forceinline__ void fetch_state(TileRegs& t, const float* __restrict__ src) {
@@ -178,7 +178,7 @@ struct RetArgs {
   const unsigned char* dones; // [nseq][T]
   float* states;              // [nseq][nch][64][64] chunk-entry states (nullable in fwd)
   float* s_final;             // [nseq][64][64] state after the last chunk (nullable)
-  int T, A, masked; float kappa;
+  int T, A, masked; float kappa; int hs;   // hs = head width (<= 64): tiles are zero-padded to 64 columns on chip
 };
 
 __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
@@ -195,13 +195,14 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
   const int nch = (a.T + Lt - 1) / Lt;
   const long row_base = (long)seq * a.T * a.A;
   const float* s0 = a.s0 ? a.s0 + (long)(a.seq_env ? a.seq_env[seq] : seq) * 4096 : nullptr;
+  const int w4 = a.hs >> 2;
   load_state(Ss, s0);
   TileRegs pq, pk, pv;
   {
     const int nv0 = min(Lt, a.T) * a.A;
-    fetch_tile(pq, a.q + row_base * a.ldq, a.ldq, nv0);
-    fetch_tile(pk, a.k + row_base * a.ldk, a.ldk, nv0);
-    fetch_tile(pv, a.v + row_base * a.ldv, a.ldv, nv0);
+    fetch_tile(pq, a.q + row_base * a.ldq, a.ldq, nv0, w4);
+    fetch_tile(pk, a.k + row_base * a.ldk, a.ldk, nv0, w4);
+    fetch_tile(pv, a.v + row_base * a.ldv, a.ldv, nv0, w4);
   }
   for (int c = 0; c < nch; ++c) {
     const int t0 = c * Lt;
@@ -216,9 +217,9 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
     if (c + 1 < nch) {  // next chunk's tiles are in flight while this chunk's GEMMs run
       const int nvn = min(Lt, a.T - (t0 + Lt)) * a.A;
       const long rn = r0 + L;
-      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn);
-      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn);
-      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn);
+      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
+      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
+      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
     }
     if (a.states) store_state(a.states + ((long)seq * nch + c) * 4096, Ss);
 
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ri = 32 * wr + acc_row(i, h);
-      if (ri < nvalid) a.r[(r0 + ri) * a.ldr + 32 * wc + lr] = o[i];
+      if (ri < nvalid && 32 * wc + lr < a.hs) a.r[(r0 + ri) * a.ldr + 32 * wc + lr] = o[i];
     }
     // state update  S <- gamma S + (eta K)^T V
     f32x16 sn;
@@ -272,7 +273,7 @@ struct RetBwdArgs {
   float* dq; float* dk; float* dv; long lddq, lddk, lddv;
   const unsigned char* dones;
   const float* states;  // [nseq][nch][64][64] from the forward
-  int T, A, masked; float kappa;
+  int T, A, masked; float kappa; int hs;
 };
 
 __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
@@ -292,16 +293,17 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
   const int Lt = 64 / a.A, L = Lt * a.A;
   const int nch = (a.T + Lt - 1) / Lt;
   const long row_base = (long)seq * a.T * a.A;
+  const int w4 = a.hs >> 2;
   load_state(Gs, nullptr);
   TileRegs pq, pk, pv, pd, ps;
   {
     const int cl = nch - 1;
     const int nvl = min(Lt, a.T - cl * Lt) * a.A;
     const long rl = row_base + (long)cl * L;
-    fetch_tile(pq, a.q + rl * a.ldq, a.ldq, nvl);
-    fetch_tile(pk, a.k + rl * a.ldk, a.ldk, nvl);
-    fetch_tile(pv, a.v + rl * a.ldv, a.ldv, nvl);
-    fetch_tile(pd, a.dr + rl * a.lddr, a.lddr, nvl);
+    fetch_tile(pq, a.q + rl * a.ldq, a.ldq, nvl, w4);
+    fetch_tile(pk, a.k + rl * a.ldk, a.ldk, nvl, w4);
+    fetch_tile(pv, a.v + rl * a.ldv, a.ldv, nvl, w4);
+    fetch_tile(pd, a.dr + rl * a.lddr, a.lddr, nvl, w4);
     fetch_state(ps, a.states + ((long)seq * nch + cl) * 4096);
   }
   for (int c = nch - 1; c >= 0; --c) {
@@ -318,10 +320,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
     build_meta(meta, a.dones + (long)seq * a.T, t0, ltc, a.A, a.kappa);
     if (c > 0) {  // previous chunk (next in the reverse sweep): loads in flight during the 9 GEMMs below
       const long rn = r0 - L;
-      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, L);
-      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, L);
-      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, L);
-      fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, L);
+      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, L, w4);
+      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, L, w4);
+      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, L, w4);
+      fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, L, w4);
       fetch_state(ps, a.states + ((long)seq * nch + c - 1) * 4096);
     }
 
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ri = 32 * wr + acc_row(i, h);
-        if (ri < nvalid) a.dq[(r0 + ri) * a.lddq + 32 * wc + lr] = acc1[i] + meta.beta[ri] * acc2[i];
+        if (ri < nvalid && 32 * wc + lr < a.hs) a.dq[(r0 + ri) * a.lddq + 32 * wc + lr] = acc1[i] + meta.beta[ri] * acc2[i];
       }
     }
     // dK = dP^T Q + eta * (V G^T)
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ri = 32 * wr + acc_row(i, h);
-        if (ri < nvalid) a.dk[(r0 + ri) * a.lddk + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
+        if (ri < nvalid && 32 * wc + lr < a.hs) a.dk[(r0 + ri) * a.lddk + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
       }
     }
     // dV = P^T dO + eta * (K G)
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ri = 32 * wr + acc_row(i, h);
-        if (ri < nvalid) a.dv[(r0 + ri) * a.lddv + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
+        if (ri < nvalid && 32 * wc + lr < a.hs) a.dv[(r0 + ri) * a.lddv + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
       }
     }
     // G <- gamma G + (beta Q)^T dO
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void k_ret_recurrent(float* __restrict__ S, co
                                                        const float* __restrict__ v, long ldq, long ldk, long ldv, long env_stride_rows,
                                                        float* __restrict__ r, long ldr, int ntok, int ret_from, float decay,
                                                        int write_state, const float* __restrict__ gp, long ldg,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta) {
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int hs, int gs) {
   // thread -> 4 state columns (c4..c4+3) x 4 state rows (rw, rw+16, rw+32, rw+48): float4 accesses, a wave
   // touches 4 consecutive 256-B rows (1 KiB contiguous) per instruction.
   __shared__ __align__(16) float qs[16][64], ks[16][64], vs[16][64];
@@ -426,11 +428,13 @@ __global__ __launch_bounds__(256) void k_ret_recurrent(float* __restrict__ S, co
   float4 s[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) s[i] = *reinterpret_cast<const float4*>(Se + (rw + 16 * i) * 64 + c4);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = tid; i < ntok * 16; i += 256) {
     const int a = i >> 4, cc = 4 * (i & 15);
-    if (a >= ret_from) *reinterpret_cast<float4*>(&qs[a][cc]) = *reinterpret_cast<const float4*>(q + (row0 + a) * ldq + cc);
-    *reinterpret_cast<float4*>(&ks[a][cc]) = *reinterpret_cast<const float4*>(k + (row0 + a) * ldk + cc);
-    *reinterpret_cast<float4*>(&vs[a][cc]) = *reinterpret_cast<const float4*>(v + (row0 + a) * ldv + cc);
+    const bool in = cc < hs;  // head width: columns beyond it are zero (state padded to 64 x 64)
+    if (a >= ret_from) *reinterpret_cast<float4*>(&qs[a][cc]) = in ? *reinterpret_cast<const float4*>(q + (row0 + a) * ldq + cc) : z4;
+    *reinterpret_cast<float4*>(&ks[a][cc]) = in ? *reinterpret_cast<const float4*>(k + (row0 + a) * ldk + cc) : z4;
+    *reinterpret_cast<float4*>(&vs[a][cc]) = in ? *reinterpret_cast<const float4*>(v + (row0 + a) * ldv + cc) : z4;
   }
   __syncthreads();
 #pragma unroll
@@ -465,17 +469,21 @@ __global__ __launch_bounds__(256) void k_ret_recurrent(float* __restrict__ S, co
   if (!gp) {
     for (int i = tid; i < (ntok - ret_from) * 64; i += 256) {
       int a = ret_from + (i >> 6), c = i & 63;
-      r[(row0 + a) * ldr + c] = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
+      if (c < hs) r[(row0 + a) * ldr + c] = (part[0][a][c] + part[1][a][c]) + (part[2][a][c] + part[3][a][c]);
     }
   } else {
-    // fused retention epilogue (retention.py:289-294): u = swish(gpre) * GroupNorm(ret); one wave per token
+    // fused retention epilogue (retention.py:289-294): u = swish(gpre) * GroupNorm(ret); one wave per token.
+    // flax GroupNorm(num_groups = n_head) on the (token*head, hs) rows: statistics over groups of gs = hs / n_head channels.
     for (int a = ret_from + wave; a < ntok; a += 4) {
       const float x = (part[0][a][lane] + part[1][a][lane]) + (part[2][a][lane] + part[3][a][lane]);
-      const float mu = wave_sum(x) * (1.0f / 64.0f);
-      const float m2 = wave_sum(x * x) * (1.0f / 64.0f);
+      float s1 = x, s2 = x * x;
+      for (int o = gs >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      const float mu = s1 / (float)gs, m2 = s2 / (float)gs;
       const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + 1e-6f);
-      const float rn = (x - mu) * rstd * gamma[lane] + beta[lane];
-      r[(row0 + a) * ldr + lane] = swishf_(gp[(row0 + a) * ldg + lane]) * rn;
+      if (lane < hs) {
+        const float rn = (x - mu) * rstd * gamma[lane] + beta[lane];
+        r[(row0 + a) * ldr + lane] = swishf_(gp[(row0 + a) * ldg + lane]) * rn;
+      }
     }
   }
 }
@@ -507,9 +515,10 @@ extern "C" int magpo_retention_num_chunks(int T, int A) { int Lt = 64 / A; retur
 extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          float* r, long ldr, const float* s0, const int* seq_env,
                                          const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
-                                         int masked, float kappa, hipStream_t st) {
+                                         int masked, float kappa, int hs, hipStream_t st) {
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
-  RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa};
+  if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
+  RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs};
   size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(ChunkMeta);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
@@ -520,9 +529,10 @@ extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* 
 extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
                                          long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
-                                         int masked, float kappa, hipStream_t st) {
+                                         int masked, float kappa, int hs, hipStream_t st) {
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
-  RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa};
+  if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
+  RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs};
   size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(ChunkMeta);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
@@ -533,10 +543,11 @@ extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* 
 extern "C" int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
                                          int write_state, const float* gp, long ldg, const float* gamma, const float* beta,
-                                         hipStream_t st) {
+                                         int hs, int gs, hipStream_t st) {
   if (ntok < 1 || ntok > 16 || ret_from < 0 || ret_from >= ntok) { set_error("retention_recurrent: 1 <= ntok <= 16, 0 <= ret_from < ntok"); return MAGPO_EINVAL; }
+  if (hs < 4 || hs > 64 || (hs & 3) || gs < 1 || gs > hs || (gs & (gs - 1))) { set_error("retention_recurrent: bad head width / group size"); return MAGPO_EINVAL; }
   hipLaunchKernelGGL(k_ret_recurrent, dim3(nenv), dim3(256), 0, st, S, q, k, v, ldq, ldk, ldv, env_stride_rows, r, ldr, ntok, ret_from,
-                     decay, write_state, gp, ldg, gamma, beta);
+                     decay, write_state, gp, ldg, gamma, beta, hs, gs);
   return check_launch("magpo_retention_recurrent");
 }
 

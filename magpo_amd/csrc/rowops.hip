@@ -22,6 +22,12 @@ __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float
 __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// mean over aligned groups of gs channels (gs = 4, 8, 16, 32 or 64) of a 64-wide row held as float4 by 16 lanes
+__device__ __forceinline__ float groupmean(float4 v, int gs) {
+  float s = f4sum(v);
+  for (int o = gs >> 3; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s / (float)gs;
+}
 // mean over a 64-wide row held as float4 by 16 consecutive lanes
 __device__ __forceinline__ float rowmean64(float4 v) { return sum16(f4sum(v)) * (1.0f / 64.0f); }
 
@@ -277,16 +283,17 @@ __global__ void k_small_operand(const float* __restrict__ obs, int ldo, int F, c
 // u = swish(gpre) * rn                                                  (retention.py:289-294)
 __global__ __launch_bounds__(256) void k_retpost_fwd(const float* __restrict__ r, int ldr, const float* __restrict__ gp, int ldg,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ u, int ldu, long R) {
+                                                     float* __restrict__ u, int ldu, long R, int hs, int gs) {
+  // flax GroupNorm(num_groups = n_head) on (token*head, hs) rows: groups of gs = hs / n_head channels; scale/bias [hs]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
-  const float4 ga = ld4(gamma + c4), be = ld4(beta + c4);
+  const float4 ga = ld4(gamma + (c4 % hs)), be = ld4(beta + (c4 % hs));
   for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
     const long row = base + wave * 4 + (lane >> 4);
     const bool ok = row < R;
     float4 x = f4zero(), g = f4zero();
     if (ok) { x = ld4(r + row * ldr + c4); g = ld4(gp + row * ldg + c4); }
-    const float mu = rowmean64(x);
-    const float m2 = rowmean64(f4mul(x, x));
+    const float mu = groupmean(x, gs);
+    const float m2 = groupmean(f4mul(x, x), gs);
     const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + NORM_EPS);
     float4 rn = make_float4((x.x - mu) * rstd * ga.x + be.x, (x.y - mu) * rstd * ga.y + be.y,
                             (x.z - mu) * rstd * ga.z + be.z, (x.w - mu) * rstd * ga.w + be.w);
@@ -299,18 +306,18 @@ __global__ __launch_bounds__(256) void k_retpost_bwd(const float* __restrict__ r
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ du, int lddu,
                                                      float* __restrict__ dr, int lddr, float* __restrict__ dgp, int lddg,
-                                                     float* __restrict__ slab_gamma, float* __restrict__ slab_beta, long R) {
+                                                     float* __restrict__ slab_gamma, float* __restrict__ slab_beta, long R, int hs, int gs) {
   __shared__ float lds[4 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
-  const float4 ga = ld4(gamma + c4), be = ld4(beta + c4);
+  const float4 ga = ld4(gamma + (c4 % hs)), be = ld4(beta + (c4 % hs));
   float4 dga = f4zero(), dbe = f4zero();
   for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
     const long row = base + wave * 4 + (lane >> 4);
     const bool ok = row < R;
     float4 x = f4zero(), g = f4zero(), d = f4zero();
     if (ok) { x = ld4(r + row * ldr + c4); g = ld4(gp + row * ldg + c4); d = ld4(du + row * lddu + c4); }
-    const float mu = rowmean64(x);
-    const float m2 = rowmean64(f4mul(x, x));
+    const float mu = groupmean(x, gs);
+    const float m2 = groupmean(f4mul(x, x), gs);
     const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + NORM_EPS);
     float4 xh = make_float4((x.x - mu) * rstd, (x.y - mu) * rstd, (x.z - mu) * rstd, (x.w - mu) * rstd);
     float4 rn = f4add(f4mul(xh, ga), be);
@@ -321,8 +328,8 @@ __global__ __launch_bounds__(256) void k_retpost_bwd(const float* __restrict__ r
     dga = f4add(dga, f4mul(drn, xh));
     dbe = f4add(dbe, drn);
     float4 gg = f4mul(drn, ga);
-    const float mg = rowmean64(gg);
-    const float mgx = rowmean64(f4mul(gg, xh));
+    const float mg = groupmean(gg, gs);
+    const float mgx = groupmean(f4mul(gg, xh), gs);
     float4 dx = make_float4((gg.x - mg - xh.x * mgx) * rstd, (gg.y - mg - xh.y * mgx) * rstd,
                             (gg.z - mg - xh.z * mgx) * rstd, (gg.w - mg - xh.w * mgx) * rstd);
     if (ok) { st4(dr + row * lddr + c4, dx); st4(dgp + row * lddg + c4, dg); }
@@ -549,17 +556,27 @@ extern "C" int magpo_small_operand(int mode, const float* obs, int ldo, int F, c
   return check_launch("magpo_small_operand");
 }
 
+static int check_groups(int hs, int gs) {
+  if (hs < 4 || hs > 64 || (64 % hs) || gs < 4 || gs > hs || (gs & (gs - 1))) {
+    set_error("retpost: head width must divide 64 and the group size must be a power of two in [4, hs]");
+    return MAGPO_EINVAL;
+  }
+  return MAGPO_OK;
+}
+
 extern "C" int magpo_retpost_fwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
-                                 float* u, int ldu, long R, hipStream_t st) {
-  hipLaunchKernelGGL(k_retpost_fwd, dim3(row_grid(R)), dim3(256), 0, st, r, ldr, gp, ldg, gamma, beta, u, ldu, R);
+                                 float* u, int ldu, long R, int hs, int gs, hipStream_t st) {
+  if (int e = check_groups(hs, gs)) return e;
+  hipLaunchKernelGGL(k_retpost_fwd, dim3(row_grid(R)), dim3(256), 0, st, r, ldr, gp, ldg, gamma, beta, u, ldu, R, hs, gs);
   return check_launch("magpo_retpost_fwd");
 }
 
 extern "C" int magpo_retpost_bwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
                                  const float* du, int lddu, float* dr, int lddr, float* dgp, int lddg, float* slab_gamma,
-                                 float* slab_beta, long R, hipStream_t st) {
+                                 float* slab_beta, long R, int hs, int gs, hipStream_t st) {
+  if (int e = check_groups(hs, gs)) return e;
   hipLaunchKernelGGL(k_retpost_bwd, dim3(row_grid(R)), dim3(256), 0, st, r, ldr, gp, ldg, gamma, beta, du, lddu, dr, lddr,
-                     dgp, lddg, slab_gamma, slab_beta, R);
+                     dgp, lddg, slab_gamma, slab_beta, R, hs, gs);
   return check_launch("magpo_retpost_bwd");
 }
 

@@ -100,7 +100,7 @@ class EnvGroup:
     reference's (device, update-batch) replica (rec_magpo.py:519, :648-653); all groups of a process share
     the parameters and the training workspaces."""
 
-    def __init__(self, env_cfg: CoordSumConfig, N: int, T: int, device, n_block: int = 1):
+    def __init__(self, env_cfg: CoordSumConfig, N: int, T: int, device, n_block: int = 1, n_head: int = 1):
         A, F = env_cfg.num_agents, env_cfg.num_agents + 1
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
@@ -109,8 +109,9 @@ class EnvGroup:
         self.traj = dict(obs=f32(T + 1, N, A, F), step_count=i32(T + 1, N), done=u8(T + 1, N), action=i32(T, N, A), value=f32(T, N, A),
                          reward=f32(T, N, A), log_prob=f32(T, N, A), adv=f32(T, N, A), targets=f32(T, N, A))
         self.metrics = dict(episode_return=f32(T, N), episode_length=i32(T, N), is_terminal_step=u8(T, N))
-        self.sable_hs = tuple(f32(n_block, N, 64, 64) for _ in range(3))       # (encoder, decoder self, decoder cross)
-        self.prev_sable_hs = tuple(f32(n_block, N, 64, 64) for _ in range(3))
+        # (encoder, decoder self, decoder cross) retention states; head states are padded to 64 x 64 on the device
+        self.sable_hs = tuple(f32(n_block, n_head, N, 64, 64) for _ in range(3))
+        self.prev_sable_hs = tuple(f32(n_block, n_head, N, 64, 64) for _ in range(3))
         self.policy_h = [f32(N * A, 128), f32(N * A, 128)]
         self.policy_h0 = f32(N * A, 128)
         self.last_val = f32(N, A)
@@ -125,7 +126,7 @@ class EnvGroup:
 class MagpoLearner:
     def __init__(self, env_cfg: CoordSumConfig, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
                  decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 512, num_groups: int = 1,
-                 n_block: int = 1):
+                 n_block: int = 1, n_head: int = 1):
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
         F = A + 1  # AgentIDWrapper (observation.py:42-54), add_agent_id: True
@@ -135,18 +136,18 @@ class MagpoLearner:
         self.L = lib()
         # one contiguous buffer [guider grads | actor grads | loss scalars] = one all-reduce message (rec_magpo.py:395-409)
         from .params import FlatParams, actor_layout, guider_layout
-        self.nb = int(n_block)
-        gn = FlatParams(guider_layout(64, F, K, self.nb), "cpu").numel
+        self.nb, self.nh = int(n_block), int(n_head)
+        gn = FlatParams(guider_layout(64, F, K, self.nb, self.nh), "cpu").numel
         an = FlatParams(actor_layout(F, 128, K), "cpu").numel
         self.grad_all = torch.zeros(gn + an + 16, dtype=torch.float32, device=device)
         self.grad_acc = torch.zeros_like(self.grad_all) if num_groups > 1 else None
         self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
-                                  max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb,
+                                  max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh,
                                   seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn])
         self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
                               grads=self.grad_all[gn:gn + an])
         self.loss_out = self.grad_all[gn + an:gn + an + 9]
-        self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb) for _ in range(num_groups)]
+        self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb, self.nh) for _ in range(num_groups)]
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         # optimiser state (optax adam: count, mu, nu)
         self.g_mu, self.g_nu = torch.zeros_like(self.guider.P.flat), torch.zeros_like(self.guider.P.flat)
@@ -268,7 +269,8 @@ class MagpoLearner:
             g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
                        g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t])
             for k in range(self.nb):
-                L.call("magpo_zero_states_where_done", g.sable_hs[0][k], g.sable_hs[1][k], g.sable_hs[2][k], tr["done"][t + 1], N, st)
+                for h in range(self.nh):
+                    L.call("magpo_zero_states_where_done", g.sable_hs[0][k][h], g.sable_hs[1][k][h], g.sable_hs[2][k][h], tr["done"][t + 1], N, st)
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])
             g.cur = 0

@@ -42,8 +42,9 @@ class FlatParams:
         return {n: self.view_of(flat, n) for n in self.shapes}
 
 
-def guider_layout(E: int, F: int, K: int, nb: int = 1) -> "OrderedDict[str, Tuple[int, ...]]":
+def guider_layout(E: int, F: int, K: int, nb: int = 1, nh: int = 1) -> "OrderedDict[str, Tuple[int, ...]]":
     assert E == 64, "the gfx950 kernels are specialised for embed_dim = 64"
+    hs = E // nh  # GroupNorm scale / bias are per head channel (retention.py:247)
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     s["enc.ln.scale"] = (E,)
     s["enc.obs.norm.scale"] = (F,)
@@ -59,8 +60,8 @@ def guider_layout(E: int, F: int, K: int, nb: int = 1) -> "OrderedDict[str, Tupl
         s[p + "ln2.scale"] = (E,)
         s[p + "retn.w_qkvg"] = (E, 4 * E)
         s[p + "retn.w_o"] = (E, E)
-        s[p + "retn.gn.scale"] = (E,)
-        s[p + "retn.gn.bias"] = (E,)
+        s[p + "retn.gn.scale"] = (hs,)
+        s[p + "retn.gn.bias"] = (hs,)
         for w in ("W_linear", "W_gate", "W_output"):
             s[p + f"ffn.{w}"] = (E, E)
     s["dec.ln.scale"] = (E,)
@@ -76,34 +77,37 @@ def guider_layout(E: int, F: int, K: int, nb: int = 1) -> "OrderedDict[str, Tupl
             s[p + f"{n}.scale"] = (E,)
         s[p + "retn1.w_qkvg"] = (E, 4 * E)
         s[p + "retn1.w_o"] = (E, E)
-        s[p + "retn1.gn.scale"] = (E,)
-        s[p + "retn1.gn.bias"] = (E,)
+        s[p + "retn1.gn.scale"] = (hs,)
+        s[p + "retn1.gn.bias"] = (hs,)
         s[p + "retn2.w_q"] = (E, E)
         s[p + "retn2.w_kvg"] = (E, 3 * E)
         s[p + "retn2.w_o"] = (E, E)
-        s[p + "retn2.gn.scale"] = (E,)
-        s[p + "retn2.gn.bias"] = (E,)
+        s[p + "retn2.gn.scale"] = (hs,)
+        s[p + "retn2.gn.bias"] = (hs,)
         for w in ("W_linear", "W_gate", "W_output"):
             s[p + f"ffn.{w}"] = (E, E)
     return s
 
 
-def guider_named_views(views: Dict[str, torch.Tensor], E: int = 64) -> Dict[str, torch.Tensor]:
-    """Reference-named parameter dict (names as oracle.networks.guider_param_shapes)."""
+def guider_named_views(views: Dict[str, torch.Tensor], E: int = 64, nh: int = 1) -> Dict[str, torch.Tensor]:
+    """Reference-named parameter dict (names / shapes as oracle.networks.guider_param_shapes): per-head projection
+    kernels [n_head, E, hs] are strided views of the fused [E, 4E] / [E, 3E] matrices (head h = columns h*hs..)."""
+    hs = E // nh
+    heads = lambda m: m.unflatten(1, (nh, hs)).permute(1, 0, 2)   # [E, nh*hs] -> [nh, E, hs] (view)
     out: Dict[str, torch.Tensor] = {}
     for n, v in views.items():
         if n.endswith("w_qkvg"):
             p = n[: -len("w_qkvg")]
-            out[p + "w_q"] = v[:, 0:E].unsqueeze(0)
-            out[p + "w_k"] = v[:, E:2 * E].unsqueeze(0)
-            out[p + "w_v"] = v[:, 2 * E:3 * E].unsqueeze(0)
+            out[p + "w_q"] = heads(v[:, 0:E])
+            out[p + "w_k"] = heads(v[:, E:2 * E])
+            out[p + "w_v"] = heads(v[:, 2 * E:3 * E])
             out[p + "w_g"] = v[:, 3 * E:4 * E]
         elif n.endswith("retn2.w_q"):
-            out[n] = v.unsqueeze(0)
+            out[n] = heads(v)
         elif n.endswith("w_kvg"):
             p = n[: -len("w_kvg")]
-            out[p + "w_k"] = v[:, 0:E].unsqueeze(0)
-            out[p + "w_v"] = v[:, E:2 * E].unsqueeze(0)
+            out[p + "w_k"] = heads(v[:, 0:E])
+            out[p + "w_v"] = heads(v[:, E:2 * E])
             out[p + "w_g"] = v[:, 2 * E:3 * E]
         else:
             out[n] = v

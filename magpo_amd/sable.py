@@ -22,10 +22,10 @@ from .params import FlatParams, guider_layout, guider_named_views, init_guider
 E = 64
 
 
-def decay_kappa(n_head: int, scaling: float) -> float:
-    """sable_network.py:366-369 in float32 for n_head = 1."""
-    k = np.float32(1.0) - np.exp(np.log(np.float32(1 / 32)))
-    return float(np.float32(k) * np.float32(scaling))
+def decay_kappas(n_head: int, scaling: float):
+    """sable_network.py:366-369 / retention.py:231-234 in float32: one kappa per head."""
+    k = 1.0 - np.exp(np.linspace(np.log(np.float32(1 / 32)), np.log(np.float32(1 / 512)), n_head, dtype=np.float32))
+    return [float(x) for x in (k.astype(np.float32) * np.float32(scaling)).astype(np.float32)]
 
 
 class _Bufs:
@@ -45,23 +45,26 @@ class SableGuider:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, embed_dim: int = 64, n_head: int = 1,
                  n_block: int = 1, decay_scaling_factor: float = 0.8, use_pe: bool = True, max_pos: int = 101,
                  wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
-        if embed_dim != 64 or n_head != 1 or n_block < 1:
-            raise NotImplementedError("gfx950 Sable kernels: embed_dim=64, n_head=1 only (SURVEY 8f rank 3)")
-        self.nb = int(n_block)
+        if embed_dim != 64 or n_head not in (1, 2, 4) or n_block < 1:
+            raise NotImplementedError("gfx950 Sable kernels: embed_dim=64 and n_head in {1, 2, 4} (SURVEY 8f rank 3)")
+        self.nb, self.nh = int(n_block), int(n_head)
+        self.hs = E // self.nh          # head width
+        self.gs = self.hs // self.nh    # flax GroupNorm(num_groups=n_head) on (token*head, hs) rows: hs / n_head channels per group
         if obs_dim > 32 or action_dim > 31:
             raise NotImplementedError("obs_dim <= 32 and action_dim <= 31 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
         self.dev = device
         self.L = lib()
-        self.kappa = decay_kappa(1, decay_scaling_factor)
+        self.kappas = decay_kappas(self.nh, decay_scaling_factor)
+        self.kappa = self.kappas[0]
         self.G = wgrad_groups
-        self.P = FlatParams(guider_layout(E, obs_dim, action_dim, self.nb), device)
+        self.P = FlatParams(guider_layout(E, obs_dim, action_dim, self.nb, self.nh), device)
         self.grads = torch.zeros_like(self.P.flat) if grads is None else grads
         assert self.grads.numel() == self.P.numel
         self.v = self.P.views()
         self.gv = self.P.views(self.grads)
-        self.named = guider_named_views(self.v)
-        self.named_grads = guider_named_views(self.gv)
+        self.named = guider_named_views(self.v, E, self.nh)
+        self.named_grads = guider_named_views(self.gv, E, self.nh)
         if seed is not None:
             init_guider(self.named, seed)
         self.npos = max_pos
@@ -145,6 +148,42 @@ class SableGuider:
                     W, idx, idx_stride, self.v["enc.obs.norm.scale"], self.F, out, ldout, outpe, ldoutpe, Wt, bias, Y, ldy, R, NOUT,
                     self._st())
 
+    # ------------------------------------------------------------------ per-head retention helpers
+    def _ret_rec(self, S, q, ldq, k, ldk, v, ldv, env_rows, u, ldu, N, ntok, ret_from, write, gp, ldg, gamma, beta):
+        """Recurrent retention + fused GroupNorm/gate for every head; S [n_head, N, 64, 64] (padded head states)."""
+        hs = self.hs
+        for h in range(self.nh):
+            o = h * hs
+            self.L.call("magpo_retention_recurrent", S[h], q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, env_rows, u[:, o:], ldu, N, ntok,
+                        ret_from, self.kappas[h], write, gp[:, o:], ldg, gamma, beta, hs, self.gs, self._st())
+
+    def _ret_fwd(self, q, ldq, k, ldk, v, ldv, r, s0, seq_env, dones, name, nseq, T, masked):
+        nch = self.L.call("magpo_retention_num_chunks", T, self.A)
+        hs = self.hs
+        for h in range(self.nh):
+            o = h * hs
+            stt = self.b.get(f"t_{name}_{h}", (nseq, nch, E, E))
+            self.L.call("magpo_retention_chunk_fwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, r[:, o:], E, s0[h], seq_env, dones, stt,
+                        None, nseq, T, self.A, masked, self.kappas[h], hs, self._st())
+
+    def _ret_bwd(self, q, ldq, k, ldk, v, ldv, dr, dq, lddq, dk, lddk, dv, lddv, dones, name, nseq, T, masked):
+        hs = self.hs
+        for h in range(self.nh):
+            o = h * hs
+            self.L.call("magpo_retention_chunk_bwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, dr[:, o:], E, dq[:, o:], lddq, dk[:, o:],
+                        lddk, dv[:, o:], lddv, dones, self.b.t[f"t_{name}_{h}"], nseq, T, self.A, masked, self.kappas[h], hs, self._st())
+
+    def _retpost_fwd(self, r, gp, ldg, gamma, beta, u, R):
+        self.L.call("magpo_retpost_fwd", r, E, gp, ldg, gamma, beta, u, E, R, self.hs, self.gs, self._st())
+
+    def _retpost_bwd(self, r, gp, ldg, pfx, du, dr, dgp, lddg, R, sa, sb):
+        v, gv = self.v, self.gv
+        self.L.call("magpo_retpost_bwd", r, E, gp, ldg, v[pfx + "gn.scale"], v[pfx + "gn.bias"], du, E, dr, E, dgp, lddg, sa, sb, R,
+                    self.hs, self.gs, self._st())
+        for h in range(self.nh):   # scale / bias [hs] are shared by the heads: fold the per-column slabs
+            self.reduce(sa[:, h * self.hs:], gv[pfx + "gn.scale"], P=self.hs, stride=64, accumulate=h > 0)
+            self.reduce(sb[:, h * self.hs:], gv[pfx + "gn.bias"], P=self.hs, stride=64, accumulate=h > 0)
+
     def act(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False):
         """One env step for N envs (SableNetwork.get_actions, sable_network.py:443-482).  obs [N,A,F] f32, pos [N] i32
         (step_count), states = (S_enc, S_d1, S_d2) each [n_block, N, 64, 64] updated in place, sample_keys = [A,2]
@@ -171,8 +210,8 @@ class SableGuider:
             else:  # x = ln(rep of the previous block) (shared self.ln, sable_network.py:150)
                 self._pro(3, rep, E, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, None, None, 0, xn, E, None, 0,
                           self.wt[f"qkvg{blk}"], None, qkvg, 4 * E, R, 4 * E)
-            L.call("magpo_retention_recurrent", s_enc[blk], qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, u, E, N, A, 0,
-                   self.kappa, 1, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], st)
+            self._ret_rec(s_enc[blk], qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, A, u, E, N, A, 0, 1,
+                          qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"])
             self.lin(u, E, self.wt[f"wo{blk}"], None, y, E, R, E, E)
             if blk == nb - 1:
                 self._pro(3, xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], False, pos_tok, 1, None, None, 0, rep, E, reppe, E,
@@ -206,13 +245,13 @@ class SableGuider:
                 else:  # block input = previous block's output x (xo); key = query = value = x + pe (xope)
                     self.lin(xope, E, self.wt[f"qkvg1{blk}"], None, qkvg1[blk][i:], A * 4 * E, N, E, 4 * E)
                     xin = xo
-                L.call("magpo_retention_recurrent", s_d1[blk], qkvg1[blk], 4 * E, qkvg1[blk][:, E:], 4 * E, qkvg1[blk][:, 2 * E:], 4 * E, A, u1, E,
-                       N, i + 1, i, self.kappa, last, qkvg1[blk][:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], st)
+                self._ret_rec(s_d1[blk], qkvg1[blk], 4 * E, qkvg1[blk][:, E:], 4 * E, qkvg1[blk][:, 2 * E:], 4 * E, A, u1, E, N, i + 1, i, last,
+                              qkvg1[blk][:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"])
                 self.lin(u1[i:], A * E, self.wt[f"wo1{blk}"], None, y1, E, N, E, E)
                 self._pro(3, xin, E, y1, E, v[d + "ln1.scale"], None, True, pos, 1, None, None, 0, None, 0, None, 0,
                           self.wt[f"kvg2{blk}"], None, kvg2[blk][i:], A * 3 * E, N, 3 * E)
-                L.call("magpo_retention_recurrent", s_d2[blk], q2[blk], E, kvg2[blk], 3 * E, kvg2[blk][:, E:], 3 * E, A, u2, E, N, i + 1, i,
-                       self.kappa, last, kvg2[blk][:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], st)
+                self._ret_rec(s_d2[blk], q2[blk], E, kvg2[blk], 3 * E, kvg2[blk][:, E:], 3 * E, A, u2, E, N, i + 1, i, last,
+                              kvg2[blk][:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"])
                 self.lin(u2[i:], A * E, self.wt[f"wo2{blk}"], None, y2, E, N, E, E)
                 if blk == nb - 1:
                     self._pro(3, rep[i:], A * E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], False, pos, 1, None, None, 0,
@@ -249,9 +288,8 @@ class SableGuider:
             e = f"enc.block{k}."
             xn, kin, qkvg, r, u, y = g(f"xn{k}"), g(f"kin{k}"), g(f"qkvg{k}", 4 * E), g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
             self.lin(kin, E, self.wt[f"qkvg{k}"], None, qkvg, 4 * E, R, E, 4 * E)
-            L.call("magpo_retention_chunk_fwd", qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, E, s0[0][k], seq_env, dones,
-                   stt(f"st_e{k}"), None, nseq, T, A, 0, self.kappa, st)
-            L.call("magpo_retpost_fwd", r, E, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], u, E, R, st)
+            self._ret_fwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, s0[0][k], seq_env, dones, f"st_e{k}", nseq, T, 0)
+            self._retpost_fwd(r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], u, R)
             self.lin(u, E, self.wt[f"wo{k}"], None, y, E, R, E, E)
             if k == nb - 1:
                 L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], self.pe, pos, 1, self.npos,
@@ -273,16 +311,14 @@ class SableGuider:
             qkvg1, r1, u1, y1 = g(f"qkvg1{k}", 4 * E), g(f"r1{k}"), g(f"u1{k}"), g(f"y1{k}")
             c, cpe, q2, kvg2, r2, u2, y2 = g(f"c{k}"), g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
             self.lin(xpe, E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
-            L.call("magpo_retention_chunk_fwd", qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, E, s0[1][k], seq_env, dones,
-                   stt(f"st_1{k}"), None, nseq, T, A, 1, self.kappa, st)
-            L.call("magpo_retpost_fwd", r1, E, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], u1, E, R, st)
+            self._ret_fwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, s0[1][k], seq_env, dones, f"st_1{k}", nseq, T, 1)
+            self._retpost_fwd(r1, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], u1, R)
             self.lin(u1, E, self.wt[f"wo1{k}"], None, y1, E, R, E, E)
             L.call("magpo_resnorm_fwd", x, E, y1, E, v[d + "ln1.scale"], None, self.pe, pos, 1, self.npos, c, E, cpe, E, R, st)
             self.lin(reppe, E, self.wt[f"q2{k}"], None, q2, E, R, E, E)
             self.lin(cpe, E, self.wt[f"kvg2{k}"], None, kvg2, 3 * E, R, E, 3 * E)
-            L.call("magpo_retention_chunk_fwd", q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, E, s0[2][k], seq_env, dones, stt(f"st_2{k}"), None,
-                   nseq, T, A, 1, self.kappa, st)
-            L.call("magpo_retpost_fwd", r2, E, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], u2, E, R, st)
+            self._ret_fwd(q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, s0[2][k], seq_env, dones, f"st_2{k}", nseq, T, 1)
+            self._retpost_fwd(r2, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], u2, R)
             self.lin(u2, E, self.wt[f"wo2{k}"], None, y2, E, R, E, E)
             if k == nb - 1:
                 L.call("magpo_resnorm_fwd", rep, E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], None, None, 0, 0, g(f"x{nb}"), E,
@@ -332,11 +368,9 @@ class SableGuider:
             self.lin(dsum2, E, v[d + "retn2.w_o"], None, du2, E, R, E, E)
             dr2 = g("dr"); dq2 = g(f"dq2_{k}"); dkvg2 = g(f"dkvg2_{k}", 3 * E)
             kvg2 = t(f"kvg2{k}")
-            L.call("magpo_retpost_bwd", t(f"r2{k}"), E, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
-                   du2, E, dr2, E, dkvg2[:, 2 * E:], 3 * E, slab("a"), slab("b"), R, st)
-            self.reduce(slab("a"), gv[d + "retn2.gn.scale"]); self.reduce(slab("b"), gv[d + "retn2.gn.bias"])
-            L.call("magpo_retention_chunk_bwd", t(f"q2{k}"), E, kvg2, 3 * E, kvg2[:, E:], 3 * E, dr2, E, dq2, E, dkvg2, 3 * E, dkvg2[:, E:], 3 * E,
-                   dones, b.t[f"t_st_2{k}"], nseq, T, A, 1, self.kappa, st)
+            self._retpost_bwd(t(f"r2{k}"), kvg2[:, 2 * E:], 3 * E, d + "retn2.", du2, dr2, dkvg2[:, 2 * E:], 3 * E, R, slab("a"), slab("b"))
+            self._ret_bwd(t(f"q2{k}"), E, kvg2, 3 * E, kvg2[:, E:], 3 * E, dr2, dq2, E, dkvg2, 3 * E, dkvg2[:, E:], 3 * E, dones,
+                          f"st_2{k}", nseq, T, 1)
             self.wgrad(t("reppe"), E, dq2, E, R, E, E, gv[d + "retn2.w_q"])
             self.wgrad(t(f"cpe{k}"), E, dkvg2, 3 * E, R, E, 3 * E, gv[d + "retn2.w_kvg"])
             dreppe = g(f"dreppe_{k}"); dcpe = g("dcpe")
@@ -356,11 +390,9 @@ class SableGuider:
             self.lin(dsum1, E, v[d + "retn1.w_o"], None, du1, E, R, E, E)
             dr1 = g("dr"); dqkvg1 = g(f"dqkvg1_{k}", 4 * E)
             qkvg1 = t(f"qkvg1{k}")
-            L.call("magpo_retpost_bwd", t(f"r1{k}"), E, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"],
-                   du1, E, dr1, E, dqkvg1[:, 3 * E:], 4 * E, slab("a"), slab("b"), R, st)
-            self.reduce(slab("a"), gv[d + "retn1.gn.scale"]); self.reduce(slab("b"), gv[d + "retn1.gn.bias"])
-            L.call("magpo_retention_chunk_bwd", qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, dr1, E, dqkvg1, 4 * E,
-                   dqkvg1[:, E:], 4 * E, dqkvg1[:, 2 * E:], 4 * E, dones, b.t[f"t_st_1{k}"], nseq, T, A, 1, self.kappa, st)
+            self._retpost_bwd(t(f"r1{k}"), qkvg1[:, 3 * E:], 4 * E, d + "retn1.", du1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
+            self._ret_bwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, dr1, dqkvg1, 4 * E, dqkvg1[:, E:], 4 * E,
+                          dqkvg1[:, 2 * E:], 4 * E, dones, f"st_1{k}", nseq, T, 1)
             self.wgrad(t(f"xpe{k}"), E, dqkvg1, 4 * E, R, E, 4 * E, gv[d + "retn1.w_qkvg"])
             dkin1 = g(f"dkin1_{k}")
             self.lin(dqkvg1, 4 * E, v[d + "retn1.w_qkvg"], None, dkin1, E, R, 4 * E, E)
@@ -394,11 +426,9 @@ class SableGuider:
             self.lin(dsum0, E, v[e + "retn.w_o"], None, du, E, R, E, E)
             dr = g("dr"); dqkvg = g(f"dqkvg_{k}", 4 * E)
             qkvg = t(f"qkvg{k}")
-            L.call("magpo_retpost_bwd", t(f"r{k}"), E, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], du, E,
-                   dr, E, dqkvg[:, 3 * E:], 4 * E, slab("a"), slab("b"), R, st)
-            self.reduce(slab("a"), gv[e + "retn.gn.scale"]); self.reduce(slab("b"), gv[e + "retn.gn.bias"])
-            L.call("magpo_retention_chunk_bwd", qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, dr, E, dqkvg, 4 * E, dqkvg[:, E:], 4 * E,
-                   dqkvg[:, 2 * E:], 4 * E, dones, b.t[f"t_st_e{k}"], nseq, T, A, 0, self.kappa, st)
+            self._retpost_bwd(t(f"r{k}"), qkvg[:, 3 * E:], 4 * E, e + "retn.", du, dr, dqkvg[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
+            self._ret_bwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, dr, dqkvg, 4 * E, dqkvg[:, E:], 4 * E, dqkvg[:, 2 * E:], 4 * E,
+                          dones, f"st_e{k}", nseq, T, 0)
             self.wgrad(t(f"kin{k}"), E, dqkvg, 4 * E, R, E, 4 * E, gv[e + "retn.w_qkvg"])
             dkin = g(f"dkin_{k}")
             self.lin(dqkvg, 4 * E, v[e + "retn.w_qkvg"], None, dkin, E, R, 4 * E, E)

@@ -144,14 +144,14 @@ def test_retpost_resnorm_headmid(L, stream):
     r, gp, du = rn(R, 64), rn(R, 64), rn(R, 64)
     ga, be = 1 + 0.1 * rn(64), 0.1 * rn(64)
     u = torch.empty(R, 64, device=DEV)
-    L.call("magpo_retpost_fwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), u, 64, R, stream)
+    L.call("magpo_retpost_fwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), u, 64, R, 64, 64, stream)
     rd, gpd, gad, bed = (t.double().requires_grad_(True) for t in (r, gp, ga, be))
     ur = onets.swish(gpd) * onets.groupnorm_rows(rd, gad, bed, 1)
     close(u, ur, what="u")
     (ur * du.double()).sum().backward()
     dr = torch.empty(R, 64, device=DEV); dgp = torch.empty(R, 64, device=DEV)
     sg = torch.zeros(grid, 64, device=DEV); sb = torch.zeros(grid, 64, device=DEV)
-    L.call("magpo_retpost_bwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), dev(du), 64, dr, 64, dgp, 64, sg, sb, R, stream)
+    L.call("magpo_retpost_bwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), dev(du), 64, dr, 64, dgp, 64, sg, sb, R, 64, 64, stream)
     close(dr, rd.grad, 1e-4, 1e-5, "dr"); close(dgp, gpd.grad, 1e-4, 1e-5, "dgp")
     close(_slabsum(sg), gad.grad, 1e-4, 1e-5, "dgamma"); close(_slabsum(sb), bed.grad, 1e-4, 1e-5, "dbeta")
     # resnorm (two norms + pe) and (one norm)
@@ -233,11 +233,11 @@ def test_retention_chunk(L, stream, A, T, masked):
     s0_store[perm.long()] = s0
     dn = dev(dones.to(torch.uint8))
     L.call("magpo_retention_chunk_fwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, r, 64, dev(s0_store), dev(perm),
-           dn, states, sfin, B, T, A, masked, kappa, stream)
+           dn, states, sfin, B, T, A, masked, kappa, 64, stream)
     close(r.reshape(B, C, 64), ref, 1e-4, 1e-5, "ret fwd")
     dbuf = torch.zeros(B * C, 256, device=DEV)
     L.call("magpo_retention_chunk_bwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, dev(dr.reshape(-1, 64)), 64,
-           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, stream)
+           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, 64, stream)
     close(dbuf[:, 0:64].reshape(B, C, 64), qd.grad, 1e-4, 1e-5, "dq")
     close(dbuf[:, 64:128].reshape(B, C, 64), kd.grad, 1e-4, 1e-5, "dk")
     close(dbuf[:, 128:192].reshape(B, C, 64), vd.grad, 1e-4, 1e-5, "dv")
@@ -250,14 +250,14 @@ def test_retention_recurrent(L, stream):
     q, k, v = (torch.randn(N * A, 64, generator=g) for _ in range(3))
     Sd = dev(S)
     r = torch.zeros(N * A, 64, device=DEV)
-    L.call("magpo_retention_recurrent", Sd, dev(q), 64, dev(k), 64, dev(v), 64, A, r, 64, N, A, 0, 0.775, 1, None, 0, None, None, stream)
+    L.call("magpo_retention_recurrent", Sd, dev(q), 64, dev(k), 64, dev(v), 64, A, r, 64, N, A, 0, 0.775, 1, None, 0, None, None, 64, 64, stream)
     qq, kk, vv = (t.double().reshape(N, A, 64) for t in (q, k, v))
     Sn = 0.775 * S.double() + kk.transpose(1, 2) @ vv
     close(Sd, Sn, what="S"); close(r.reshape(N, A, 64), qq @ Sn, what="ret")
     # decoder iteration i = 2: tokens 0..2 applied on the fly, output for token 2 only, state left untouched
     S2 = dev(S)
     r2 = torch.zeros(N * A, 64, device=DEV)
-    L.call("magpo_retention_recurrent", S2, dev(q), 64, dev(k), 64, dev(v), 64, A, r2, 64, N, 3, 2, 0.775, 0, None, 0, None, None, stream)
+    L.call("magpo_retention_recurrent", S2, dev(q), 64, dev(k), 64, dev(v), 64, A, r2, 64, N, 3, 2, 0.775, 0, None, 0, None, None, 64, 64, stream)
     Sn = 0.775 * S.double() + kk[:, :3].transpose(1, 2) @ vv[:, :3]
     close(S2, S, 0, 0, "state must not be written")
     close(r2.reshape(N, A, 64)[:, 2], (qq[:, 2:3] @ Sn)[:, 0], what="ret token 2")

@@ -13,18 +13,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _mk(A, K, TL, maxval, N, T, P=2, M=2, seed=42, nb=1):
+def _mk(A, K, TL, maxval, N, T, P=2, M=2, seed=42, nb=1, nh=1):
     from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
     spec = ocs.CoordSumSpec(A, K, TL, maxval)
-    scfg = onets.SableCfg(A, K, A + 1, n_block=nb)
+    scfg = onets.SableCfg(A, K, A + 1, n_block=nb, n_head=nh)
     osys = olearn.SystemCfg(rollout_length=T, ppo_epochs=P, num_minibatches=M)
-    gp = onets.init_guider_params(1, 64, A + 1, K, nb=nb)
+    gp = onets.init_guider_params(1, 64, A + 1, K, nb=nb, nh=nh)
     ap = onets.init_actor_params(2, A + 1, 128, K)
     ol = olearn.OracleLearner(spec, N, osys, scfg, gp, ap)
     key = oprng.split(oprng.prng_key(seed), 4)[0]
     ol.setup(key)
     dl = MagpoLearner(CoordSumConfig(A, K, TL, maxval), N, SystemConfig(rollout_length=T, ppo_epochs=P, num_minibatches=M), DEV,
-                      net_seed=None, wgrad_groups=8, n_block=nb)
+                      net_seed=None, wgrad_groups=8, n_block=nb, n_head=nh)
     dl.guider.load_named(gp)
     dl.actor.load_named(ap)
     dl.setup(key)
@@ -39,10 +39,11 @@ def close(a, b, rtol, atol, what):
     assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} (ref scale {ref:.3e})"
 
 
-@pytest.mark.parametrize("A,K,TL,maxval,N,T,nb", [(4, 20, 10, 60, 8, 16, 1), (2, 10, 7, 15, 4, 12, 1), (3, 10, 9, 30, 6, 11, 1),
-                                                    (4, 20, 10, 60, 8, 16, 2), (8, 15, 9, 100, 4, 11, 3)])
-def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb):
-    ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb)
+@pytest.mark.parametrize("A,K,TL,maxval,N,T,nb,nh", [(4, 20, 10, 60, 8, 16, 1, 1), (2, 10, 7, 15, 4, 12, 1, 1), (3, 10, 9, 30, 6, 11, 1, 1),
+                                                       (4, 20, 10, 60, 8, 16, 2, 1), (8, 15, 9, 100, 4, 11, 3, 1),
+                                                       (5, 20, 9, 80, 4, 11, 2, 2), (3, 10, 9, 30, 6, 10, 1, 4)])
+def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh):
+    ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb, nh=nh)
     assert np.array_equal(dl.env.target.cpu().numpy(), ol.env_state["target"])
     assert np.array_equal(dl.key, ol.key)
     om = ol.rollout(record_logits=True)
@@ -62,7 +63,9 @@ def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb):
         assert np.array_equal(dl.metrics[k].cpu().numpy(), om[k]), k
     assert om["is_terminal_step"].any(), "the test must cross an episode boundary"
     for d, o in zip(dl.sable_hs, ol.sable_hs):
-        close(d, o[:, 0].transpose(0, 1), 1e-4, 1e-6, "sable state")
+        hs = 64 // nh   # device head states are zero-padded to 64 x 64; oracle layout (N, nh, nb, hs, hs)
+        close(d[:, :, :, :hs, :hs], o.permute(2, 1, 0, 3, 4), 1e-4, 1e-6, "sable state")
+        assert float(d[:, :, :, hs:, :].abs().max() if hs < 64 else 0.0) == 0.0
     close(dl.policy_h[dl._cur], ol.policy_h.reshape(N * A, 128), 1e-4, 1e-6, "policy hidden")
     assert np.array_equal(dl.key, ol.key)
 
