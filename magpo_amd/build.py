@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(os.path.dirname(HERE), "build")
 OUT = os.path.join(HERE, "libmagpo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"] + os.environ.get("MAGPO_EXTRA_FLAGS", "").split()
 
 
 def _newer(src, dst):

@@ -1,0 +1,518 @@
+// Fused Sable acting step (SableNetwork.get_actions, mava/networks/sable_network.py:443-482) for gfx950:
+// ONE launch per environment step, WAVE-AUTONOMOUS: a single-wave workgroup owns EPW environments and carries them
+// through the encoder (all A tokens), the A autoregressive decoder iterations (decode.py:111-153) and the categorical
+// sampling with no workgroup barrier at all.  The rollout is a chain of dependent small ops, so what matters is the
+// number of dependent memory round trips per step, not bandwidth or flops (measured: ~2 us per dependent global
+// access, in-kernel stage timing, profiles/):
+//   * activations live in REGISTERS in a feature-major layout -- lane (env = l & 15, kq = l >> 4) holds the 16 features
+//     n = 16 g + 4 kq + r (g, r in 0..3) of one env's 64-wide row.  A dense layer is computed transposed,
+//     Y^T[n][env] = sum_k Wt[n][k] X^T[k][env], on v_mfma_f32_16x16x4_f32 with W as the A operand (float4 fragments
+//     straight from L2, prefetched 4 column groups ahead) and the activation registers as the B operand; the
+//     accumulator comes out in the same feature-major layout, so dense layers, RMSNorm (16 in-lane adds + 2
+//     xor-shuffles), GELU, residuals and positional encodings chain without touching LDS or memory;
+//   * the retention step works on one env at a time with the whole 64x64 state in the wave's registers (lane ->
+//     columns c4..c4+3 of rows rg + 4i), 16 float4 loads in flight and the next state prefetched; q/k/v/g rows reach
+//     the state layout through a small per-wave LDS tile; GroupNorm + swish gate are fused behind it;
+//   * sampling: the logits never leave registers; gumbel noise from the JAX threefry stream (rl.hip: k_sample).
+// Only what later agents / the training pass need goes to (L2-resident) scratch: this step's k, v rows, obs_rep, q2.
+#include "common.hpp"
+#include <string.h>
+
+namespace magpo {
+
+constexpr int AE = 64;           // embed dim
+constexpr float EPSN = 1e-6f;
+constexpr float FMIN_ = -3.4028234663852886e38f;
+constexpr int MAXB = 4;          // max blocks
+constexpr int MAXA = 8;          // max agents of the fused path (token staging registers)
+constexpr int QP = 272;          // LDS pitch of a [q|k|v|g] token row: 16 mod 64 -> the (env, kq) float4 pattern is conflict-minimal
+constexpr int UP = 80;           // LDS pitch of a 64-wide row
+
+struct ActBlk {
+  const float *qkvg_t, *wo_t, *ln1, *ln2, *gn_g, *gn_b;                                     // encoder block
+  const float *qkvg1_t, *wo1_t, *dln1, *gn1_g, *gn1_b;                                       // decoder self-retention
+  const float *q2_t, *kvg2_t, *wo2_t, *dln2, *dln3, *gn2_g, *gn2_b;                           // decoder cross-retention
+  float *qkvg1, *q2, *kvg2;                                                                   // scratch [N*A][256|64|192]
+};
+struct ActArgs {
+  int N, A, K, F, nb, nh, hs, gs, npos, value_only;
+  const float* obs; const int* pos; const unsigned char* mask; const uint32_t* keys_dev; uint32_t keys[16][2];
+  const float *s_obs, *W_obs, *s_encln, *W_act, *s_decln;
+  const float *vh0_t, *vh0_b, *vh_s, *vh_w, *vh_b1;
+  const float *h0_t, *h0_b, *h_s, *h1_t, *h1_b;
+  const float* pe;
+  float kappa[4];
+  ActBlk blk[MAXB];
+  float *S_enc, *S_d1, *S_d2;     // [nb][nh][N][4096]
+  float *xn, *kin, *qkvg, *u, *y, *rep, *reppe, *hv;    // scratch [N*A][64 | 256]  (used: xn, qkvg, u, rep)
+  float *xa, *kin1, *y1, *c, *cpe, *y2, *xo, *xope, *hp, *hn, *logits, *u1, *u2; int* prev;   // unused by this kernel (table layout kept)
+  int* action; float* logp; float* value;
+};
+
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// order this wave's LDS / global writes before its later reads by other lanes (single-wave workgroup)
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- feature-major rows: reg j <-> feature 16 (j >> 2) + 4 kq + (j & 3) -------------------------------------------
+struct Row { float v[16]; };
+__device__ __forceinline__ Row row_load(const float* p /* row base */, int kq) {
+  Row r;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { const float4 t = ld4g(p + 16 * g + 4 * kq); r.v[4 * g] = t.x; r.v[4 * g + 1] = t.y; r.v[4 * g + 2] = t.z; r.v[4 * g + 3] = t.w; }
+  return r;
+}
+__device__ __forceinline__ void row_store(float* p, int kq, const Row& r) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) st4g(p + 16 * g + 4 * kq, make_float4(r.v[4 * g], r.v[4 * g + 1], r.v[4 * g + 2], r.v[4 * g + 3]));
+}
+__device__ __forceinline__ float row_sum(const Row& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += r.v[j];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+__device__ __forceinline__ Row row_add(const Row& a, const Row& b) {
+  Row r;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r.v[j] = a.v[j] + b.v[j];
+  return r;
+}
+__device__ __forceinline__ Row row_rms(const Row& x, const float* scale, int kq) {
+  Row q;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) q.v[j] = x.v[j] * x.v[j];
+  const float rstd = rsqrtf(row_sum(q) * (1.0f / 64.0f) + EPSN);
+  const Row s = row_load(scale, kq);
+  Row r;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r.v[j] = x.v[j] * rstd * s.v[j];
+  return r;
+}
+__device__ __forceinline__ Row row_gelu(const Row& x) {
+  Row r;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r.v[j] = gelu_tanh(x.v[j]);
+  return r;
+}
+
+// ---- dense layer, transposed on 16x16x4 fp32 MFMA: out(g, acc) receives features 16 g + 4 kq + (0..3) of every env ------
+template <int NG, class OUT>
+__device__ __forceinline__ void wgemm(const Row& x, const float* __restrict__ Wt, int m, int kq, OUT&& out) {
+  constexpr int PD = NG < 4 ? NG : 4;
+  float4 w[PD][4];
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) w[p][gk] = ld4g(Wt + (long)(16 * p + m) * AE + 16 * gk + 4 * kq);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].x, x.v[4 * gk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].y, x.v[4 * gk + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].z, x.v[4 * gk + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].w, x.v[4 * gk + 3], acc, 0, 0, 0);
+    }
+    if (g + PD < NG) {
+#pragma unroll
+      for (int gk = 0; gk < 4; ++gk) w[g % PD][gk] = ld4g(Wt + (long)(16 * (g + PD) + m) * AE + 16 * gk + 4 * kq);
+    }
+    out(g, acc);
+  }
+}
+// 64 -> 64 layer into registers (+ optional bias)
+__device__ __forceinline__ Row dense64(const Row& x, const float* __restrict__ Wt, const float* __restrict__ bias, int m, int kq) {
+  Row y;
+  wgemm<4>(x, Wt, m, kq, [&](int g, f32x4 acc) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = ld4g(bias + 16 * g + 4 * kq);
+    y.v[4 * g] = acc[0] + b.x; y.v[4 * g + 1] = acc[1] + b.y; y.v[4 * g + 2] = acc[2] + b.z; y.v[4 * g + 3] = acc[3] + b.w;
+  });
+  return y;
+}
+
+// ---- recurrent retention over the wave's envs, one (env, head) state at a time ------------------------------------
+//   S_eff = kappa * S + sum_{a < ntok} k_a^T v_a ; u_a = swish(g_a) * GroupNorm(q_a S_eff) for a in [ret_from, ntok)
+// ENC: ntok = A, all tokens staged from the global [q|k|v|g] rows `hist`; u rows -> global uout[(env*A + a)*64].
+// DEC: ntok = i + 1, tokens a < i staged from the global k|v history (hist rows, columns hcol..hcol+127), token i read
+//      from the wave's TQ tile; u -> LDS tile U[env].
+template <bool ENC, int NA>
+__device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* __restrict__ S0 /* head 0 of this block */, long NS,
+                                         const ActArgs& a, int env0, int nvalid, int i, const float* __restrict__ hist, long ldh,
+                                         int hcol, float* __restrict__ uout, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, int write_state) {
+  const int lane = threadIdx.x, c4 = 4 * (lane & 15), rg = lane >> 4;
+  const int A = a.A, nh = a.nh, hs = a.hs, gs = a.gs;
+  const int ntok = ENC ? A : i + 1, ret_from = ENC ? 0 : i, nstage = ENC ? A : i;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool colin = c4 < hs;
+  float4 gam = z4, bet = z4;
+  if (colin) { gam = ld4g(gamma + c4); bet = ld4g(beta + c4); }
+  float4 s[16], sn[16], hreg[NA];
+  auto load_state = [&](int pair) {
+    const int e = pair / nh, h = pair - e * nh;
+    const float* Se = S0 + (long)h * NS + (long)(env0 + e) * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sn[r] = ld4g(Se + (rg + 4 * r) * 64 + c4);
+  };
+  auto load_tokens = [&](int e) {
+    const long row0 = (long)(env0 + e) * A;
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+      if (t < nstage) {
+        if (ENC) hreg[t] = ld4g(hist + (row0 + t) * ldh + 4 * lane);
+        else if (lane < 32) hreg[t] = ld4g(hist + (row0 + t) * ldh + hcol + 4 * lane);
+      }
+    }
+  };
+  load_state(0);
+  load_tokens(0);
+  const int npairs = nvalid * nh;
+  for (int pair = 0; pair < npairs; ++pair) {
+    const int e = pair / nh, h = pair - e * nh, o = h * hs;
+    const long row0 = (long)(env0 + e) * A;
+    float* Se = S0 + (long)h * NS + (long)(env0 + e) * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = sn[r];
+    if (pair + 1 < npairs) load_state(pair + 1);
+    if (h == 0) {
+      __builtin_amdgcn_wave_barrier();   // reads of the previous env's tokens are done (in-order DS ops of one wave)
+#pragma unroll
+      for (int t = 0; t < NA; ++t) {
+        if (t < nstage) {
+          if (ENC) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[t];
+          else if (lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[t];
+        }
+      }
+      if (e + 1 < nvalid) load_tokens(e + 1);
+      wsync();
+    }
+    const float decay = a.kappa[h];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r].x *= decay; s[r].y *= decay; s[r].z *= decay; s[r].w *= decay; }
+    for (int t = 0; t < ntok; ++t) {
+      const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
+      const float4 vv = colin ? *reinterpret_cast<const float4*>(tk + 128 + o + c4) : z4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int sr = rg + 4 * r;
+        const float kk = sr < hs ? tk[64 + o + sr] : 0.f;
+        s[r].x += kk * vv.x; s[r].y += kk * vv.y; s[r].z += kk * vv.z; s[r].w += kk * vv.w;
+      }
+    }
+    if (write_state) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st4g(Se + (rg + 4 * r) * 64 + c4, s[r]);
+    }
+    for (int t = ret_from; t < ntok; ++t) {
+      const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
+      float4 p = z4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int sr = rg + 4 * r;
+        const float qq = sr < hs ? tk[o + sr] : 0.f;
+        p.x += qq * s[r].x; p.y += qq * s[r].y; p.z += qq * s[r].z; p.w += qq * s[r].w;
+      }
+      p.x += __shfl_xor(p.x, 16, 64); p.y += __shfl_xor(p.y, 16, 64); p.z += __shfl_xor(p.z, 16, 64); p.w += __shfl_xor(p.w, 16, 64);
+      p.x += __shfl_xor(p.x, 32, 64); p.y += __shfl_xor(p.y, 32, 64); p.z += __shfl_xor(p.z, 32, 64); p.w += __shfl_xor(p.w, 32, 64);
+      // fused epilogue (retention.py:289-294): GroupNorm over groups of gs channels, then the swish gate
+      float s1 = (p.x + p.y) + (p.z + p.w), s2 = (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
+      for (int x = gs >> 3; x > 0; x >>= 1) { s1 += __shfl_xor(s1, x, 64); s2 += __shfl_xor(s2, x, 64); }
+      const float mu = s1 / (float)gs, m2 = s2 / (float)gs;
+      const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
+      if (colin && rg == 0) {
+        const float4 g4 = *reinterpret_cast<const float4*>(tk + 192 + o + c4);
+        float4 o4;
+        o4.x = swishf_(g4.x) * ((p.x - mu) * rstd * gam.x + bet.x);
+        o4.y = swishf_(g4.y) * ((p.y - mu) * rstd * gam.y + bet.y);
+        o4.z = swishf_(g4.z) * ((p.z - mu) * rstd * gam.z + bet.z);
+        o4.w = swishf_(g4.w) * ((p.w - mu) * rstd * gam.w + bet.w);
+        if (ENC) st4g(uout + (row0 + t) * AE + o + c4, o4);
+        else *reinterpret_cast<float4*>(U + e * UP + o + c4) = o4;
+      }
+    }
+  }
+}
+
+// Optional in-kernel stage timing (debug builds only: -DMAGPO_ACT_PROF): wall-clock ticks (100 MHz) per stage class
+// [0 dense/rows, 1 retention, 2 sampling, 3 encoder total] summed over every 64th wave.
+#ifdef MAGPO_ACT_PROF
+__device__ unsigned long long g_act_prof[8];
+#define PROF(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { unsigned long long t_ = wall_clock64(); \
+  atomicAdd(&g_act_prof[k], t_ - t_last); t_last = t_; } } while (0)
+#else
+#define PROF(k)
+#endif
+
+template <int EPW, int NA>
+__global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* TQ = smem;                  // [EPW][QP]  this iteration's [q|k|v|g] rows, one per env
+  float* HK = TQ + EPW * QP;         // [A][QP]    staged token rows of the env being processed
+  float* U = HK + a.A * QP;          // [EPW][UP]  gated retention output, one row per env
+  float* XS = U + EPW * UP;          // [EPW][UP]  block input x parked across the self-retention (register relief)
+#ifdef MAGPO_ACT_PROF
+  unsigned long long t_last = wall_clock64();
+#endif
+  const int lane = threadIdx.x, env = lane & 15, kq = lane >> 4, m = env;
+  const int env0 = blockIdx.x * EPW;
+  const int nvalid = min(EPW, a.N - env0);
+  const bool valid = env < nvalid;
+  const int le = valid ? env : 0;
+  const long ge = env0 + le;   // invalid lanes shadow env 0 of the wave (reads stay legal, nothing is stored)
+  const int A = a.A, nb = a.nb;
+  const long NS = (long)a.N * 4096;
+  int p_ = a.pos[ge];
+  p_ = p_ < 0 ? 0 : (p_ >= a.npos ? a.npos - 1 : p_);
+  const Row pe = row_load(a.pe + (long)p_ * AE, kq);
+
+  // ---------------- encoder over the A tokens of the step (act_encoder_fn, encode.py:58-84)
+  for (int b = 0; b < nb; ++b) {
+    const ActBlk& B = a.blk[b];
+    for (int t = 0; t < A; ++t) {
+      const long row = ge * A + t;
+      Row x;
+      if (b == 0) {   // x = rms(gelu(rmsnorm_F(obs) * s_obs @ W_obs)) * s_encln   (sable_network.py:93-101,126,132)
+        const float* o = a.obs + row * a.F;
+        float ms = 0.f;
+        for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
+        const float rstd = rsqrtf(ms / (float)a.F + EPSN);
+        Row z;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z.v[j] = 0.f;
+        for (int f = 0; f < a.F; ++f) {
+          const float of = o[f] * rstd * a.s_obs[f];
+          const Row w = row_load(a.W_obs + f * AE, kq);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) z.v[j] += of * w.v[j];
+        }
+        x = row_rms(row_gelu(z), a.s_encln, kq);
+      } else {        // x = ln(rep of the previous block) (shared self.ln, sable_network.py:150)
+        x = row_rms(row_load(a.rep + row * AE, kq), a.s_encln, kq);
+      }
+      if (valid) row_store(a.xn + row * AE, kq, x);
+      const Row kin = row_add(x, pe);
+      float* qrow = a.qkvg + row * 256;
+      wgemm<16>(kin, B.qkvg_t, m, kq, [&](int g, f32x4 acc) {
+        if (valid) st4g(qrow + 16 * g + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));
+      });
+    }
+    wsync();
+    PROF(0);
+    ret_pass<true, NA>(TQ, HK, U, a.S_enc + (long)b * a.nh * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, B.gn_g, B.gn_b, 1);
+    wsync();
+    PROF(1);
+    for (int t = 0; t < A; ++t) {
+      const long row = ge * A + t;
+      const Row y = dense64(row_load(a.u + row * AE, kq), B.wo_t, nullptr, m, kq);
+      const Row x = row_load(a.xn + row * AE, kq);
+      const Row rep = row_rms(row_rms(row_add(x, y), B.ln1, kq), B.ln2, kq);
+      if (valid) row_store(a.rep + row * AE, kq, rep);
+      if (b == nb - 1) {
+        const Row hv = row_rms(row_gelu(dense64(rep, a.vh0_t, a.vh0_b, m, kq)), a.vh_s, kq);
+        const Row w = row_load(a.vh_w, kq);
+        Row hw;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hw.v[j] = hv.v[j] * w.v[j];
+        const float val = row_sum(hw) + a.vh_b1[0];
+        if (valid && kq == 0) a.value[row] = val;
+        if (!a.value_only) {
+          const Row reppe = row_add(rep, pe);
+          for (int db = 0; db < nb; ++db) {
+            const Row q2 = dense64(reppe, a.blk[db].q2_t, nullptr, m, kq);
+            if (valid) row_store(a.blk[db].q2 + row * AE, kq, q2);
+          }
+        }
+      }
+    }
+    wsync();
+    PROF(0);
+  }
+  PROF(3);
+  if (a.value_only) return;   // uniform: bootstrap value only (rec_magpo.py:202-208)
+
+  // ---------------- autoregressive decoder (decode.py:111-153): token i of every env
+  int prev = 0;   // 0 = start token, action + 1 afterwards
+  for (int i = 0; i < A; ++i) {
+    const int last = i == A - 1;
+    const long row = ge * A + i;
+    Row xo;
+    for (int b = 0; b < nb; ++b) {
+      const ActBlk& B = a.blk[b];
+      Row xin;
+      if (b == 0) xin = row_rms(row_gelu(row_load(a.W_act + (long)prev * AE, kq)), a.s_decln, kq);   // action embedding (:258-267)
+      else xin = xo;
+      if (valid) row_store(XS + env * UP, kq, xin);
+      {
+        const Row kin = row_add(xin, pe);
+        float* hrow = B.qkvg1 + row * 256;
+        wgemm<16>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
+          const float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          if (valid) {
+            *reinterpret_cast<float4*>(TQ + env * QP + 16 * g + 4 * kq) = v4;
+            if (g >= 4 && g < 12) st4g(hrow + 16 * g + 4 * kq, v4);   // k, v of this token: history for the later agents
+          }
+        });
+      }
+      wsync();
+      PROF(0);
+      ret_pass<false, NA>(TQ, HK, U, a.S_d1 + (long)b * a.nh * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, B.gn1_g, B.gn1_b, last);
+      wsync();
+      PROF(1);
+      Row cpe;
+      {
+        const Row y1 = dense64(row_load(U + le * UP, kq), B.wo1_t, nullptr, m, kq);
+        cpe = row_add(row_rms(row_add(row_load(XS + le * UP, kq), y1), B.dln1, kq), pe);
+      }
+      {
+        // cross-retention: q from the encoder (q2 row of this token), k/v/g from the decoder stream
+        if (valid) {
+          const Row q2 = row_load(B.q2 + row * AE, kq);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(TQ + env * QP + 16 * g + 4 * kq) = make_float4(q2.v[4 * g], q2.v[4 * g + 1], q2.v[4 * g + 2], q2.v[4 * g + 3]);
+        }
+        float* hrow = B.kvg2 + row * 192;
+        wgemm<12>(cpe, B.kvg2_t, m, kq, [&](int g, f32x4 acc) {
+          const float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          if (valid) {
+            *reinterpret_cast<float4*>(TQ + env * QP + 64 + 16 * g + 4 * kq) = v4;
+            if (g < 8) st4g(hrow + 16 * g + 4 * kq, v4);
+          }
+        });
+      }
+      wsync();
+      PROF(0);
+      ret_pass<false, NA>(TQ, HK, U, a.S_d2 + (long)b * a.nh * NS, NS, a, env0, nvalid, i, B.kvg2, 192, 0, nullptr, B.gn2_g, B.gn2_b, last);
+      wsync();
+      PROF(1);
+      {
+        const Row y2 = dense64(row_load(U + le * UP, kq), B.wo2_t, nullptr, m, kq);
+        const Row repi = row_load(a.rep + row * AE, kq);
+        xo = row_rms(row_rms(row_add(repi, y2), B.dln2, kq), B.dln3, kq);
+      }
+    }
+    // head (sable_network.py:296-319) and sampling
+    const Row hn = row_rms(row_gelu(dense64(xo, a.h0_t, a.h0_b, m, kq)), a.h_s, kq);
+    Row lg;
+    wgemm<4>(hn, a.h1_t, m, kq, [&](int g, f32x4 acc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int n = 16 * g + 4 * kq + r; lg.v[4 * g + r] = acc[r] + (n < a.K ? a.h1_b[n] : 0.f); }
+    });
+    PROF(0);
+    const uint32_t k0 = a.keys_dev ? a.keys_dev[2 * i] : a.keys[i][0], k1 = a.keys_dev ? a.keys_dev[2 * i + 1] : a.keys[i][1];
+    const unsigned char* mk = a.mask ? a.mask + (ge * A + i) * a.K : nullptr;
+    float xv[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n = 16 * (j >> 2) + 4 * kq + (j & 3);
+      xv[j] = (n < a.K) ? ((mk && !mk[n]) ? FMIN_ : lg.v[j]) : -INFINITY;
+      mx = fmaxf(mx, xv[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n = 16 * (j >> 2) + 4 * kq + (j & 3);
+      if (n < a.K) se += expf(xv[j] - mx);
+    }
+    se += __shfl_xor(se, 16, 64);
+    se += __shfl_xor(se, 32, 64);
+    const float lse = mx + logf(se);
+    float best = -INFINITY, best_lp = 0.f;
+    int arg = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n = 16 * (j >> 2) + 4 * kq + (j & 3);
+      if (n < a.K) {
+        const float lp = xv[j] - lse;
+        const uint32_t bits = random_bits32(k0, k1, (uint32_t)(ge * a.K + n));
+        const float f = __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f;
+        const float uu = fmaxf(1.17549435e-38f, f + 1.17549435e-38f);
+        const float gmb = (float)(-log(-log((double)uu)));
+        const float vv = gmb + lp;
+        if (vv > best || (vv == best && n < arg)) { best = vv; arg = n; best_lp = lp; }
+      }
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {   // first-max over the 4 lanes of the env
+      const float ob = __shfl_xor(best, sh, 64), olp = __shfl_xor(best_lp, sh, 64);
+      const int oa = __shfl_xor(arg, sh, 64);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; best_lp = olp; }
+    }
+    if (valid && kq == 0) { a.action[row] = arg; a.logp[row] = best_lp; }
+    prev = arg + 1;
+    PROF(2);
+  }
+}
+
+}  // namespace magpo
+
+using namespace magpo;
+
+// Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
+//   dims_host[10] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only}; kappa_host[4]; keys_host [A][2] or NULL (then
+//   ptrs[3] = device key table);  ptrs_host[48] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
+extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs,
+                               int nptrs, const void* const* blk_ptrs, int nblk_ptrs, hipStream_t st) {
+  ActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.N = dims_host[0]; a.A = dims_host[1]; a.K = dims_host[2]; a.F = dims_host[3]; a.nb = dims_host[4]; a.nh = dims_host[5];
+  a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9];
+  if (a.N <= 0) return MAGPO_OK;
+  if (a.A < 1 || a.A > MAXA || a.nb < 1 || a.nb > MAXB || a.nh < 1 || a.nh > 4 || a.K < 1 || a.K > 64 || a.F < 1 || a.hs * a.nh != AE ||
+      a.gs < 4 || a.gs > a.hs || (a.gs & (a.gs - 1)) || a.npos < 1) {
+    set_error("magpo_sable_act: unsupported shape (1 <= A <= 8, n_block <= 4, n_head in {1,2,4}, K <= 64)");
+    return MAGPO_EINVAL;
+  }
+  if (nptrs != 48 || nblk_ptrs != 21 * a.nb) { set_error("magpo_sable_act: pointer table size mismatch"); return MAGPO_EINVAL; }
+  for (int i = 0; i < 4; ++i) a.kappa[i] = kappa_host[i];
+  if (keys_host) for (int i = 0; i < a.A; ++i) { a.keys[i][0] = keys_host[2 * i]; a.keys[i][1] = keys_host[2 * i + 1]; }
+  int p = 0;
+#define P(T, f) a.f = (T)ptrs[p++];
+  P(const float*, obs) P(const int*, pos) P(const unsigned char*, mask) P(const uint32_t*, keys_dev)
+  P(const float*, s_obs) P(const float*, W_obs) P(const float*, s_encln) P(const float*, W_act) P(const float*, s_decln)
+  P(const float*, vh0_t) P(const float*, vh0_b) P(const float*, vh_s) P(const float*, vh_w) P(const float*, vh_b1)
+  P(const float*, h0_t) P(const float*, h0_b) P(const float*, h_s) P(const float*, h1_t) P(const float*, h1_b)
+  P(const float*, pe)
+  P(float*, S_enc) P(float*, S_d1) P(float*, S_d2)
+  P(float*, xn) P(float*, kin) P(float*, qkvg) P(float*, u) P(float*, y) P(float*, rep) P(float*, reppe) P(float*, hv)
+  P(float*, xa) P(float*, kin1) P(float*, y1) P(float*, c) P(float*, cpe) P(float*, y2) P(float*, xo) P(float*, xope) P(float*, hp)
+  P(float*, hn) P(float*, logits) P(float*, u1) P(float*, u2) P(int*, prev)
+  P(int*, action) P(float*, logp) P(float*, value)
+#undef P
+  if (!keys_host && !a.keys_dev && !a.value_only) { set_error("magpo_sable_act: no sampling keys"); return MAGPO_EINVAL; }
+  for (int b = 0; b < a.nb; ++b) {
+    const void* const* q = blk_ptrs + 21 * b;
+    ActBlk& B = a.blk[b];
+    B.qkvg_t = (const float*)q[0]; B.wo_t = (const float*)q[1]; B.ln1 = (const float*)q[2]; B.ln2 = (const float*)q[3];
+    B.gn_g = (const float*)q[4]; B.gn_b = (const float*)q[5];
+    B.qkvg1_t = (const float*)q[6]; B.wo1_t = (const float*)q[7]; B.dln1 = (const float*)q[8]; B.gn1_g = (const float*)q[9]; B.gn1_b = (const float*)q[10];
+    B.q2_t = (const float*)q[11]; B.kvg2_t = (const float*)q[12]; B.wo2_t = (const float*)q[13]; B.dln2 = (const float*)q[14]; B.dln3 = (const float*)q[15];
+    B.gn2_g = (const float*)q[16]; B.gn2_b = (const float*)q[17];
+    B.qkvg1 = (float*)q[18]; B.q2 = (float*)q[19]; B.kvg2 = (float*)q[20];
+  }
+  constexpr int EPW = 8;
+  const size_t lds = (size_t)((EPW + a.A) * QP + 2 * EPW * UP) * sizeof(float);
+  if (a.A <= 4) hipLaunchKernelGGL((k_sable_act<EPW, 4>), dim3((a.N + EPW - 1) / EPW), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL((k_sable_act<EPW, 8>), dim3((a.N + EPW - 1) / EPW), dim3(64), lds, st, a);
+  return check_launch("magpo_sable_act");
+}
+
+#ifdef MAGPO_ACT_PROF
+extern "C" int magpo_debug_act_prof(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_act_prof), sizeof(unsigned long long) * 8) != hipSuccess) return MAGPO_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_act_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
+  return MAGPO_OK;
+}
+#endif

@@ -202,6 +202,7 @@ class MagpoLearner:
             g.cur = 0
 
     # ------------------------------------------------------------------ rollout (rec_magpo.py:126-212)
+    fused_act = True  # one launch per env step for the whole Sable acting step (csrc/act_fused.hip)
     use_graph = True  # replay the whole rollout as one HIP graph (removes ~11K host launches per rollout)
 
     def rollout(self):
@@ -262,7 +263,8 @@ class MagpoLearner:
         g.policy_h0.copy_(g.policy_h[g.cur])
         for t in range(T):
             obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
-            self.guider.act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t])
+            act = self.guider.act_fused if self.fused_act else self.guider.act
+            act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t])
             h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
             self.actor.step(obs, h_in, done_prev, h_out)
             g.cur = 1 - g.cur
@@ -274,7 +276,8 @@ class MagpoLearner:
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])
             g.cur = 0
-        self.guider.act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
+        act = self.guider.act_fused if self.fused_act else self.guider.act
+        act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
         L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], g.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
                self.sys.gamma, self.sys.gae_lambda, st)
 

@@ -73,6 +73,7 @@ class SableGuider:
             self.L.call("magpo_pe_table", self.pe, max_pos, E, self._st())
         self.wt: Dict[str, torch.Tensor] = {}
         self.b = _Bufs(device)
+        self._act_tabs: Dict[tuple, tuple] = {}
         # weight-gradient GEMMs run on a side stream: they are off the critical path of the backward chain
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.overlap_wgrad = False  # opt-in (bench.py --overlap): ~0.5 %, but per-kernel timings then include contention
@@ -267,6 +268,57 @@ class SableGuider:
                 k0, k1, kdev = int(sample_keys[i][0]), int(sample_keys[i][1]), None
             L.call("magpo_sample_categorical", logits, E, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
                    k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
+
+    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False):
+        """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a workgroup carries
+        32 envs through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64]."""
+        A, K, F, nb, nh = self.A, self.K, self.F, self.nb, self.nh
+        if A > 8:   # token staging registers of the fused kernel: larger teams take the kernel-by-kernel path
+            return self.act(obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=mask, value_only=value_only)
+        N = obs.shape[0]
+        R = N * A
+        v, b = self.v, self.b
+        s_enc, s_d1, s_d2 = states
+        if value_only:  # bootstrap value (rec_magpo.py:202-208): states must not change
+            s_enc = b.get("a_senc_tmp", tuple(s_enc.shape)).copy_(s_enc)
+        kdev = sample_keys if torch.is_tensor(sample_keys) else None
+        cache_key = (N, bool(value_only), obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
+                     None if kdev is None else kdev.data_ptr(), s_enc.data_ptr(), s_d1.data_ptr(), s_d2.data_ptr(),
+                     None if action_out is None else action_out.data_ptr(), None if logp_out is None else logp_out.data_ptr(),
+                     value_out.data_ptr())
+        tabs = self._act_tabs.get(cache_key)
+        if tabs is None:
+            g = lambda n, w=E, rows=R: b.get("f_" + n, (rows, w))
+            ptr = lambda t: 0 if t is None else t.data_ptr()
+            glob = [obs, pos, mask, kdev,
+                    v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], v["enc.ln.scale"], v["dec.act.kernel"], v["dec.ln.scale"],
+                    self.wt["vh0"], v["enc.head.dense0.bias"], v["enc.head.norm.scale"], v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
+                    self.wt["h0"], v["dec.head.dense0.bias"], v["dec.head.norm.scale"], self.wt["h1"], v["dec.head.dense1.bias"],
+                    self.pe, s_enc, s_d1, s_d2,
+                    g("xn"), g("kin"), g("qkvg", 4 * E), g("u"), g("y"), g("rep"), g("reppe"), g("hv"),
+                    g("xa", E, N), g("kin1", E, N), g("y1", E, N), g("c", E, N), g("cpe", E, N), g("y2", E, N), g("xo", E, N),
+                    g("xope", E, N), g("hp", E, N), g("hn", E, N), g("logits", E, N), g("u1"), g("u2"),
+                    b.get("f_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out]
+            blk = []
+            for k in range(nb):
+                e, d = f"enc.block{k}.", f"dec.block{k}."
+                blk += [self.wt[f"qkvg{k}"], self.wt[f"wo{k}"], v[e + "ln1.scale"], v[e + "ln2.scale"], v[e + "retn.gn.scale"], v[e + "retn.gn.bias"],
+                        self.wt[f"qkvg1{k}"], self.wt[f"wo1{k}"], v[d + "ln1.scale"], v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"],
+                        self.wt[f"q2{k}"], self.wt[f"kvg2{k}"], self.wt[f"wo2{k}"], v[d + "ln2.scale"], v[d + "ln3.scale"],
+                        v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
+                        g(f"qkvg1_{k}", 4 * E), g(f"q2_{k}"), g(f"kvg2_{k}", 3 * E)]
+            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0], dtype=np.int32),
+                    np.array((self.kappas + [0.0] * 4)[:4], dtype=np.float32),
+                    np.array([ptr(t) for t in glob], dtype=np.uint64), np.array([ptr(t) for t in blk], dtype=np.uint64))
+            if len(self._act_tabs) > 4096:
+                self._act_tabs.clear()
+            self._act_tabs[cache_key] = tabs
+        dims, kap, gp, bp = tabs
+        keys = None
+        if kdev is None and not value_only:
+            keys = np.ascontiguousarray(np.asarray(sample_keys, dtype=np.uint32).reshape(A, 2))
+        self.L.call("magpo_sable_act", dims.ctypes.data, kap.ctypes.data, None if keys is None else keys.ctypes.data,
+                    gp.ctypes.data, int(gp.size), bp.ctypes.data, int(bp.size), self._st())
 
     # ------------------------------------------------------------------ training forward (chunkwise form)
     def train_fwd(self, obs, prev_idx, pos, dones, s0, seq_env, nseq: int, T: int):

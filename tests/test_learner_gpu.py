@@ -124,3 +124,27 @@ def test_graph_replay_equals_eager_rollout():
             assert torch.equal(ls[0].traj[k], ls[1].traj[k]), (it, k)
         assert torch.equal(ls[0].guider.P.flat, ls[1].guider.P.flat) and np.array_equal(ls[0].key, ls[1].key)
     assert not ls[1].groups[0].graph_failed
+
+
+@pytest.mark.parametrize("A,K,N,nb,nh", [(4, 20, 70, 1, 1), (5, 15, 33, 2, 2), (16, 6, 40, 1, 4)])
+def test_fused_act_equals_kernel_composition(A, K, N, nb, nh):
+    """k_sable_act (one launch per env step) against the kernel-by-kernel acting path: same actions, and values /
+    log-probs / retention states to fp32 rounding, over ragged workgroups (N not a multiple of 32) and episode ends."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    sysc = SystemConfig(rollout_length=12, ppo_epochs=1, num_minibatches=1)
+    key = host_split(prng_key(11), 4)[0]
+    ls = []
+    for fused in (False, True):
+        l = MagpoLearner(CoordSumConfig(A, K, 7, 3 * K), N, sysc, "cuda", net_seed=9, wgrad_groups=4, n_block=nb, n_head=nh)
+        l.fused_act, l.use_graph = fused, False
+        l.setup(key)
+        l.rollout()
+        ls.append(l)
+    a, b = ls
+    assert torch.equal(a.traj["action"], b.traj["action"])
+    assert bool(a.traj["done"].any())
+    for k in ("value", "log_prob", "adv"):
+        close(b.traj[k], a.traj[k], 1e-5, 1e-6, k)
+    close(b.last_val, a.last_val, 1e-5, 1e-6, "last_val")
+    for x, y in zip(a.sable_hs, b.sable_hs):
+        close(y, x, 1e-5, 1e-6, "sable state")
