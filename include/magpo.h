@@ -114,7 +114,8 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
  * dims_host[10] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only}; kappa_host[4] (per head);
  * keys_host [A][2] sampling keys by value, or NULL with ptrs[3] = device key table (static arguments for graph replay);
  * ptrs_host[48]: obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
- *   pe | S_enc S_d1 S_d2 ([n_block][n_head][N][64][64], updated in place) | scratch xn kin qkvg u y rep reppe hv ([N*A] rows) |
+ *   pe | S_enc S_d1 S_d2 ([n_block][n_head][N][64][64], updated in place) | scratch xn ([N*A] rows), done [N] u8 or NULL (envs whose
+ *   episode just ended: their carried states read as zero, rec_magpo.py:164-169), scratch qkvg u y rep reppe hv ([N*A] rows) |
  *   xa kin1 y1 c cpe y2 xo xope hp hn logits ([N] rows) | u1 u2 ([N*A] rows) | prev [N][A] i32 | action [N][A] i32, logp, value [N][A];
  * blk_ptrs_host[21 * n_block]: qkvg_t wo_t ln1 ln2 gn_g gn_b | qkvg1_t wo1_t dln1 gn1_g gn1_b | q2_t kvg2_t wo2_t dln2 dln3 gn2_g gn2_b |
  *   scratch qkvg1 [N*A][256], q2 [N*A][64], kvg2 [N*A][192].   (*_t = transposed weights as produced by magpo_transpose_pad) */

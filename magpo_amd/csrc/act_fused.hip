@@ -11,11 +11,12 @@
 //     accumulator comes out in the same feature-major layout, so dense layers, RMSNorm (16 in-lane adds + 2
 //     xor-shuffles), GELU, residuals and positional encodings chain without touching LDS or memory;
 //   * the retention step works on one env at a time with the whole 64x64 state in the wave's registers (lane ->
-//     columns c4..c4+3 of rows rg + 4i), 16 float4 loads in flight and the next state prefetched; q/k/v/g rows reach
+//     columns c4..c4+3 of rows 16 rg .. 16 rg + 15), with the next states prefetched several deep; q/k/v/g rows reach
 //     the state layout through a small per-wave LDS tile; GroupNorm + swish gate are fused behind it;
 //   * sampling: the logits never leave registers; gumbel noise from the JAX threefry stream (rl.hip: k_sample).
 // Only what later agents / the training pass need goes to (L2-resident) scratch: this step's k, v rows, obs_rep, q2.
 #include "common.hpp"
+#include <stdlib.h>
 #include <string.h>
 
 namespace magpo {
@@ -26,7 +27,8 @@ constexpr float FMIN_ = -3.4028234663852886e38f;
 constexpr int MAXB = 4;          // max blocks
 constexpr int MAXA = 8;          // max agents of the fused path (token staging registers)
 constexpr int QP = 272;          // LDS pitch of a [q|k|v|g] token row: 16 mod 64 -> the (env, kq) float4 pattern is conflict-minimal
-constexpr int UP = 80;           // LDS pitch of a 64-wide row
+constexpr int UP = 80;
+           // LDS pitch of a 64-wide row
 
 struct ActBlk {
   const float *qkvg_t, *wo_t, *ln1, *ln2, *gn_g, *gn_b;                                     // encoder block
@@ -44,18 +46,67 @@ struct ActArgs {
   float kappa[4];
   ActBlk blk[MAXB];
   float *S_enc, *S_d1, *S_d2;     // [nb][nh][N][4096]
-  float *xn, *kin, *qkvg, *u, *y, *rep, *reppe, *hv;    // scratch [N*A][64 | 256]  (used: xn, qkvg, u, rep)
+  float *xn; const unsigned char* done; float *qkvg, *u, *y, *rep, *reppe, *hv;    // scratch [N*A][64 | 256]  (used: xn, qkvg, u, rep); done [N] or NULL
   float *xa, *kin1, *y1, *c, *cpe, *y2, *xo, *xope, *hp, *hn, *logits, *u1, *u2; int* prev;   // unused by this kernel (table layout kept)
   int* action; float* logp; float* value;
 };
 
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming accesses for the retention states (each byte is touched once per pass): keep them from displacing the
+// weights and the scratch rows in L2
+__device__ __forceinline__ float4 ld4nt(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4nt(float* p, float4 v) {
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
 // order this wave's LDS / global writes before its later reads by other lanes (single-wave workgroup)
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// LDS-only ordering inside one wave (DS ops of a wave execute in order; this only pins the compiler's schedule)
+__device__ __forceinline__ void lsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// swish gate on the hardware exp / rcp units (abs. error ~1e-7, inside the fp32 parity tolerance; cf. gru.hip)
+__device__ __forceinline__ float fswish(float x) { return x * fast_sigmoid(x); }
+
+// ---- cross-lane sums on the VALU (no LDS round trip): v_permlane{16,32}_swap for lane ^ 16 / lane ^ 32, DPP inside a 16-lane row
+__device__ __forceinline__ float xsum16(float v) {   // v[l] + v[l ^ 16]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float xsum32(float v) {   // v[l] + v[l ^ 32]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float xget32(float v, int lane) {   // v[l ^ 32]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(lane < 32 ? r[1] : r[0]);
+}
+__device__ __forceinline__ float xget16(float v, int lane) {   // v[l ^ 16]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float((lane & 16) ? r[0] : r[1]);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce sum over aligned groups of GL lanes (GL = 1, 2, 4, 8, 16) of a 16-lane row
+__device__ __forceinline__ float gsum(float v, int gl) {
+  if (gl >= 16) v += dpp_<0x140>(v);   // row_mirror
+  if (gl >= 8) v += dpp_<0x141>(v);    // row_half_mirror
+  if (gl >= 4) v += dpp_<0x4E>(v);     // quad_perm [2,3,0,1]
+  if (gl >= 2) v += dpp_<0xB1>(v);     // quad_perm [1,0,3,2]
+  return v;
 }
 
 // ---- feature-major rows: reg j <-> feature 16 (j >> 2) + 4 kq + (j & 3) -------------------------------------------
@@ -74,9 +125,7 @@ __device__ __forceinline__ float row_sum(const Row& r) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) s += r.v[j];
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
+  return xsum32(xsum16(s));
 }
 __device__ __forceinline__ Row row_add(const Row& a, const Row& b) {
   Row r;
@@ -139,121 +188,159 @@ __device__ __forceinline__ Row dense64(const Row& x, const float* __restrict__ W
   return y;
 }
 
+#ifdef MAGPO_ACT_PROF
+__device__ unsigned long long g_act_prof[16];
+#define RT_DECL() unsigned long long rt_acc[5] = {0, 0, 0, 0, 0}; unsigned long long rt_last = clock64();
+#define RT(k) do { unsigned long long t_ = clock64(); rt_acc[k] += t_ - rt_last; rt_last = t_; } while (0)
+#define RT_FLUSH() do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&g_act_prof[8 + k_], rt_acc[k_]); } } while (0)
+#else
+#define RT_DECL()
+#define RT(k)
+#define RT_FLUSH()
+#endif
+
 // ---- recurrent retention over the wave's envs, one (env, head) state at a time ------------------------------------
 //   S_eff = kappa * S + sum_{a < ntok} k_a^T v_a ; u_a = swish(g_a) * GroupNorm(q_a S_eff) for a in [ret_from, ntok)
 // ENC: ntok = A, all tokens staged from the global [q|k|v|g] rows `hist`; u rows -> global uout[(env*A + a)*64].
 // DEC: ntok = i + 1, tokens a < i staged from the global k|v history (hist rows, columns hcol..hcol+127), token i read
 //      from the wave's TQ tile; u -> LDS tile U[env].
-template <bool ENC, int NA>
+template <bool ENC, int NA, int NBUF, int NH>
 __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* __restrict__ S0 /* head 0 of this block */, long NS,
                                          const ActArgs& a, int env0, int nvalid, int i, const float* __restrict__ hist, long ldh,
                                          int hcol, float* __restrict__ uout, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, int write_state) {
+                                         const float* __restrict__ beta, int write_state, unsigned long long dmask) {
   const int lane = threadIdx.x, c4 = 4 * (lane & 15), rg = lane >> 4;
-  const int A = a.A, nh = a.nh, hs = a.hs, gs = a.gs;
+  const int A = a.A, nh = NH ? NH : a.nh, hs = NH ? AE / NH : a.hs, gs = NH ? AE / (NH * NH) : a.gs;   // NH = 0: run-time head count
   const int ntok = ENC ? A : i + 1, ret_from = ENC ? 0 : i, nstage = ENC ? A : i;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool colin = c4 < hs;
+  const bool colin = c4 < hs, rowin = 16 * rg < hs;
+  const float inv_gs = 1.0f / (float)gs;
+  const int cc = colin ? c4 : 0, rr = rowin ? 16 * rg : 0;   // clamped offsets for the unconditional LDS reads   // lane -> state columns c4..c4+3 of rows 16 rg .. 16 rg + 15
   float4 gam = z4, bet = z4;
   if (colin) { gam = ld4g(gamma + c4); bet = ld4g(beta + c4); }
-  float4 s[16], sn[16], hreg[NA];
-  auto load_state = [&](int pair) {
+  // NBUF state buffers rotate through the (env, head) pairs: NBUF - 1 states (16 KB each) are in flight behind the
+  // one being used.  The pipeline body is branch-free (clamped prefetch indices, predicated stores) so that the
+  // waits on the oldest loads leave the younger ones outstanding.
+  // Issue order matters: vmcnt retires in order, so a pair's token rows are loaded right behind its state -- both are
+  // first needed in the same iteration, and everything younger stays outstanding.
+  float4 buf[NBUF][16], hreg[NBUF][NA];
+  RT_DECL();
+  const int npairs = nvalid * nh;
+  auto prefetch = [&](float4 (&dst)[16], float4 (&tok)[NA], int pair) {
+    pair = min(pair, npairs - 1);
     const int e = pair / nh, h = pair - e * nh;
     const float* Se = S0 + (long)h * NS + (long)(env0 + e) * 4096;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sn[r] = ld4g(Se + (rg + 4 * r) * 64 + c4);
-  };
-  auto load_tokens = [&](int e) {
+    for (int r = 0; r < 16; ++r) dst[r] = ld4nt(Se + (16 * rg + r) * 64 + c4);
     const long row0 = (long)(env0 + e) * A;
 #pragma unroll
     for (int t = 0; t < NA; ++t) {
       if (t < nstage) {
-        if (ENC) hreg[t] = ld4g(hist + (row0 + t) * ldh + 4 * lane);
-        else if (lane < 32) hreg[t] = ld4g(hist + (row0 + t) * ldh + hcol + 4 * lane);
+        if (ENC) tok[t] = ld4g(hist + (row0 + t) * ldh + 4 * lane);
+        else if (lane < 32) tok[t] = ld4g(hist + (row0 + t) * ldh + hcol + 4 * lane);
       }
     }
   };
-  load_state(0);
-  load_tokens(0);
-  const int npairs = nvalid * nh;
-  for (int pair = 0; pair < npairs; ++pair) {
-    const int e = pair / nh, h = pair - e * nh, o = h * hs;
-    const long row0 = (long)(env0 + e) * A;
-    float* Se = S0 + (long)h * NS + (long)(env0 + e) * 4096;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = sn[r];
-    if (pair + 1 < npairs) load_state(pair + 1);
-    if (h == 0) {
-      __builtin_amdgcn_wave_barrier();   // reads of the previous env's tokens are done (in-order DS ops of one wave)
+  for (int j = 0; j < NBUF - 1; ++j) prefetch(buf[j], hreg[j], j);
+  for (int base = 0; base < npairs; base += NBUF) {
+#pragma unroll
+    for (int j = 0; j < NBUF; ++j) {
+      const int pair = base + j;
+      const bool live = pair < npairs;          // tail slots recompute the last pair and store nothing
+      const int pc = min(pair, npairs - 1);
+      const int e = pc / nh, h = pc - e * nh, o = h * hs;
+      const long row0 = (long)(env0 + e) * A;
+      float* Se = S0 + (long)h * NS + (long)(env0 + e) * 4096;
+      float4 (&s)[16] = buf[j];
+      RT(0);
+      prefetch(buf[(j + NBUF - 1) % NBUF], hreg[(j + NBUF - 1) % NBUF], pair + NBUF - 1);
+      // stage this env's token rows (rewritten per head: keeps the body branch-free)
+      __builtin_amdgcn_wave_barrier();   // reads of the previous pair's tokens are done (in-order DS ops of one wave)
 #pragma unroll
       for (int t = 0; t < NA; ++t) {
         if (t < nstage) {
-          if (ENC) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[t];
-          else if (lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[t];
+          if (ENC) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[j][t];
+          else if (lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[j][t];
         }
       }
-      if (e + 1 < nvalid) load_tokens(e + 1);
-      wsync();
-    }
-    const float decay = a.kappa[h];
+      lsync();   // LDS only: a workgroup-scope fence here would drain the prefetches (vmcnt(0))
+      RT(1);
+      // episode ended on the previous step: the carried state is zero (rec_magpo.py:164-169)
+      const float decay = ((dmask >> e) & 1ull) ? 0.f : a.kappa[h];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r].x *= decay; s[r].y *= decay; s[r].z *= decay; s[r].w *= decay; }
-    for (int t = 0; t < ntok; ++t) {
-      const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
-      const float4 vv = colin ? *reinterpret_cast<const float4*>(tk + 128 + o + c4) : z4;
+      for (int r = 0; r < 16; ++r) { s[r].x *= decay; s[r].y *= decay; s[r].z *= decay; s[r].w *= decay; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int sr = rg + 4 * r;
-        const float kk = sr < hs ? tk[64 + o + sr] : 0.f;
-        s[r].x += kk * vv.x; s[r].y += kk * vv.y; s[r].z += kk * vv.z; s[r].w += kk * vv.w;
+      for (int t = 0; t < NA; ++t) {
+        if (t < ntok) {
+          const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
+          float4 vv = *reinterpret_cast<const float4*>(tk + 128 + o + cc);   // unconditional loads (a predicated load becomes
+          if (!colin) vv = z4;                                                  // an exec-masked block with its own LDS wait)
+          float kk[16];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            float4 k4 = *reinterpret_cast<const float4*>(tk + 64 + o + rr + 4 * r4);
+            if (!rowin) k4 = z4;
+            kk[4 * r4] = k4.x; kk[4 * r4 + 1] = k4.y; kk[4 * r4 + 2] = k4.z; kk[4 * r4 + 3] = k4.w;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[r].x += kk[r] * vv.x; s[r].y += kk[r] * vv.y; s[r].z += kk[r] * vv.z; s[r].w += kk[r] * vv.w; }
+        }
       }
-    }
-    if (write_state) {
+      RT(2);
+      if (write_state && live) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st4g(Se + (rg + 4 * r) * 64 + c4, s[r]);
-    }
-    for (int t = ret_from; t < ntok; ++t) {
-      const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
-      float4 p = z4;
+        for (int r = 0; r < 16; ++r) st4nt(Se + (16 * rg + r) * 64 + c4, s[r]);
+      }
+      RT(3);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int sr = rg + 4 * r;
-        const float qq = sr < hs ? tk[o + sr] : 0.f;
-        p.x += qq * s[r].x; p.y += qq * s[r].y; p.z += qq * s[r].z; p.w += qq * s[r].w;
+      for (int t = 0; t < NA; ++t) {
+        if (t < ret_from || t >= ntok) continue;
+        const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
+        float4 p = z4;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          float4 q4 = *reinterpret_cast<const float4*>(tk + o + rr + 4 * r4);
+          if (!rowin) q4 = z4;
+          p.x += q4.x * s[4 * r4].x; p.y += q4.x * s[4 * r4].y; p.z += q4.x * s[4 * r4].z; p.w += q4.x * s[4 * r4].w;
+          p.x += q4.y * s[4 * r4 + 1].x; p.y += q4.y * s[4 * r4 + 1].y; p.z += q4.y * s[4 * r4 + 1].z; p.w += q4.y * s[4 * r4 + 1].w;
+          p.x += q4.z * s[4 * r4 + 2].x; p.y += q4.z * s[4 * r4 + 2].y; p.z += q4.z * s[4 * r4 + 2].z; p.w += q4.z * s[4 * r4 + 2].w;
+          p.x += q4.w * s[4 * r4 + 3].x; p.y += q4.w * s[4 * r4 + 3].y; p.z += q4.w * s[4 * r4 + 3].z; p.w += q4.w * s[4 * r4 + 3].w;
+        }
+        p.x = xsum32(xsum16(p.x)); p.y = xsum32(xsum16(p.y)); p.z = xsum32(xsum16(p.z)); p.w = xsum32(xsum16(p.w));
+        // fused epilogue (retention.py:289-294): GroupNorm over groups of gs channels, then the swish gate
+        float s1 = (p.x + p.y) + (p.z + p.w), s2 = (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
+        s1 = gsum(s1, gs >> 2); s2 = gsum(s2, gs >> 2);
+        const float mu = s1 * inv_gs, m2 = s2 * inv_gs;
+        const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
+        const float4 g4 = *reinterpret_cast<const float4*>(tk + 192 + o + cc);
+        if (colin && rg == 0 && live) {
+          float4 o4;
+          o4.x = fswish(g4.x) * ((p.x - mu) * rstd * gam.x + bet.x);
+          o4.y = fswish(g4.y) * ((p.y - mu) * rstd * gam.y + bet.y);
+          o4.z = fswish(g4.z) * ((p.z - mu) * rstd * gam.z + bet.z);
+          o4.w = fswish(g4.w) * ((p.w - mu) * rstd * gam.w + bet.w);
+          if (ENC) st4g(uout + (row0 + t) * AE + o + c4, o4);
+          else *reinterpret_cast<float4*>(U + e * UP + o + c4) = o4;
+        }
       }
-      p.x += __shfl_xor(p.x, 16, 64); p.y += __shfl_xor(p.y, 16, 64); p.z += __shfl_xor(p.z, 16, 64); p.w += __shfl_xor(p.w, 16, 64);
-      p.x += __shfl_xor(p.x, 32, 64); p.y += __shfl_xor(p.y, 32, 64); p.z += __shfl_xor(p.z, 32, 64); p.w += __shfl_xor(p.w, 32, 64);
-      // fused epilogue (retention.py:289-294): GroupNorm over groups of gs channels, then the swish gate
-      float s1 = (p.x + p.y) + (p.z + p.w), s2 = (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
-      for (int x = gs >> 3; x > 0; x >>= 1) { s1 += __shfl_xor(s1, x, 64); s2 += __shfl_xor(s2, x, 64); }
-      const float mu = s1 / (float)gs, m2 = s2 / (float)gs;
-      const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
-      if (colin && rg == 0) {
-        const float4 g4 = *reinterpret_cast<const float4*>(tk + 192 + o + c4);
-        float4 o4;
-        o4.x = swishf_(g4.x) * ((p.x - mu) * rstd * gam.x + bet.x);
-        o4.y = swishf_(g4.y) * ((p.y - mu) * rstd * gam.y + bet.y);
-        o4.z = swishf_(g4.z) * ((p.z - mu) * rstd * gam.z + bet.z);
-        o4.w = swishf_(g4.w) * ((p.w - mu) * rstd * gam.w + bet.w);
-        if (ENC) st4g(uout + (row0 + t) * AE + o + c4, o4);
-        else *reinterpret_cast<float4*>(U + e * UP + o + c4) = o4;
-      }
+      RT(4);
     }
   }
+  RT_FLUSH();
 }
 
 // Optional in-kernel stage timing (debug builds only: -DMAGPO_ACT_PROF): wall-clock ticks (100 MHz) per stage class
 // [0 dense/rows, 1 retention, 2 sampling, 3 encoder total] summed over every 64th wave.
 #ifdef MAGPO_ACT_PROF
-__device__ unsigned long long g_act_prof[8];
 #define PROF(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { unsigned long long t_ = wall_clock64(); \
   atomicAdd(&g_act_prof[k], t_ - t_last); t_last = t_; } } while (0)
 #else
 #define PROF(k)
 #endif
 
-template <int EPW, int NA>
-__global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
+template <int EPW, int NA, int NH>
+__global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* TQ = smem;                  // [EPW][QP]  this iteration's [q|k|v|g] rows, one per env
   float* HK = TQ + EPW * QP;         // [A][QP]    staged token rows of the env being processed
@@ -268,11 +355,13 @@ __global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
   const bool valid = env < nvalid;
   const int le = valid ? env : 0;
   const long ge = env0 + le;   // invalid lanes shadow env 0 of the wave (reads stay legal, nothing is stored)
-  const int A = a.A, nb = a.nb;
+  const int A = a.A, nb = a.nb, nh_ = NH ? NH : a.nh;
   const long NS = (long)a.N * 4096;
   int p_ = a.pos[ge];
   p_ = p_ < 0 ? 0 : (p_ >= a.npos ? a.npos - 1 : p_);
   const Row pe = row_load(a.pe + (long)p_ * AE, kq);
+  // envs whose episode ended on the previous step (bit e): one flag load per kernel, kept out of the retention pipeline
+  const unsigned long long dmask = a.done ? __ballot(valid && kq == 0 && a.done[ge] != 0) : 0ull;
 
   // ---------------- encoder over the A tokens of the step (act_encoder_fn, encode.py:58-84)
   for (int b = 0; b < nb; ++b) {
@@ -307,7 +396,7 @@ __global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
     }
     wsync();
     PROF(0);
-    ret_pass<true, NA>(TQ, HK, U, a.S_enc + (long)b * a.nh * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, B.gn_g, B.gn_b, 1);
+    ret_pass<true, NA, (EPW == 16 ? 4 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
     wsync();
     PROF(1);
     for (int t = 0; t < A; ++t) {
@@ -364,7 +453,7 @@ __global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
       }
       wsync();
       PROF(0);
-      ret_pass<false, NA>(TQ, HK, U, a.S_d1 + (long)b * a.nh * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, B.gn1_g, B.gn1_b, last);
+      ret_pass<false, NA, (EPW == 16 ? 4 : 2), NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, B.gn1_g, B.gn1_b, last, dmask);
       wsync();
       PROF(1);
       Row cpe;
@@ -391,7 +480,7 @@ __global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
       }
       wsync();
       PROF(0);
-      ret_pass<false, NA>(TQ, HK, U, a.S_d2 + (long)b * a.nh * NS, NS, a, env0, nvalid, i, B.kvg2, 192, 0, nullptr, B.gn2_g, B.gn2_b, last);
+      ret_pass<false, NA, (EPW == 16 ? 4 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.kvg2, 192, 0, nullptr, B.gn2_g, B.gn2_b, last, dmask);
       wsync();
       PROF(1);
       {
@@ -418,16 +507,15 @@ __global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
       xv[j] = (n < a.K) ? ((mk && !mk[n]) ? FMIN_ : lg.v[j]) : -INFINITY;
       mx = fmaxf(mx, xv[j]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, xget16(mx, lane));
+    mx = fmaxf(mx, xget32(mx, lane));
     float se = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int n = 16 * (j >> 2) + 4 * kq + (j & 3);
       if (n < a.K) se += expf(xv[j] - mx);
     }
-    se += __shfl_xor(se, 16, 64);
-    se += __shfl_xor(se, 32, 64);
+    se = xsum32(xsum16(se));
     const float lse = mx + logf(se);
     float best = -INFINITY, best_lp = 0.f;
     int arg = 0x7fffffff;
@@ -446,8 +534,8 @@ __global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
     }
 #pragma unroll
     for (int sh = 16; sh <= 32; sh <<= 1) {   // first-max over the 4 lanes of the env
-      const float ob = __shfl_xor(best, sh, 64), olp = __shfl_xor(best_lp, sh, 64);
-      const int oa = __shfl_xor(arg, sh, 64);
+      const float ob = sh == 16 ? xget16(best, lane) : xget32(best, lane), olp = sh == 16 ? xget16(best_lp, lane) : xget32(best_lp, lane);
+      const int oa = __float_as_int(sh == 16 ? xget16(__int_as_float(arg), lane) : xget32(__int_as_float(arg), lane));
       if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; best_lp = olp; }
     }
     if (valid && kq == 0) { a.action[row] = arg; a.logp[row] = best_lp; }
@@ -459,6 +547,14 @@ __global__ __launch_bounds__(64, 2) void k_sable_act(ActArgs a) {
 }  // namespace magpo
 
 using namespace magpo;
+
+template <int EPW> static void launch_act(const ActArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)((EPW + a.A) * QP + 2 * EPW * UP) * sizeof(float);
+  const dim3 grid((a.N + EPW - 1) / EPW), blk(64);
+  if (a.A <= 4 && a.nh == 1) hipLaunchKernelGGL((k_sable_act<EPW, 4, 1>), grid, blk, lds, st, a);   // the benchmark shape: everything static
+  else if (a.A <= 4) hipLaunchKernelGGL((k_sable_act<EPW, 4, 0>), grid, blk, lds, st, a);
+  else hipLaunchKernelGGL((k_sable_act<EPW, 8, 0>), grid, blk, lds, st, a);
+}
 
 // Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
 //   dims_host[10] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only}; kappa_host[4]; keys_host [A][2] or NULL (then
@@ -486,7 +582,7 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   P(const float*, h0_t) P(const float*, h0_b) P(const float*, h_s) P(const float*, h1_t) P(const float*, h1_b)
   P(const float*, pe)
   P(float*, S_enc) P(float*, S_d1) P(float*, S_d2)
-  P(float*, xn) P(float*, kin) P(float*, qkvg) P(float*, u) P(float*, y) P(float*, rep) P(float*, reppe) P(float*, hv)
+  P(float*, xn) P(const unsigned char*, done) P(float*, qkvg) P(float*, u) P(float*, y) P(float*, rep) P(float*, reppe) P(float*, hv)
   P(float*, xa) P(float*, kin1) P(float*, y1) P(float*, c) P(float*, cpe) P(float*, y2) P(float*, xo) P(float*, xope) P(float*, hp)
   P(float*, hn) P(float*, logits) P(float*, u1) P(float*, u2) P(int*, prev)
   P(int*, action) P(float*, logp) P(float*, value)
@@ -502,17 +598,17 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
     B.gn2_g = (const float*)q[16]; B.gn2_b = (const float*)q[17];
     B.qkvg1 = (float*)q[18]; B.q2 = (float*)q[19]; B.kvg2 = (float*)q[20];
   }
-  constexpr int EPW = 8;
-  const size_t lds = (size_t)((EPW + a.A) * QP + 2 * EPW * UP) * sizeof(float);
-  if (a.A <= 4) hipLaunchKernelGGL((k_sable_act<EPW, 4>), dim3((a.N + EPW - 1) / EPW), dim3(64), lds, st, a);
-  else hipLaunchKernelGGL((k_sable_act<EPW, 8>), dim3((a.N + EPW - 1) / EPW), dim3(64), lds, st, a);
+  // 16 envs per wave (full MFMA tiles, half the weight traffic) once that still gives every SIMD a wave; 8 below
+  int epw = a.N >= 16 * 4 * 256 ? 16 : 8;
+  if (const char* e = getenv("MAGPO_ACT_EPW")) epw = atoi(e) == 16 ? 16 : 8;
+  if (epw == 16) launch_act<16>(a, st); else launch_act<8>(a, st);
   return check_launch("magpo_sable_act");
 }
 
 #ifdef MAGPO_ACT_PROF
 extern "C" int magpo_debug_act_prof(unsigned long long* out_host, int reset) {
-  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_act_prof), sizeof(unsigned long long) * 8) != hipSuccess) return MAGPO_ELAUNCH;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_act_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_act_prof), sizeof(unsigned long long) * 16) != hipSuccess) return MAGPO_ELAUNCH;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_act_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
   return MAGPO_OK;
 }
 #endif

@@ -202,6 +202,7 @@ class MagpoLearner:
             g.cur = 0
 
     # ------------------------------------------------------------------ rollout (rec_magpo.py:126-212)
+    overlap_actor_step = False  # (measured slower: the acting kernel already fills every wave slot) actor hidden-state carry on a side stream beside the guider's acting kernel
     fused_act = True  # one launch per env step for the whole Sable acting step (csrc/act_fused.hip)
     use_graph = True  # replay the whole rollout as one HIP graph (removes ~11K host launches per rollout)
 
@@ -261,22 +262,40 @@ class MagpoLearner:
         for d, s in zip(g.prev_sable_hs, g.sable_hs):
             d.copy_(s)
         g.policy_h0.copy_(g.policy_h[g.cur])
-        for t in range(T):
-            obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
-            act = self.guider.act_fused if self.fused_act else self.guider.act
-            act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t])
-            h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
-            self.actor.step(obs, h_in, done_prev, h_out)
-            g.cur = 1 - g.cur
-            g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
-                       g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t])
+        main = torch.cuda.current_stream()
+        side = self._actor_stream if self.overlap_actor_step else None
+        fused = self.fused_act
+        act = self.guider.act_fused if fused else self.guider.act
+
+        def zero_done(done):
             for k in range(self.nb):
                 for h in range(self.nh):
-                    L.call("magpo_zero_states_where_done", g.sable_hs[0][k][h], g.sable_hs[1][k][h], g.sable_hs[2][k][h], tr["done"][t + 1], N, st)
+                    L.call("magpo_zero_states_where_done", g.sable_hs[0][k][h], g.sable_hs[1][k][h], g.sable_hs[2][k][h], done, N, st)
+
+        for t in range(T):
+            obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
+            # the actor's hidden-state carry is a pure function of (obs, done): it runs beside the guider on a side stream
+            h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.actor.step(obs, h_in, done_prev, h_out)
+            else:
+                self.actor.step(obs, h_in, done_prev, h_out)
+            g.cur = 1 - g.cur
+            if fused:   # states of envs whose episode just ended read as zero inside the kernel (rec_magpo.py:164-169)
+                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], done=done_prev)
+            else:
+                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t])
+            g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
+                       g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t])
+            if not fused or t == T - 1:
+                zero_done(tr["done"][t + 1])
+        if side is not None:
+            main.wait_stream(side)
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])
             g.cur = 0
-        act = self.guider.act_fused if self.fused_act else self.guider.act
         act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
         L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], g.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
                self.sys.gamma, self.sys.gae_lambda, st)

@@ -269,23 +269,27 @@ class SableGuider:
             L.call("magpo_sample_categorical", logits, E, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
                    k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
 
-    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False):
-        """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a workgroup carries
-        32 envs through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64]."""
+    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None):
+        """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a wave carries 8 envs
+        through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64].  ``done`` [N] u8
+        (optional): envs whose episode ended on the previous step -- their carried states are read as zero
+        (rec_magpo.py:164-169), which replaces a separate zeroing pass between steps."""
         A, K, F, nb, nh = self.A, self.K, self.F, self.nb, self.nh
         if A > 8:   # token staging registers of the fused kernel: larger teams take the kernel-by-kernel path
+            if done is not None:
+                for k in range(nb):
+                    for h in range(nh):
+                        self.L.call("magpo_zero_states_where_done", states[0][k][h], states[1][k][h], states[2][k][h], done, obs.shape[0], self._st())
             return self.act(obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=mask, value_only=value_only)
         N = obs.shape[0]
         R = N * A
         v, b = self.v, self.b
-        s_enc, s_d1, s_d2 = states
-        if value_only:  # bootstrap value (rec_magpo.py:202-208): states must not change
-            s_enc = b.get("a_senc_tmp", tuple(s_enc.shape)).copy_(s_enc)
+        s_enc, s_d1, s_d2 = states   # value_only (bootstrap value, rec_magpo.py:202-208): the kernel writes no state
         kdev = sample_keys if torch.is_tensor(sample_keys) else None
         cache_key = (N, bool(value_only), obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
                      None if kdev is None else kdev.data_ptr(), s_enc.data_ptr(), s_d1.data_ptr(), s_d2.data_ptr(),
                      None if action_out is None else action_out.data_ptr(), None if logp_out is None else logp_out.data_ptr(),
-                     value_out.data_ptr())
+                     value_out.data_ptr(), None if done is None else done.data_ptr())
         tabs = self._act_tabs.get(cache_key)
         if tabs is None:
             g = lambda n, w=E, rows=R: b.get("f_" + n, (rows, w))
@@ -295,7 +299,7 @@ class SableGuider:
                     self.wt["vh0"], v["enc.head.dense0.bias"], v["enc.head.norm.scale"], v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
                     self.wt["h0"], v["dec.head.dense0.bias"], v["dec.head.norm.scale"], self.wt["h1"], v["dec.head.dense1.bias"],
                     self.pe, s_enc, s_d1, s_d2,
-                    g("xn"), g("kin"), g("qkvg", 4 * E), g("u"), g("y"), g("rep"), g("reppe"), g("hv"),
+                    g("xn"), done, g("qkvg", 4 * E), g("u"), g("y"), g("rep"), g("reppe"), g("hv"),
                     g("xa", E, N), g("kin1", E, N), g("y1", E, N), g("c", E, N), g("cpe", E, N), g("y2", E, N), g("xo", E, N),
                     g("xope", E, N), g("hp", E, N), g("hn", E, N), g("logits", E, N), g("u1"), g("u2"),
                     b.get("f_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out]
