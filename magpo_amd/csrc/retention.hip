@@ -18,14 +18,22 @@
 namespace magpo {
 
 constexpr int TL = 64 + LDP;  // tile pitch
+constexpr int FWD_MAXC = 8, BWD_MAXC = 16;   // chunks per sequence whose bookkeeping is built up front (LDS budget: 2 fwd workgroups / CU)
 
 struct ChunkMeta {      // per-chunk decay bookkeeping in LDS
-  float kpow[66];       // kappa^p
-  int cnt[64];          // per token: # dones among chunk timesteps [0..lt]
-  int lt[64];           // per token: chunk-local timestep (invalid tokens: -1)
+  signed char cnt[64];  // per token: # dones among chunk timesteps [0..lt]   (invalid tokens: -1)
+  signed char lt[64];   // per token: chunk-local timestep (invalid tokens: -1)
   float beta[64];       // incoming-state weight per token
   float eta[64];        // outgoing-state weight per token
   float gamma;          // state carry factor
+  float pad_[3];
+};
+// Bookkeeping of a whole sequence: built ONCE per workgroup (all chunks in parallel) when the sequence has at most
+// MAXC chunks -- building it chunk by chunk costs ~6 us per chunk (dependent flag loads, powf, two barriers), a quarter
+// of the backward kernel's time (in-kernel phase timing, scripts/ret_prof.py).
+template <int MAXC> struct SeqMeta {
+  float kpow[68];       // kappa^p, p = 0..65
+  ChunkMeta ch[MAXC];
 };
 
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, long ld, int nvalid, int w4 = 16) {
@@ -129,45 +137,47 @@ __device__ __forceinline__ void acc_zero(f32x16& a) {
 }
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// Build the per-chunk metadata.  dones: this sequence's per-timestep flags; t0 first timestep of
-// the chunk; ltc number of valid timesteps; A agents.
-__device__ __forceinline__ void build_meta(ChunkMeta& m, const unsigned char* __restrict__ dones, int t0, int ltc, int A,
-                                           float kappa) {
+// Build the metadata of chunks c0 .. c0+count-1 into ch[0 .. count-1].  dones: this sequence's per-timestep flags.
+__device__ __forceinline__ void build_meta(float* __restrict__ kpow, ChunkMeta* __restrict__ ch, const unsigned char* __restrict__ dones,
+                                           int T, int Lt, int A, float kappa, int c0, int count) {
   const int tid = threadIdx.x;
-  if (tid < 66) m.kpow[tid] = powf(kappa, (float)tid);
-  if (tid < 64) {
-    int lt = tid / A;
+  for (int idx = tid; idx < count * 64; idx += 256) {
+    const int cc = idx >> 6, tok = idx & 63;
+    const int t0 = (c0 + cc) * Lt, ltc = min(Lt, T - t0);
+    const int lt = tok / A;
+    int c = -1, l = -1;
     if (lt < ltc) {
-      int c = 0;
-      for (int s = 0; s <= lt; ++s) c += dones[t0 + s] ? 1 : 0;
-      m.lt[tid] = lt;
-      m.cnt[tid] = c;
-    } else {
-      m.lt[tid] = -1;
-      m.cnt[tid] = -1;
+      c = 0;
+      l = lt;
+      for (int s2 = 0; s2 <= lt; ++s2) c += dones[t0 + s2] ? 1 : 0;
     }
+    ch[cc].lt[tok] = (signed char)l;
+    ch[cc].cnt[tok] = (signed char)c;
   }
   __syncthreads();
-  if (tid < 64) {
-    int lt = m.lt[tid];
-    int ctot = m.cnt[(ltc - 1) * A];
+  for (int idx = tid; idx < count * 64; idx += 256) {
+    const int cc = idx >> 6, tok = idx & 63;
+    const int t0 = (c0 + cc) * Lt, ltc = min(Lt, T - t0);
+    ChunkMeta& m = ch[cc];
+    const int lt = m.lt[tok];
+    const int ctot = m.cnt[(ltc - 1) * A];
     float b = 0.f, e = 0.f;
     if (lt >= 0) {
-      b = (m.cnt[tid] == 0) ? m.kpow[lt + 1] : 0.f;
-      e = (m.cnt[tid] == ctot) ? m.kpow[ltc - 1 - lt] : 0.f;
+      b = (m.cnt[tok] == 0) ? kpow[lt + 1] : 0.f;
+      e = (m.cnt[tok] == ctot) ? kpow[ltc - 1 - lt] : 0.f;
     }
-    m.beta[tid] = b;
-    m.eta[tid] = e;
-    if (tid == 0) m.gamma = (ctot == 0) ? m.kpow[ltc] : 0.f;
+    m.beta[tok] = b;
+    m.eta[tok] = e;
+    if (tok == 0) m.gamma = (ctot == 0) ? kpow[ltc] : 0.f;
   }
   __syncthreads();
 }
 
-__device__ __forceinline__ float decay_w(const ChunkMeta& m, int i, int j, int masked) {
+__device__ __forceinline__ float decay_w(const float* __restrict__ kpow, const ChunkMeta& m, int i, int j, int masked) {
   const int li = m.lt[i], lj = m.lt[j];
   if (li < 0 || lj < 0 || li < lj || m.cnt[i] != m.cnt[j]) return 0.f;
   if (masked && j > i) return 0.f;
-  return m.kpow[li - lj];
+  return kpow[li - lj];
 }
 
 struct RetArgs {
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
   float* Ks = Qs + 64 * TL;
   float* Vs = Ks + 64 * TL;
   float* Ss = Vs + 64 * TL;
-  ChunkMeta& meta = *reinterpret_cast<ChunkMeta*>(Ss + 64 * TL);
+  SeqMeta<FWD_MAXC>& sm = *reinterpret_cast<SeqMeta<FWD_MAXC>*>(Ss + 64 * TL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, h = lane >> 5;
   const int seq = blockIdx.x;
@@ -197,6 +207,9 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
   const float* s0 = a.s0 ? a.s0 + (long)(a.seq_env ? a.seq_env[seq] : seq) * 4096 : nullptr;
   const int w4 = a.hs >> 2;
   load_state(Ss, s0);
+  const bool pre = nch <= FWD_MAXC;   // whole-sequence bookkeeping up front
+  if (tid < 66) sm.kpow[tid] = powf(a.kappa, (float)tid);   // (visible after the first barrier inside build_meta)
+  if (pre) build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, 0, nch);
   TileRegs pq, pk, pv;
   {
     const int nv0 = min(Lt, a.T) * a.A;
@@ -213,7 +226,9 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
     stash_tile(Qs, pq);
     stash_tile(Ks, pk);
     stash_tile(Vs, pv);
-    build_meta(meta, a.dones + (long)seq * a.T, t0, ltc, a.A, a.kappa);  // contains __syncthreads
+    if (!pre) build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, c, 1);  // contains __syncthreads
+    else __syncthreads();
+    const ChunkMeta& meta = sm.ch[pre ? c : 0];
     if (c + 1 < nch) {  // next chunk's tiles are in flight while this chunk's GEMMs run
       const int nvn = min(Lt, a.T - (t0 + Lt)) * a.A;
       const long rn = r0 + L;
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
     for (int i = 0; i < 16; ++i) {
       const int ri = 32 * wr + acc_row(i, h);
       o[i] *= meta.beta[ri];
-      sc[i] *= decay_w(meta, ri, 32 * wc + lr, a.masked);
+      sc[i] *= decay_w(sm.kpow, meta, ri, 32 * wc + lr, a.masked);
     }
     __syncthreads();  // everyone done reading Qs
 #pragma unroll
@@ -276,6 +291,17 @@ struct RetBwdArgs {
   int T, A, masked; float kappa; int hs;
 };
 
+#ifdef MAGPO_RET_PROF
+__device__ unsigned long long g_ret_prof[8];
+#define RP_DECL() unsigned long long rp_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long rp_last = clock64();
+#define RP(k) do { unsigned long long t_ = clock64(); rp_acc[k] += t_ - rp_last; rp_last = t_; } while (0)
+#define RP_FLUSH() do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_ret_prof[k_], rp_acc[k_]); } } while (0)
+#else
+#define RP_DECL()
+#define RP(k)
+#define RP_FLUSH()
+#endif
+
 __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* Qs = smem;
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
   float* Gs = Ss + 64 * TL;   // dL/dS_{c+1}
   float* Ps = Gs + 64 * TL;
   float* dPs = Ps + 64 * TL;
-  ChunkMeta& meta = *reinterpret_cast<ChunkMeta*>(dPs + 64 * TL);
+  SeqMeta<BWD_MAXC>& sm = *reinterpret_cast<SeqMeta<BWD_MAXC>*>(dPs + 64 * TL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, h = lane >> 5;
   const int seq = blockIdx.x;
@@ -295,6 +321,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
   const long row_base = (long)seq * a.T * a.A;
   const int w4 = a.hs >> 2;
   load_state(Gs, nullptr);
+  const bool pre = nch <= BWD_MAXC;
+  if (tid < 66) sm.kpow[tid] = powf(a.kappa, (float)tid);   // (visible after the first barrier inside build_meta)
+  if (pre) build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, 0, nch);
+  RP_DECL();
   TileRegs pq, pk, pv, pd, ps;
   {
     const int cl = nch - 1;
@@ -317,7 +347,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
     stash_tile(Vs, pv);
     stash_tile(Ds, pd);
     stash_tile(Ss, ps);
-    build_meta(meta, a.dones + (long)seq * a.T, t0, ltc, a.A, a.kappa);
+    if (!pre) {
+      build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, c, 1);
+    } else __syncthreads();
+    const ChunkMeta& meta = sm.ch[pre ? c : 0];
     if (c > 0) {  // previous chunk (next in the reverse sweep): loads in flight during the 9 GEMMs below
       const long rn = r0 - L;
       fetch_tile(pq, a.q + rn * a.ldq, a.ldq, L, w4);
@@ -327,6 +360,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       fetch_state(ps, a.states + ((long)seq * nch + c - 1) * 4096);
     }
 
+    RP(0);
     // P = (Q K^T) * w ; dP = (dO V^T) * w
     Frag doa = load_rowfrag(Ds, 32 * wr + lr, h);
     {
@@ -341,12 +375,13 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ri = 32 * wr + acc_row(i, h);
-        const float w = decay_w(meta, ri, 32 * wc + lr, a.masked);
+        const float w = decay_w(sm.kpow, meta, ri, 32 * wc + lr, a.masked);
         Ps[ri * TL + 32 * wc + lr] = p[i] * w;
         dPs[ri * TL + 32 * wc + lr] = dp[i] * w;
       }
     }
     __syncthreads();
+    RP(1);
     // dQ = dP K + beta * (dO S_c^T)
     {
       f32x16 acc1, acc2;
@@ -362,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
         if (ri < nvalid && 32 * wc + lr < a.hs) a.dq[(r0 + ri) * a.lddq + 32 * wc + lr] = acc1[i] + meta.beta[ri] * acc2[i];
       }
     }
+    RP(2);
     // dK = dP^T Q + eta * (V G^T)
     {
       f32x16 acc1, acc2;
@@ -377,6 +413,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
         if (ri < nvalid && 32 * wc + lr < a.hs) a.dk[(r0 + ri) * a.lddk + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
       }
     }
+    RP(3);
     // dV = P^T dO + eta * (K G)
     {
       f32x16 acc1, acc2;
@@ -391,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
         if (ri < nvalid && 32 * wc + lr < a.hs) a.dv[(r0 + ri) * a.lddv + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
       }
     }
+    RP(4);
     // G <- gamma G + (beta Q)^T dO
     {
       f32x16 gn;
@@ -402,7 +440,9 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) Gs[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr] = gn[i];
     }
+    RP(5);
   }
+  RP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -519,7 +559,7 @@ extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* 
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs};
-  size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(ChunkMeta);
+  size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(SeqMeta<FWD_MAXC>);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_ret_chunk_fwd, dim3(nseq), dim3(256), lds, st, a);
@@ -533,7 +573,7 @@ extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* 
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs};
-  size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(ChunkMeta);
+  size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(SeqMeta<BWD_MAXC>);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_ret_chunk_bwd, dim3(nseq), dim3(256), lds, st, a);
@@ -556,3 +596,11 @@ extern "C" int magpo_zero_states_where_done(float* s0, float* s1, float* s2, con
   hipLaunchKernelGGL(k_zero_states, dim3(nenv), dim3(256), 0, st, s0, s1, s2, done);
   return check_launch("magpo_zero_states_where_done");
 }
+
+#ifdef MAGPO_RET_PROF
+extern "C" int magpo_debug_ret_prof(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_ret_prof), sizeof(unsigned long long) * 8) != hipSuccess) return MAGPO_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_ret_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
+  return MAGPO_OK;
+}
+#endif
