@@ -18,6 +18,10 @@
 namespace magpo {
 
 constexpr int TL = 64 + LDP;  // tile pitch
+// Sink for the stores of invalid tile elements (ragged last chunk, narrow heads): every lane always issues the same
+// number of stores, so the compiler can wait for the prefetched tiles with vmcnt(#stores) instead of draining the
+// store queue (vmcnt(0)) at the top of every chunk.
+__device__ float g_ret_trash[64 * 64];
 constexpr int FWD_MAXC = 8, BWD_MAXC = 16;   // chunks per sequence whose bookkeeping is built up front (LDS budget: 2 fwd workgroups / CU)
 
 struct ChunkMeta {      // per-chunk decay bookkeeping in LDS
@@ -62,12 +66,12 @@ __device__ __forceinline__ void store_state(float* __restrict__ dst, const float
 // register staging of a 64x64 tile (4 float4 per thread): fetch from HBM now, stash into LDS one chunk later
 struct TileRegs { float4 v[4]; };
 __device__ __forceinline__ void fetch_tile(TileRegs& t, const float* __restrict__ src, long ld, int nvalid, int w4) {
+  // unconditional loads from clamped addresses (a predicated load is an exec-masked block); stash_tile zero-fills
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = threadIdx.x + 256 * j;
-    const int r = i >> 4, c4 = i & 15;
-    t.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nvalid && c4 < w4) t.v[j] = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
+    const int r = min(i >> 4, nvalid - 1), c4 = min(i & 15, w4 - 1);
+    t.v[j] = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
   }
 }
 __device__ __forceinline__ void fetch_state(TileRegs& t, const float* __restrict__ src) {
@@ -77,11 +81,12 @@ __device__ __forceinline__ void fetch_state(TileRegs& t, const float* __restrict
     t.v[j] = *reinterpret_cast<const float4*>(src + (i >> 4) * 64 + 4 * (i & 15));
   }
 }
-__device__ __forceinline__ void stash_tile(float* __restrict__ dst, const TileRegs& t) {
+__device__ __forceinline__ void stash_tile(float* __restrict__ dst, const TileRegs& t, int nvalid = 64, int w4 = 16) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = threadIdx.x + 256 * j;
-    *reinterpret_cast<float4*>(&dst[(i >> 4) * TL + 4 * (i & 15)]) = t.v[j];
+    const bool ok = (i >> 4) < nvalid && (i & 15) < w4;
+    *reinterpret_cast<float4*>(&dst[(i >> 4) * TL + 4 * (i & 15)]) = ok ? t.v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -180,6 +185,30 @@ __device__ __forceinline__ float decay_w(const float* __restrict__ kpow, const C
   return kpow[li - lj];
 }
 
+// Per-lane copy of the chunk bookkeeping for the 16 accumulator rows (and the one column) a lane owns: loaded once per
+// chunk with batched LDS reads, so that the GEMM epilogues do not pay one dependent LDS round trip per element.
+struct LaneMeta {
+  float beta[16], eta[16], w[16];   // w: decay weights of this lane's 16 (row, column) pairs
+};
+__device__ __forceinline__ void load_lane_meta(LaneMeta& lm, const float* __restrict__ kpow, const ChunkMeta& m, int wr, int col, int h,
+                                               int masked) {
+  const int lj = m.lt[col], cj = m.cnt[col];
+  int li[16], ci[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ri = 32 * wr + acc_row(i, h);
+    li[i] = m.lt[ri]; ci[i] = m.cnt[ri];
+    lm.beta[i] = m.beta[ri]; lm.eta[i] = m.eta[ri];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ri = 32 * wr + acc_row(i, h);
+    const bool on = li[i] >= 0 && lj >= 0 && li[i] >= lj && ci[i] == cj && !(masked && col > ri);
+    const float kp = kpow[on ? li[i] - lj : 0];   // unconditional (clamped) read, selected afterwards
+    lm.w[i] = on ? kp : 0.f;
+  }
+}
+
 struct RetArgs {
   const float* q; const float* k; const float* v; long ldq, ldk, ldv;   // row strides (floats)
   float* r; long ldr;
@@ -221,17 +250,19 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
     const int t0 = c * Lt;
     const int ltc = min(Lt, a.T - t0);
     const int nvalid = ltc * a.A;
+    const bool full = nvalid == 64 && a.hs == 64;
     const long r0 = row_base + (long)c * L;
     __syncthreads();  // previous chunk finished with Qs/Ks/Vs, Ss updated
-    stash_tile(Qs, pq);
-    stash_tile(Ks, pk);
-    stash_tile(Vs, pv);
+    stash_tile(Qs, pq, nvalid, w4);
+    stash_tile(Ks, pk, nvalid, w4);
+    stash_tile(Vs, pv, nvalid, w4);
     if (!pre) build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, c, 1);  // contains __syncthreads
     else __syncthreads();
     const ChunkMeta& meta = sm.ch[pre ? c : 0];
-    if (c + 1 < nch) {  // next chunk's tiles are in flight while this chunk's GEMMs run
-      const int nvn = min(Lt, a.T - (t0 + Lt)) * a.A;
-      const long rn = r0 + L;
+    {  // next chunk's tiles are in flight while this chunk's GEMMs run (last chunk: re-reads itself, branch-free)
+      const bool more = c + 1 < nch;
+      const int nvn = more ? min(Lt, a.T - (t0 + Lt)) * a.A : nvalid;
+      const long rn = more ? r0 + L : r0;
       fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
       fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
       fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
@@ -241,6 +272,8 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
     f32x16 sc, o;
     acc_zero(sc);
     acc_zero(o);
+    LaneMeta lm;
+    load_lane_meta(lm, sm.kpow, meta, wr, 32 * wc + lr, h, a.masked);
     {
       Frag qa = load_rowfrag(Qs, 32 * wr + lr, h);
       Frag kb = load_rowfrag(Ks, 32 * wc + lr, h);
@@ -250,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ri = 32 * wr + acc_row(i, h);
-      o[i] *= meta.beta[ri];
-      sc[i] *= decay_w(sm.kpow, meta, ri, 32 * wc + lr, a.masked);
+      o[i] *= lm.beta[i];
+      sc[i] *= lm.w[i];
     }
     __syncthreads();  // everyone done reading Qs
 #pragma unroll
@@ -262,9 +295,10 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
       mma_rc(o, pa, Vs, 32 * wc + lr, h);      // P V
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
       const int ri = 32 * wr + acc_row(i, h);
-      if (ri < nvalid && 32 * wc + lr < a.hs) a.r[(r0 + ri) * a.ldr + 32 * wc + lr] = o[i];
+      float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.r + (r0 + ri) * a.ldr + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
+      *dst = o[i];
     }
     // state update  S <- gamma S + (eta K)^T V
     f32x16 sn;
@@ -340,27 +374,31 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
     const int t0 = c * Lt;
     const int ltc = min(Lt, a.T - t0);
     const int nvalid = ltc * a.A;
+    const bool full = nvalid == 64 && a.hs == 64;
     const long r0 = row_base + (long)c * L;
     __syncthreads();
-    stash_tile(Qs, pq);
-    stash_tile(Ks, pk);
-    stash_tile(Vs, pv);
-    stash_tile(Ds, pd);
+    stash_tile(Qs, pq, nvalid, w4);
+    stash_tile(Ks, pk, nvalid, w4);
+    stash_tile(Vs, pv, nvalid, w4);
+    stash_tile(Ds, pd, nvalid, w4);
     stash_tile(Ss, ps);
     if (!pre) {
       build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, c, 1);
     } else __syncthreads();
     const ChunkMeta& meta = sm.ch[pre ? c : 0];
-    if (c > 0) {  // previous chunk (next in the reverse sweep): loads in flight during the 9 GEMMs below
-      const long rn = r0 - L;
-      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, L, w4);
-      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, L, w4);
-      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, L, w4);
-      fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, L, w4);
-      fetch_state(ps, a.states + ((long)seq * nch + c - 1) * 4096);
+    {  // previous chunk (next in the reverse sweep): loads in flight during the 9 GEMMs below (chunk 0 re-reads itself)
+      const long rn = c > 0 ? r0 - L : r0;
+      const int nvn = c > 0 ? L : nvalid;
+      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
+      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
+      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
+      fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, nvn, w4);
+      fetch_state(ps, a.states + ((long)seq * nch + max(c - 1, 0)) * 4096);
     }
 
     RP(0);
+    LaneMeta lm;
+    load_lane_meta(lm, sm.kpow, meta, wr, 32 * wc + lr, h, a.masked);
     // P = (Q K^T) * w ; dP = (dO V^T) * w
     Frag doa = load_rowfrag(Ds, 32 * wr + lr, h);
     {
@@ -375,9 +413,8 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ri = 32 * wr + acc_row(i, h);
-        const float w = decay_w(sm.kpow, meta, ri, 32 * wc + lr, a.masked);
-        Ps[ri * TL + 32 * wc + lr] = p[i] * w;
-        dPs[ri * TL + 32 * wc + lr] = dp[i] * w;
+        Ps[ri * TL + 32 * wc + lr] = p[i] * lm.w[i];
+        dPs[ri * TL + 32 * wc + lr] = dp[i] * lm.w[i];
       }
     }
     __syncthreads();
@@ -392,9 +429,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       Frag sb = load_rowfrag(Ss, 32 * wc + lr, h);
       mma_rr(acc2, doa, sb);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
         const int ri = 32 * wr + acc_row(i, h);
-        if (ri < nvalid && 32 * wc + lr < a.hs) a.dq[(r0 + ri) * a.lddq + 32 * wc + lr] = acc1[i] + meta.beta[ri] * acc2[i];
+        float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.dq + (r0 + ri) * a.lddq + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
+        *dst = acc1[i] + lm.beta[i] * acc2[i];
       }
     }
     RP(2);
@@ -408,9 +446,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       Frag gb = load_rowfrag(Gs, 32 * wc + lr, h);
       mma_rr(acc2, va, gb);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
         const int ri = 32 * wr + acc_row(i, h);
-        if (ri < nvalid && 32 * wc + lr < a.hs) a.dk[(r0 + ri) * a.lddk + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
+        float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.dk + (r0 + ri) * a.lddk + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
+        *dst = acc1[i] + lm.eta[i] * acc2[i];
       }
     }
     RP(3);
@@ -423,9 +462,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       Frag ka = load_rowfrag(Ks, 32 * wr + lr, h);
       mma_rc(acc2, ka, Gs, 32 * wc + lr, h);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
         const int ri = 32 * wr + acc_row(i, h);
-        if (ri < nvalid && 32 * wc + lr < a.hs) a.dv[(r0 + ri) * a.lddv + 32 * wc + lr] = acc1[i] + meta.eta[ri] * acc2[i];
+        float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.dv + (r0 + ri) * a.lddv + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
+        *dst = acc1[i] + lm.eta[i] * acc2[i];
       }
     }
     RP(4);
