@@ -37,17 +37,28 @@ __device__ __forceinline__ long tok_row(int rho, int t, int T, int A) {
 
 // W_h^T fragments (3 gates x 128 k x 32 columns per wave = 192 VGPRs) stay in registers for the whole scan;
 // wave w owns hidden columns 32w..32w+31 for both 32-row halves.  One wave per SIMD (launch bound 1).
-__global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
+// FULL = every one of the block's 64 rows is valid (all but the last block): loads and stores are then unconditional
+// straight-line code; a predicated access is an exec-masked block with its own wait and a per-element global flag load
+// sits on the step's critical path, so the reset flags of the block's rows are staged in LDS once.
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) {
   __shared__ __align__(16) float hbuf[2][64 * HP];
+  extern __shared__ unsigned char rflag[];   // [64][T] reset-before-step flags of the block's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
-  const int rho0 = blockIdx.x * 64;
+  const int rho0 = (block0 + blockIdx.x) * 64;
   const int col = 32 * wave + lr;
+  const int T = a.T;
   float4 wf[3][16];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
     for (int u = 0; u < 16; ++u) wf[g][u] = *reinterpret_cast<const float4*>(a.Wht + ((long)g * H + col) * H + 64 * h + 4 * u);
   const float bhn = a.b_hn[col];
+  for (int i = tid; i < 64 * T; i += 256) {
+    const int rl = i / T, t = i - rl * T;
+    const int rho = min(rho0 + rl, a.NR - 1);
+    rflag[i] = a.reset[(long)(rho / a.A) * T + t];
+  }
   // initial carry (with the reset of step 0 applied)
   for (int i = tid; i < 64 * (H / 4); i += 256) {
     int r = i / (H / 4), c4 = i - r * (H / 4);
@@ -55,23 +66,18 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rho < a.NR) {
       int seq = rho / a.A;
-      if (!a.reset[(long)seq * a.T]) {
+      if (!a.reset[(long)seq * T]) {
         long src = a.h0_idx ? a.h0_idx[rho] : rho;
         v = *reinterpret_cast<const float4*>(a.h0 + src * H + 4 * c4);
       }
     }
     *reinterpret_cast<float4*>(&hbuf[0][r * HP + 4 * c4]) = v;
   }
-  // per-row bookkeeping (no integer division inside the scan): token row of step 0 and sequence index
+  // per-row bookkeeping (no integer division inside the scan): token row of step 0 (invalid rows shadow the last valid one)
   __shared__ long rbase[64];
-  __shared__ int rseq[64];
-  if (tid < 64) {
-    const int rho = rho0 + tid;
-    if (rho < a.NR) { rbase[tid] = tok_row(rho, 0, a.T, a.A); rseq[tid] = rho / a.A; }
-    else { rbase[tid] = -1; rseq[tid] = 0; }
-  }
+  if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
   __syncthreads();
-  for (int t = 0; t < a.T; ++t) {
+  for (int t = 0; t < T; ++t) {
     const float* hold = hbuf[t & 1];
     float* hnew = hbuf[(t + 1) & 1];
 #pragma unroll 1
@@ -82,15 +88,10 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const long rb = rbase[rl];
-        if (rb >= 0) {
-          const long row = rb + (long)t * a.A;
-          rowi[i] = row;
-          const float* x = a.xi + row * G3;
-          xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
-        } else {
-          rowi[i] = -1; xr[i] = 0.f; xz[i] = 0.f; xn[i] = 0.f;
-        }
+        const long row = rbase[rl] + (long)t * a.A;
+        rowi[i] = row;
+        const float* x = a.xi + row * G3;
+        xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
       }
       f32x16 ar, az, an;
 #pragma unroll
@@ -112,26 +113,26 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a) {
         az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[1][u].w, az, 0, 0, 0);
         an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[2][u].w, an, 0, 0, 0);
       }
+      const bool more = t + 1 < T;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
-        float hn_new = 0.f;
-        if (rowi[i] >= 0) {
-          const long row = rowi[i];
-          const float hb = an[i] + bhn;
-          const float r = fast_sigmoid(xr[i] + ar[i]);
-          const float z = fast_sigmoid(xz[i] + az[i]);
-          const float n = fast_tanh(xn[i] + r * hb);
-          const float hp = hold[rl * HP + col];
-          hn_new = (1.0f - z) * n + z * hp;
+        const long row = rowi[i];
+        const float hb = an[i] + bhn;
+        const float r = fast_sigmoid(xr[i] + ar[i]);
+        const float z = fast_sigmoid(xz[i] + az[i]);
+        const float n = fast_tanh(xn[i] + r * hb);
+        const float hp = hold[rl * HP + col];
+        float hn_new = (1.0f - z) * n + z * hp;
+        if (FULL || rho0 + rl < a.NR) {
           a.hs[row * H + col] = hn_new;
           if (a.gates) {
             float* g = a.gates + row * (4 * H);
             g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
           }
           if (a.hprev) a.hprev[row * H + col] = hp;
-          if (t + 1 < a.T && a.reset[(long)((rho0 + rl) / a.A) * a.T + t + 1]) hn_new = 0.f;
         }
+        if (more && rflag[rl * T + t + 1]) hn_new = 0.f;
         hnew[rl * HP + col] = hn_new;
       }
     }
@@ -151,12 +152,14 @@ struct GruBwdArgs {
   int T, A, NR;
 };
 
-__global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a) {
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block0) {
   extern __shared__ __align__(16) float smem[];
   float* dht = smem;                 // [64][HP]   dL/dh carried from step t+1 (already includes the direct z path)
   float* dhht = dht + 64 * HP;       // [64][G3P]  dhh of the current step
+  unsigned char* rflag = reinterpret_cast<unsigned char*>(dhht + 64 * G3P);   // [64][T] reset flags of the block's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
-  const int rho0 = blockIdx.x * 64;
+  const int rho0 = (block0 + blockIdx.x) * 64;
   const int col = 32 * wave + lr;
   // W_h (natural [H][3H]) as the B operand of dh_prev = dhh @ W_h^T: lane (col, h) holds k in [192 h, 192 h + 192)
   float4 wf[48];
@@ -165,11 +168,11 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a) {
   for (int i = tid; i < 64 * HP; i += 256) dht[i] = 0.f;
   float bacc = 0.f;  // thread owns column (tid & 127) for rows (tid >> 7) + 2k
   __shared__ long rbase[64];
-  __shared__ int rseq[64];
-  if (tid < 64) {
-    const int rho = rho0 + tid;
-    if (rho < a.NR) { rbase[tid] = tok_row(rho, 0, a.T, a.A); rseq[tid] = rho / a.A; }
-    else { rbase[tid] = -1; rseq[tid] = 0; }
+  if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, a.T, a.A);   // invalid rows shadow the last valid one
+  for (int i = tid; i < 64 * a.T; i += 256) {
+    const int rl = i / a.T, t = i - rl * a.T;
+    const int rho = min(rho0 + rl, a.NR - 1);
+    rflag[i] = a.reset[(long)(rho / a.A) * a.T + t];
   }
   __syncthreads();
   const int c = tid & 127;
@@ -179,44 +182,39 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a) {
     for (int kb = 0; kb < 32; kb += 8) {
       float gr[8], gz[8], gn[8], gh[8], hp[8], dh[8];
       long rowv[8];
-      bool rst[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int rl = (tid >> 7) + 2 * (kb + k);
-        const long rb = rbase[rl];
-        if (rb >= 0) {
-          const long row = rb + (long)t * a.A;
-          rowv[k] = row;
-          rst[k] = a.reset[(long)rseq[rl] * a.T + t] != 0;
-          const float* g = a.gates + row * (4 * H);
-          gr[k] = g[c]; gz[k] = g[H + c]; gn[k] = g[2 * H + c]; gh[k] = g[3 * H + c];
-          hp[k] = a.hprev[row * H + c];
-          dh[k] = a.dhs[row * H + c];
-        } else {
-          rowv[k] = -1; rst[k] = false; gr[k] = gz[k] = gn[k] = gh[k] = hp[k] = dh[k] = 0.f;
-        }
+        const long row = rbase[rl] + (long)t * a.A;
+        rowv[k] = row;
+        const float* g = a.gates + row * (4 * H);
+        gr[k] = g[c]; gz[k] = g[H + c]; gn[k] = g[2 * H + c]; gh[k] = g[3 * H + c];
+        hp[k] = a.hprev[row * H + c];
+        dh[k] = a.dhs[row * H + c];
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int rl = (tid >> 7) + 2 * (kb + k);
-        float d_r = 0.f, d_z = 0.f, d_hb = 0.f, carry = 0.f;
-        if (rowv[k] >= 0) {
-          const float r = gr[k], z = gz[k], n = gn[k], hb = gh[k];
-          const float dht_ = dh[k] + dht[rl * HP + c];
-          const float dn = dht_ * (1.0f - z);
-          const float dz = dht_ * (hp[k] - n);
-          const float dan = dn * (1.0f - n * n);
-          d_hb = dan * r;
-          d_r = dan * hb * r * (1.0f - r);
-          d_z = dz * z * (1.0f - z);
-          carry = rst[k] ? 0.f : dht_ * z;
+        const bool ok = FULL || rho0 + rl < a.NR;
+        const bool rst = rflag[rl * a.T + t] != 0;
+        const float r = gr[k], z = gz[k], n = gn[k], hb = gh[k];
+        const float dht_ = dh[k] + dht[rl * HP + c];
+        const float dn = dht_ * (1.0f - z);
+        const float dz = dht_ * (hp[k] - n);
+        const float dan = dn * (1.0f - n * n);
+        float d_hb = dan * r;
+        float d_r = dan * hb * r * (1.0f - r);
+        float d_z = dz * z * (1.0f - z);
+        float carry = rst ? 0.f : dht_ * z;
+        if (ok) {
           float* dx = a.dxi + rowv[k] * G3;
           dx[c] = d_r; dx[H + c] = d_z; dx[2 * H + c] = dan;
           float* dq = a.dhh + rowv[k] * G3;
           dq[c] = d_r; dq[H + c] = d_z; dq[2 * H + c] = d_hb;
           bacc += d_hb;
-          if (rst[k]) { d_r = 0.f; d_z = 0.f; d_hb = 0.f; }  // no gradient into the (zeroed) previous state
         }
+        if (rst || !ok) { d_r = 0.f; d_z = 0.f; d_hb = 0.f; }  // no gradient into the (zeroed) previous state
+        if (!ok) carry = 0.f;
         dhht[rl * G3P + c] = d_r;
         dhht[rl * G3P + H + c] = d_z;
         dhht[rl * G3P + 2 * H + c] = d_hb;
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a) {
   __shared__ float bsh[256];
   bsh[tid] = bacc;
   __syncthreads();
-  if (tid < 128) a.slab_bhn[(long)blockIdx.x * H + tid] = bsh[tid] + bsh[tid + 128];
+  if (tid < 128) a.slab_bhn[(long)(block0 + blockIdx.x) * H + tid] = bsh[tid] + bsh[tid + 128];
 }
 
 // Y[R][N] = act(X[R][F] @ W[F][N] + b) for small F (actor pre-torso, torsos.py:36-47)
@@ -281,7 +279,12 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
                                   const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
                                   hipStream_t st) {
   GruArgs a{xi, Wht, b_hn, h0, h0_idx, reset, hs, gates, hprev, T, A, nseq * A};
-  hipLaunchKernelGGL(k_gru_scan_fwd, dim3((a.NR + 63) / 64), dim3(256), 0, st, a);
+  if (a.NR <= 0) return MAGPO_OK;
+  const size_t lds = (size_t)64 * T;   // reset flags of the block's rows
+  if (lds > 24 * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }
+  const int nfull = a.NR / 64;
+  if (nfull) hipLaunchKernelGGL(k_gru_scan_fwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
+  if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_fwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_scan_fwd");
 }
 
@@ -290,10 +293,18 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
                                   const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
                                   hipStream_t st) {
   GruBwdArgs a{gates, hprev, reset, dhs, Wh, dxi, dhh, slab_bhn, T, A, nseq * A};
-  size_t lds = (size_t)(64 * HP + 64 * G3P) * sizeof(float);
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL(k_gru_scan_bwd, dim3((a.NR + 63) / 64), dim3(256), lds, st, a);
+  if (a.NR <= 0) return MAGPO_OK;
+  const size_t lds = (size_t)(64 * HP + 64 * G3P) * sizeof(float) + (size_t)64 * T;
+  if (lds > 150 * 1024) { set_error("magpo_gru_scan_bwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_set = lds;
+  }
+  const int nfull = a.NR / 64;
+  if (nfull) hipLaunchKernelGGL(k_gru_scan_bwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
+  if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_bwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_scan_bwd");
 }
 
