@@ -106,15 +106,11 @@ __global__ __launch_bounds__(256) void k_linear_w(const float* __restrict__ X, i
   const int ntiles = (R + 31) >> 5;
   float4 af[KH / 4], an[KH / 4];
   auto fetch = [&](int tile, float4* dst) {
-    const long row = (long)tile * 32 + lr;
-    if (tile < ntiles && row < R) {
-      const float* xp = X + row * (long)ldx + h * KH;
+    // unconditional loads from a clamped row (rows past the end are never stored): no exec-masked block in the pipeline
+    const long row = min((long)tile * 32 + lr, (long)R - 1);
+    const float* xp = X + row * (long)ldx + h * KH;
 #pragma unroll
-      for (int u = 0; u < KH / 4; ++u) dst[u] = *reinterpret_cast<const float4*>(xp + 4 * u);
-    } else {
-#pragma unroll
-      for (int u = 0; u < KH / 4; ++u) dst[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int u = 0; u < KH / 4; ++u) dst[u] = *reinterpret_cast<const float4*>(xp + 4 * u);
   };
   fetch(blockIdx.x, af);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -135,20 +131,34 @@ __global__ __launch_bounds__(256) void k_linear_w(const float* __restrict__ X, i
 #pragma unroll
       for (int b = 0; b < NCB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u].w, wf[b][u].w, acc[b], 0, 0, 0);
     }
+    if (!Ypre && act <= ACT_RELU && (long)tile * 32 + 32 <= R && c0 + 32 * NCB <= NOUT) {
+      // the common case (whole tile, plain / relu output): straight-line stores, no per-element exec masking
 #pragma unroll
-    for (int b = 0; b < NCB; ++b) {
-      const int n = c0 + 32 * b + lr;
-      if (n < NOUT) {
+      for (int b = 0; b < NCB; ++b) {
+        float* yp = Y + ((long)tile * 32 + 4 * h) * (long)ldy + c0 + 32 * b + lr;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const long gr = (long)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (gr < R) {
-            float v = acc[b][i] + bv[b];
-            if (Ypre) Ypre[gr * (long)ldy + n] = v;
-            if (act == ACT_RELU) v = fmaxf(v, 0.f);
-            else if (act == ACT_GELU) v = gelu_tanh(v);
-            else if (act == ACT_SWISH) v = swishf_(v);
-            Y[gr * (long)ldy + n] = v;
+          float v = acc[b][i] + bv[b];
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          yp[(long)((i & 3) + 8 * (i >> 2)) * ldy] = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) {
+        const int n = c0 + 32 * b + lr;
+        if (n < NOUT) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const long gr = (long)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (gr < R) {
+              float v = acc[b][i] + bv[b];
+              if (Ypre) Ypre[gr * (long)ldy + n] = v;
+              if (act == ACT_RELU) v = fmaxf(v, 0.f);
+              else if (act == ACT_GELU) v = gelu_tanh(v);
+              else if (act == ACT_SWISH) v = swishf_(v);
+              Y[gr * (long)ldy + n] = v;
+            }
           }
         }
       }
@@ -365,7 +375,16 @@ __global__ __launch_bounds__(256) void k_linear_wk(const float* __restrict__ X, 
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][u].w, wf[kc][u].w, acc, 0, 0, 0);
       }
     }
-    if (n < NOUT) {
+    if (act <= ACT_RELU && (long)tile * 32 + 32 <= R && c0 + 32 <= NOUT) {
+      // the common case (whole tile, plain / relu output): straight-line stores, no per-element exec masking
+      float* yp = Y + ((long)tile * 32 + 4 * h) * (long)ldy + n;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = acc[i] + bv;
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        yp[(long)((i & 3) + 8 * (i >> 2)) * ldy] = v;
+      }
+    } else if (n < NOUT) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const long gr = (long)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
