@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_linear_w(const float* __restrict__ X, i
                                                   float* __restrict__ Ypre, int R, int NOUT, int act) {
   constexpr int KH = KIN / 2;  // k values per lane half
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, h = lane >> 5;
-  const int c0 = (blockIdx.y * 4 + wave) * 32 * NCB;
+  const int c0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 32 * NCB;
   if (c0 >= NOUT) return;
   float4 wf[NCB][KH / 4];
   float bv[NCB];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_linear_wk(const float* __restrict__ X, 
                                                    int R, int NOUT, int act) {
   constexpr int NKC = KIN / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, h = lane >> 5;
-  const int c0 = (blockIdx.y * 4 + wave) * 32;
+  const int c0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 32;
   if (c0 >= NOUT) return;
   const int n = c0 + lr;
   float4 wf[NKC][8];
@@ -551,12 +551,14 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
   if (R <= 0) return MAGPO_OK;
   if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
   if ((KIN == 128 || KIN == 192 || KIN == 256 || KIN == 384) && !Ypre) {
+    // persistent waves: one wave per (walker, 32-column group); blocks of 4 / 2 / 1 waves so that every wave slot of
+    // a CU can be filled (a 3-wave block leaves a quarter of the slots idle), about one resident wave set in total
     const int ncg = (NOUT + 31) / 32;
-    const int wpb = ncg < 4 ? ncg : 4;
+    const int wpb = (ncg % 4 == 0) ? 4 : ((ncg % 2 == 0) ? 2 : 1);
     const long ntiles = (R + 31) / 32;
     long walkers = 2048 / wpb;
     if (walkers > ntiles) walkers = ntiles;
-    dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
+    dim3 grid((unsigned)walkers, (unsigned)(ncg / wpb)), block(64 * wpb);
     if (KIN == 128) hipLaunchKernelGGL((k_linear_wk<128>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
     else if (KIN == 192) hipLaunchKernelGGL((k_linear_wk<192>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
     else if (KIN == 256) hipLaunchKernelGGL((k_linear_wk<256>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
@@ -565,13 +567,14 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
   }
   if (KIN == 64 || KIN == 128) {
     // wave-autonomous path: 64 columns per wave, up to 4 waves (256 columns) per workgroup
-    const int cpw = KIN == 64 ? 64 : 32;  // columns per wave
+    const int cpw = KIN == 64 ? 64 : 32;  // columns per wave (128 per wave was measured slower: 256 VGPRs + spills)
     const int ncg = (NOUT + cpw - 1) / cpw;
-    const int wpb = ncg < 4 ? ncg : 4;
+    const int wpb = (ncg % 4 == 0) ? 4 : ((ncg % 2 == 0) ? 2 : 1);
     const long ntiles = (R + 31) / 32;
-    long walkers = 2048 / wpb;  // 2 waves per SIMD on 256 CUs (register-limited)
+    long walkers = 2048 / ncg;  // about one resident wave set (2 waves per SIMD on 256 CUs, register-limited)
+    if (walkers < 1) walkers = 1;
     if (walkers > ntiles) walkers = ntiles;
-    dim3 grid((unsigned)walkers, (unsigned)((ncg + 3) / 4)), block(64 * wpb);
+    dim3 grid((unsigned)walkers, (unsigned)(ncg / wpb)), block(64 * wpb);
     if (KIN == 64) hipLaunchKernelGGL((k_linear_w<64, 2>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
     else hipLaunchKernelGGL((k_linear_w<128, 1>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, Ypre, (int)R, NOUT, act);
     return check_launch("magpo_linear");
