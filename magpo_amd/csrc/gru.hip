@@ -166,7 +166,6 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
 #pragma unroll
   for (int u = 0; u < 48; ++u) wf[u] = *reinterpret_cast<const float4*>(a.Wh + (long)col * G3 + 192 * h + 4 * u);
   for (int i = tid; i < 64 * HP; i += 256) dht[i] = 0.f;
-  float bacc = 0.f;  // thread owns column (tid & 127) for rows (tid >> 7) + 2k
   __shared__ long rbase[64];
   if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, a.T, a.A);   // invalid rows shadow the last valid one
   for (int i = tid; i < 64 * a.T; i += 256) {
@@ -175,50 +174,62 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
     rflag[i] = a.reset[(long)(rho / a.A) * a.T + t];
   }
   __syncthreads();
-  const int c = tid & 127;
+  // ---- elementwise map: thread owns 4 consecutive columns c4..c4+3 of rows rl = (tid >> 5) + 8 k (k = 0..7): every global
+  // access is a float4 (6 loads + 6 stores per row instead of 24 + 24 scalars; the scalar version kept >63 stores in flight,
+  // so the in-order vmcnt throttled the whole phase)
+  const int c4 = 4 * (tid & 31), rg = tid >> 5;
+  float4 bacc4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = a.T - 1; t >= 0; --t) {
-    // ---- elementwise phase: column c, rows rl = (tid >> 7) + 2 k, in groups of 8 rows with all loads issued first
-#pragma unroll 1
-    for (int kb = 0; kb < 32; kb += 8) {
-      float gr[8], gz[8], gn[8], gh[8], hp[8], dh[8];
+    {
+      float4 gr[8], gz[8], gn[8], gh[8], hp[8], dh[8];
       long rowv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int rl = (tid >> 7) + 2 * (kb + k);
+        const int rl = rg + 8 * k;
         const long row = rbase[rl] + (long)t * a.A;
         rowv[k] = row;
-        const float* g = a.gates + row * (4 * H);
-        gr[k] = g[c]; gz[k] = g[H + c]; gn[k] = g[2 * H + c]; gh[k] = g[3 * H + c];
-        hp[k] = a.hprev[row * H + c];
-        dh[k] = a.dhs[row * H + c];
+        const float* g = a.gates + row * (4 * H) + c4;
+        gr[k] = *reinterpret_cast<const float4*>(g); gz[k] = *reinterpret_cast<const float4*>(g + H);
+        gn[k] = *reinterpret_cast<const float4*>(g + 2 * H); gh[k] = *reinterpret_cast<const float4*>(g + 3 * H);
+        hp[k] = *reinterpret_cast<const float4*>(a.hprev + row * H + c4);
+        dh[k] = *reinterpret_cast<const float4*>(a.dhs + row * H + c4);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int rl = (tid >> 7) + 2 * (kb + k);
+        const int rl = rg + 8 * k;
         const bool ok = FULL || rho0 + rl < a.NR;
         const bool rst = rflag[rl * a.T + t] != 0;
-        const float r = gr[k], z = gz[k], n = gn[k], hb = gh[k];
-        const float dht_ = dh[k] + dht[rl * HP + c];
-        const float dn = dht_ * (1.0f - z);
-        const float dz = dht_ * (hp[k] - n);
-        const float dan = dn * (1.0f - n * n);
-        float d_hb = dan * r;
-        float d_r = dan * hb * r * (1.0f - r);
-        float d_z = dz * z * (1.0f - z);
-        float carry = rst ? 0.f : dht_ * z;
-        if (ok) {
-          float* dx = a.dxi + rowv[k] * G3;
-          dx[c] = d_r; dx[H + c] = d_z; dx[2 * H + c] = dan;
-          float* dq = a.dhh + rowv[k] * G3;
-          dq[c] = d_r; dq[H + c] = d_z; dq[2 * H + c] = d_hb;
-          bacc += d_hb;
+        const float4 dc = *reinterpret_cast<const float4*>(&dht[rl * HP + c4]);
+        float4 o_r, o_z, o_an, o_hb, carry;
+#define GRU_BWD_ELEM(X)                                                   \
+        {                                                                 \
+          const float r = gr[k].X, z = gz[k].X, n = gn[k].X, hb = gh[k].X; \
+          const float dht_ = dh[k].X + dc.X;                              \
+          const float dn = dht_ * (1.0f - z);                             \
+          const float dz = dht_ * (hp[k].X - n);                          \
+          const float dan = dn * (1.0f - n * n);                          \
+          o_an.X = dan;                                                   \
+          o_hb.X = dan * r;                                               \
+          o_r.X = dan * hb * r * (1.0f - r);                              \
+          o_z.X = dz * z * (1.0f - z);                                    \
+          carry.X = rst ? 0.f : dht_ * z;                                 \
         }
-        if (rst || !ok) { d_r = 0.f; d_z = 0.f; d_hb = 0.f; }  // no gradient into the (zeroed) previous state
-        if (!ok) carry = 0.f;
-        dhht[rl * G3P + c] = d_r;
-        dhht[rl * G3P + H + c] = d_z;
-        dhht[rl * G3P + 2 * H + c] = d_hb;
-        dht[rl * HP + c] = carry;  // direct path; the GEMM below adds dhh @ W_h^T
+        GRU_BWD_ELEM(x) GRU_BWD_ELEM(y) GRU_BWD_ELEM(z) GRU_BWD_ELEM(w)
+#undef GRU_BWD_ELEM
+        if (ok) {
+          float* dx = a.dxi + rowv[k] * G3 + c4;
+          *reinterpret_cast<float4*>(dx) = o_r; *reinterpret_cast<float4*>(dx + H) = o_z; *reinterpret_cast<float4*>(dx + 2 * H) = o_an;
+          float* dq = a.dhh + rowv[k] * G3 + c4;
+          *reinterpret_cast<float4*>(dq) = o_r; *reinterpret_cast<float4*>(dq + H) = o_z; *reinterpret_cast<float4*>(dq + 2 * H) = o_hb;
+          bacc4.x += o_hb.x; bacc4.y += o_hb.y; bacc4.z += o_hb.z; bacc4.w += o_hb.w;
+        }
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rst || !ok) { o_r = z4; o_z = z4; o_hb = z4; }  // no gradient into the (zeroed) previous state
+        if (!ok) carry = z4;
+        *reinterpret_cast<float4*>(&dhht[rl * G3P + c4]) = o_r;
+        *reinterpret_cast<float4*>(&dhht[rl * G3P + H + c4]) = o_z;
+        *reinterpret_cast<float4*>(&dhht[rl * G3P + 2 * H + c4]) = o_hb;
+        *reinterpret_cast<float4*>(&dht[rl * HP + c4]) = carry;  // direct path; the GEMM below adds dhh @ W_h^T
       }
     }
     __syncthreads();
@@ -245,11 +256,16 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
     }
     __syncthreads();
   }
-  // b_hn gradient: sum over the two row-parities handled by threads c and c+128
-  __shared__ float bsh[256];
-  bsh[tid] = bacc;
+  // b_hn gradient: sum over the 8 row groups (threads with the same tid & 31)
+  __shared__ float bsh[8][H];
+  *reinterpret_cast<float4*>(&bsh[rg][c4]) = bacc4;
   __syncthreads();
-  if (tid < 128) a.slab_bhn[(long)(block0 + blockIdx.x) * H + tid] = bsh[tid] + bsh[tid + 128];
+  if (tid < H) {
+    float sb = 0.f;
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) sb += bsh[r8][tid];
+    a.slab_bhn[(long)(block0 + blockIdx.x) * H + tid] = sb;
+  }
 }
 
 // Y[R][N] = act(X[R][F] @ W[F][N] + b) for small F (actor pre-torso, torsos.py:36-47)
