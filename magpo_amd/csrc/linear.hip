@@ -11,6 +11,7 @@
 // once in LDS ([64][KIN+4] floats, ds_read_b128 per lane conflict-free); B fragments come
 // straight from L2 into VGPRs (each lane owns one output column and 32 contiguous k's).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace magpo {
 
@@ -400,6 +401,95 @@ __global__ __launch_bounds__(256) void k_linear_wk(const float* __restrict__ X, 
   }
 }
 
+// Wide-input dense layer, second form: weights register-resident as in k_linear_wk, but the 32-row activation tile is
+// fetched ONCE per workgroup with fully coalesced loads and shared by the 4 waves through a double-buffered LDS tile.
+// k_linear_wk lets every wave fetch its own copy of the tile as per-lane 128-B row pieces: 64 cache lines touched by each
+// load instruction, 4096 line requests per tile and workgroup -- the L1 tag rate, not MFMA or HBM, bounds it (~50 % of the
+// MFMA peak).  Here a tile costs KIN/4 coalesced line requests and one barrier.
+template <int KIN, int NW>
+__global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict__ X, int ldx, const float* __restrict__ Wt,
+                                                    const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                    int R, int NOUT, int act) {
+  constexpr int NKC = KIN / 64, PT = KIN + LDP, NT = 64 * NW, NLD = 32 * (KIN / 4) / NT;   // NLD float4 per thread and tile
+  extern __shared__ __align__(16) float ll_smem[];                // 2 x [32][PT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int c0 = (blockIdx.y * NW + wave) * 32;
+  const bool colon = c0 < NOUT;                                   // waves past the last column group only help with the loads
+  const int n = c0 + lr;
+  float4 wf[NKC][8];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      wf[kc][u] = colon ? *reinterpret_cast<const float4*>(Wt + (long)n * KIN + kc * 64 + 32 * h + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float bv = (bias && n < NOUT) ? bias[n] : 0.f;
+  const int ntiles = (R + 31) >> 5;
+  float4 pre[NLD];
+#define LL_FETCH(TILE)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                      \
+    const int idx = tid + NT * j;                                                                        \
+    const long row = min((long)(TILE) * 32 + idx / (KIN / 4), (long)R - 1);                               \
+    pre[j] = *reinterpret_cast<const float4*>(X + row * (long)ldx + 4 * (idx % (KIN / 4)));              \
+  }
+#define LL_STASH(BUF)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                      \
+    const int idx = tid + NT * j;                                                                        \
+    *reinterpret_cast<float4*>(&(BUF)[(idx / (KIN / 4)) * PT + 4 * (idx % (KIN / 4))]) = pre[j];         \
+  }
+  LL_FETCH(blockIdx.x)
+  LL_STASH(ll_smem)
+  __syncthreads();
+  int par = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const float* buf = ll_smem + par * 32 * PT;
+    LL_FETCH(min(tile + (int)gridDim.x, ntiles - 1))   // in flight under this tile's MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* ap = buf + lr * PT + 32 * h;
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + kc * 64 + 4 * u);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[kc][u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[kc][u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[kc][u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[kc][u].w, acc, 0, 0, 0);
+      }
+    }
+    float* nbuf = ll_smem + (par ^ 1) * 32 * PT;     // the other buffer: nobody reads it during this tile
+    LL_STASH(nbuf)
+    if (colon) {
+      if (act <= ACT_RELU && (long)tile * 32 + 32 <= R && c0 + 32 <= NOUT) {
+        float* yp = Y + ((long)tile * 32 + 4 * h) * (long)ldy + n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = acc[i] + bv;
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          yp[(long)((i & 3) + 8 * (i >> 2)) * ldy] = v;
+        }
+      } else if (n < NOUT) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long gr = (long)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (gr < R) {
+            float v = acc[i] + bv;
+            if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == ACT_GELU) v = gelu_tanh(v);
+            else if (act == ACT_SWISH) v = swishf_(v);
+            Y[gr * (long)ldy + n] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();   // next tile stashed by everyone, this tile's LDS reads done
+    par ^= 1;
+  }
+#undef LL_FETCH
+#undef LL_STASH
+}
+
 // dW slab: grid (G, ceil(NOUT / (64 NB)), KIN / 64).  Software pipeline: the next row tile is fetched
 // from HBM into registers while the MFMAs of the current tile run out of LDS.
 template <int NB>
@@ -550,7 +640,8 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
                             long R, int KIN, int NOUT, int act, hipStream_t stream) {
   if (R <= 0) return MAGPO_OK;
   if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
-  if ((KIN == 128 || KIN == 192 || KIN == 256 || KIN == 384) && !Ypre) {
+  static const bool lds64 = []() { const char* e = getenv("MAGPO_LINEAR_LDS64"); return !e || atoi(e) != 0; }();
+  if ((KIN == 128 || KIN == 192 || KIN == 256 || KIN == 384 || (KIN == 64 && lds64)) && !Ypre) {
     // persistent waves: one wave per (walker, 32-column group); blocks of 4 / 2 / 1 waves so that every wave slot of
     // a CU can be filled (a 3-wave block leaves a quarter of the slots idle), about one resident wave set in total
     const int ncg = (NOUT + 31) / 32;
@@ -559,6 +650,31 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
     long walkers = 2048 / wpb;
     if (walkers > ntiles) walkers = ntiles;
     dim3 grid((unsigned)walkers, (unsigned)(ncg / wpb)), block(64 * wpb);
+    static const bool use_lds = []() { const char* e = getenv("MAGPO_LINEAR_LDS"); return !e || atoi(e) != 0; }();
+    if (use_lds) {
+      // shared-tile form: 4 waves per block, 2 when the column groups do not fill blocks of 4 (every wave then has MFMA work);
+      // column groups past NOUT idle in the MFMA part but help loading
+      const int nw = (ncg % 4 == 0) ? 4 : 2;
+      const int gy = (ncg + nw - 1) / nw;
+      long wk2 = 2048 / nw;   // about 2 waves per SIMD; LDS 2 x 32 x (KIN + 4) floats per block
+      if (wk2 > ntiles) wk2 = ntiles;
+      dim3 g2((unsigned)wk2, (unsigned)gy), b2(64 * nw);
+      const size_t lds = (size_t)2 * 32 * (KIN + LDP) * sizeof(float);
+#define LAUNCH_LDS(K_)                                                                                                   \
+      {                                                                                                                 \
+        static bool attr = false;                                                                                       \
+        if (!attr && lds > 65536) {                                                                                     \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_lds<K_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_lds<K_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+          attr = true;                                                                                                  \
+        }                                                                                                               \
+        if (nw == 4) hipLaunchKernelGGL((k_linear_lds<K_, 4>), g2, b2, lds, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act); \
+        else hipLaunchKernelGGL((k_linear_lds<K_, 2>), g2, b2, lds, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act); \
+      }
+      if (KIN == 64) LAUNCH_LDS(64) else if (KIN == 128) LAUNCH_LDS(128) else if (KIN == 192) LAUNCH_LDS(192) else if (KIN == 256) LAUNCH_LDS(256) else LAUNCH_LDS(384)
+#undef LAUNCH_LDS
+      return check_launch("magpo_linear");
+    }
     if (KIN == 128) hipLaunchKernelGGL((k_linear_wk<128>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
     else if (KIN == 192) hipLaunchKernelGGL((k_linear_wk<192>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
     else if (KIN == 256) hipLaunchKernelGGL((k_linear_wk<256>), grid, block, 0, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act);
