@@ -492,6 +492,17 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
 
 // dW slab: grid (G, ceil(NOUT / (64 NB)), KIN / 64).  Software pipeline: the next row tile is fetched
 // from HBM into registers while the MFMAs of the current tile run out of LDS.
+#ifdef MAGPO_WG_PROF
+__device__ unsigned long long g_wg_prof[8];
+#define WP_DECL() unsigned long long wp_acc[4] = {0, 0, 0, 0}; unsigned long long wp_last = clock64();
+#define WP(k) do { unsigned long long t_ = clock64(); wp_acc[k] += t_ - wp_last; wp_last = t_; } while (0)
+#define WP_FLUSH() do { if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && blockIdx.y == 0 && blockIdx.z == 0) { for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_wg_prof[k_], wp_acc[k_]); } } while (0)
+#else
+#define WP_DECL()
+#define WP(k)
+#define WP_FLUSH()
+#endif
+
 template <int NB>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
                                                int R, int KIN, int NOUT, float* __restrict__ slab,
@@ -513,73 +524,146 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
   const bool do_bias = bias_slab != nullptr && kb == 0;
   const bool full_cols = (c0 + 64 * NB <= NOUT) && ((ldy & 3) == 0);
 
-  float4 xr[4], yr[4 * NB];
-  auto fetch = [&](int tile) {
-    const long row0 = (long)tile * 64;
+  WP_DECL();
+  if (full_cols) {
+    float4 nx[4 + 4 * NB];   // next tile: 4 float4 of X, then 4 NB of dY
+    // Fast path (whole column block, aligned rows): the next tile's 4 + 4 NB loads are issued ONE AT A TIME between the
+    // MFMA steps of the current tile.  Issued as a burst they sit in front of the MFMA loop in the wave's in-order
+    // instruction stream while the memory pipeline back-pressures (in-kernel timing: the burst took as long as the
+    // MFMA loop itself).  Loads are unconditional from clamped rows; rows past the end are zeroed when stashed.
+    constexpr int YR = 16 * NB;                      // float4 per dY row of this column block
+    const int rx = tid >> 4, cx = 4 * (tid & 15);    // X: float4 j of this thread is row rx + 16 j
+    const int ry = tid / YR, cy = 4 * (tid % YR);    // dY: float4 j is row ry + (256 / YR) j
+    const float* xb = X + kb * 64 + cx;
+    const float* yb = dY + c0 + cy;
+#define WG_LOADX(J, ROW0) nx[J] = *reinterpret_cast<const float4*>(xb + min((ROW0) + rx + 16 * (J), (long)R - 1) * (long)ldx)
+#define WG_LOADY(J, ROW0) nx[4 + (J)] = *reinterpret_cast<const float4*>(yb + min((ROW0) + ry + (256 / YR) * (J), (long)R - 1) * (long)ldy)
+    {
+      const long row0 = (long)min(g, ntiles - 1) * 64;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid + 256 * j;
-      const int r = i >> 4, c4 = i & 15;
-      const long gr = row0 + r;
-      xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < R) xr[j] = *reinterpret_cast<const float4*>(X + gr * (long)ldx + kb * 64 + 4 * c4);
+      for (int j = 0; j < 4; ++j) WG_LOADX(j, row0);
+#pragma unroll
+      for (int j = 0; j < 4 * NB; ++j) WG_LOADY(j, row0);
     }
+    for (int tile = g; tile < ntiles; tile += G) {
+      const long row0 = (long)tile * 64;
+      const long row0n = (long)min(tile + G, ntiles - 1) * 64;
+      __syncthreads();          // MFMAs of the previous tile have finished reading LDS
+      WP(0);
 #pragma unroll
-    for (int j = 0; j < 4 * NB; ++j) {
-      const int i = tid + 256 * j;
-      const int r = i / (16 * NB), c4 = i - r * (16 * NB);
-      const long gr = row0 + r;
-      const int col = c0 + 4 * c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < R) {
-        const float* p = dY + gr * (long)ldy + col;
-        if (full_cols || col + 3 < NOUT) v = *reinterpret_cast<const float4*>(p);
-        else {
-          if (col + 0 < NOUT) v.x = p[0];
-          if (col + 1 < NOUT) v.y = p[1];
-          if (col + 2 < NOUT) v.z = p[2];
+      for (int j = 0; j < 4; ++j) {   // (component-wise selects: a select between &nx[j] and a zero slot would pin nx[] in scratch)
+        float4 v = nx[j];
+        const bool ok = row0 + rx + 16 * j < R;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        *reinterpret_cast<float4*>(&xs[(rx + 16 * j) * LDX + cx]) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4 * NB; ++j) {
+        float4 v = nx[4 + j];
+        const bool ok = row0 + ry + (256 / YR) * j < R;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        *reinterpret_cast<float4*>(&ys[(ry + (256 / YR) * j) * LDY + cy]) = v;
+      }
+      __syncthreads();
+      WP(1);
+      WP(2);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const int tok = 32 * h + s;
+        const float a = xs[tok * LDX + 32 * wr + lr];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float bb = ys[tok * LDY + 64 * b + 32 * wc + lr];
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[b], 0, 0, 0);
+        }
+        // one load of the next tile every second MFMA step (after unrolling, s and the register index are constants)
+        if ((s & 1) && (s >> 1) < 4 + 4 * NB) {
+          const int li = s >> 1;
+          const float* src = li < 4 ? xb + min(row0n + rx + 16 * li, (long)R - 1) * (long)ldx
+                                    : yb + min(row0n + ry + (256 / YR) * (li - 4), (long)R - 1) * (long)ldy;
+          nx[li] = *reinterpret_cast<const float4*>(src);
         }
       }
-      yr[j] = v;
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid + 256 * j;
-      *reinterpret_cast<float4*>(&xs[(i >> 4) * LDX + 4 * (i & 15)]) = xr[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 4 * NB; ++j) {
-      const int i = tid + 256 * j;
-      const int r = i / (16 * NB), c4 = i - r * (16 * NB);
-      *reinterpret_cast<float4*>(&ys[r * LDY + 4 * c4]) = yr[j];
-    }
-  };
-
-  if (g < ntiles) fetch(g);
-  for (int tile = g; tile < ntiles; tile += G) {
-    __syncthreads();          // MFMAs of the previous tile have finished reading LDS
-    stash();
-    __syncthreads();
-    if (tile + G < ntiles) fetch(tile + G);   // in flight during the MFMA loop below
-#pragma unroll 4
-    for (int s = 0; s < 32; ++s) {
-      const int tok = 32 * h + s;
-      const float a = xs[tok * LDX + 32 * wr + lr];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float bb = ys[tok * LDY + 64 * b + 32 * wc + lr];
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[b], 0, 0, 0);
+      WP(3);
+      if (do_bias && tid < 64 * NB) {
+        float sb = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) sb += ys[r * LDY + tid];
+        bsum += sb;
       }
     }
-    if (do_bias && tid < 64 * NB) {
-      float sb = 0.f;
+#undef WG_LOADX
+#undef WG_LOADY
+  } else {
+    float4 xq[4], yq[4 * NB];
+    auto fetch = [&](int tile) {
+      const long row0 = (long)tile * 64;
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j;
+        const int r = i >> 4, c4 = i & 15;
+        const long gr = row0 + r;
+        xq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < R) xq[j] = *reinterpret_cast<const float4*>(X + gr * (long)ldx + kb * 64 + 4 * c4);
+      }
+  #pragma unroll
+      for (int j = 0; j < 4 * NB; ++j) {
+        const int i = tid + 256 * j;
+        const int r = i / (16 * NB), c4 = i - r * (16 * NB);
+        const long gr = row0 + r;
+        const int col = c0 + 4 * c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < R) {
+          const float* p = dY + gr * (long)ldy + col;
+          if (full_cols || col + 3 < NOUT) v = *reinterpret_cast<const float4*>(p);
+          else {
+            if (col + 0 < NOUT) v.x = p[0];
+            if (col + 1 < NOUT) v.y = p[1];
+            if (col + 2 < NOUT) v.z = p[2];
+          }
+        }
+        yq[j] = v;
+      }
+    };
+    auto stash = [&]() {
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j;
+        *reinterpret_cast<float4*>(&xs[(i >> 4) * LDX + 4 * (i & 15)]) = xq[j];
+      }
+  #pragma unroll
+      for (int j = 0; j < 4 * NB; ++j) {
+        const int i = tid + 256 * j;
+        const int r = i / (16 * NB), c4 = i - r * (16 * NB);
+        *reinterpret_cast<float4*>(&ys[r * LDY + 4 * c4]) = yq[j];
+      }
+    };
+
+    if (g < ntiles) fetch(g);
+    for (int tile = g; tile < ntiles; tile += G) {
+      __syncthreads();          // MFMAs of the previous tile have finished reading LDS
+      stash();
+      __syncthreads();
+      if (tile + G < ntiles) fetch(tile + G);   // in flight during the MFMA loop below
+#pragma unroll 4
+      for (int s = 0; s < 32; ++s) {
+        const int tok = 32 * h + s;
+        const float a = xs[tok * LDX + 32 * wr + lr];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float bb = ys[tok * LDY + 64 * b + 32 * wc + lr];
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[b], 0, 0, 0);
+        }
+      }
+      if (do_bias && tid < 64 * NB) {
+        float sb = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 64; ++r) sb += ys[r * LDY + tid];
-      bsum += sb;
+        for (int r = 0; r < 64; ++r) sb += ys[r * LDY + tid];
+        bsum += sb;
+      }
     }
   }
+  WP_FLUSH();
   float* out = slab + (long)g * KIN * NOUT;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -781,3 +865,11 @@ extern "C" int magpo_transpose_pad(const float* W, float* Wt, int K, int N, int 
   hipLaunchKernelGGL(k_transpose_pad, dim3((total + 255) / 256), dim3(256), 0, stream, W, Wt, K, N, Npad);
   return check_launch("magpo_transpose_pad");
 }
+
+#ifdef MAGPO_WG_PROF
+extern "C" int magpo_debug_wg_prof(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_wg_prof), sizeof(unsigned long long) * 8) != hipSuccess) return MAGPO_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_wg_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
+  return MAGPO_OK;
+}
+#endif
