@@ -126,6 +126,9 @@ int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                        const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
                        magpo_stream_t stream);
+/* hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
+int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,
+                    float* h_last, int nenv, int T, int A, magpo_stream_t stream);
 int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned char* reset, const float* dhs,
                        const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
                        magpo_stream_t stream);

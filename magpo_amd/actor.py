@@ -100,6 +100,18 @@ class GruActor:
         self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
         return logits
 
+    def carry(self, obs_tm, h_in, reset_tm, h_out):
+        """Hidden-state carry over a whole rollout at once: obs_tm [T,N,A,F] (time-major trajectory), reset_tm [T,N] u8
+        reset-before-step flags, h_in / h_out [N*A,128].  Same result as T calls of :meth:`step` (ScannedRNN, base.py:121-149):
+        the carry depends on (obs, done) only, never on the sampled actions."""
+        L, st, A, F, v, b = self.L, self._st(), self.A, self.F, self.v, self.b
+        T, N = obs_tm.shape[0], obs_tm.shape[1]
+        R = T * N * A
+        emb = b.get("c_emb", (R, H)); xi = b.get("c_xi", (R, 3 * H))
+        L.call("magpo_small_linear", obs_tm, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
+        self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
+        L.call("magpo_gru_carry", xi, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, st)
+
     def seq_fwd(self, obs, dones, h0, h0_idx, nseq: int, T: int):
         """obs [R,F] rows (seq, t, agent); dones [nseq,T] u8 resets; h0 [*,128] gathered through h0_idx [nseq*A].
         Returns raw logits [R,64] (K valid columns)."""

@@ -28,6 +28,8 @@ struct GruArgs {
   float* gates;           // [R][4H] r | z | n | (h W_hn + b_hn)   (nullable: acting)
   float* hprev;           // [R][H] reset-applied state each step started from (nullable: acting)
   int T, A, NR;           // NR = nseq * A recurrent rows
+  int time_major;         // 0: rows (seq, t, agent), reset [nseq][T];  1: rows (t, seq, agent), reset [T][nseq] (rollout trajectory)
+  float* h_last;          // [NR][H] state after the last step (nullable)
 };
 
 __device__ __forceinline__ long tok_row(int rho, int t, int T, int A) {
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
   for (int i = tid; i < 64 * T; i += 256) {
     const int rl = i / T, t = i - rl * T;
     const int rho = min(rho0 + rl, a.NR - 1);
-    rflag[i] = a.reset[(long)(rho / a.A) * T + t];
+    rflag[i] = a.time_major ? a.reset[(long)t * (a.NR / a.A) + rho / a.A] : a.reset[(long)(rho / a.A) * T + t];
   }
   // initial carry (with the reset of step 0 applied)
   for (int i = tid; i < 64 * (H / 4); i += 256) {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rho < a.NR) {
       int seq = rho / a.A;
-      if (!a.reset[(long)seq * T]) {
+      if (!(a.time_major ? a.reset[seq] : a.reset[(long)seq * T])) {
         long src = a.h0_idx ? a.h0_idx[rho] : rho;
         v = *reinterpret_cast<const float4*>(a.h0 + src * H + 4 * c4);
       }
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
   }
   // per-row bookkeeping (no integer division inside the scan): token row of step 0 (invalid rows shadow the last valid one)
   __shared__ long rbase[64];
-  if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
+  if (tid < 64) rbase[tid] = a.time_major ? (long)min(rho0 + tid, a.NR - 1) : tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
+  const long t_stride = a.time_major ? a.NR : a.A;   // rows between consecutive steps of one recurrent row
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const float* hold = hbuf[t & 1];
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const long row = rbase[rl] + (long)t * a.A;
+        const long row = rbase[rl] + (long)t * t_stride;
         rowi[i] = row;
         const float* x = a.xi + row * G3;
         xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         const float hp = hold[rl * HP + col];
         float hn_new = (1.0f - z) * n + z * hp;
         if (FULL || rho0 + rl < a.NR) {
-          a.hs[row * H + col] = hn_new;
+          if (a.hs) a.hs[row * H + col] = hn_new;
+          if (a.h_last && !more) a.h_last[(long)(rho0 + rl) * H + col] = hn_new;
           if (a.gates) {
             float* g = a.gates + row * (4 * H);
             g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
@@ -294,7 +298,7 @@ using namespace magpo;
 extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                                   const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
                                   hipStream_t st) {
-  GruArgs a{xi, Wht, b_hn, h0, h0_idx, reset, hs, gates, hprev, T, A, nseq * A};
+  GruArgs a{xi, Wht, b_hn, h0, h0_idx, reset, hs, gates, hprev, T, A, nseq * A, 0, nullptr};
   if (a.NR <= 0) return MAGPO_OK;
   const size_t lds = (size_t)64 * T;   // reset flags of the block's rows
   if (lds > 24 * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }
@@ -302,6 +306,21 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
   if (nfull) hipLaunchKernelGGL(k_gru_scan_fwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
   if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_fwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_scan_fwd");
+}
+
+// Hidden-state carry over a time-major trajectory (the rollout's obs / done buffers): rows (t, env, agent), reset [T][nenv];
+// only the state after the last step is written.  The carry is a pure function of (obs, done), so the rollout computes it
+// once for all T steps instead of once per env step (ScannedRNN semantics, base.py:121-149).
+extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,
+                               float* h_last, int nenv, int T, int A, hipStream_t st) {
+  GruArgs a{xi, Wht, b_hn, h0, nullptr, reset_tm, nullptr, nullptr, nullptr, T, A, nenv * A, 1, h_last};
+  if (a.NR <= 0 || T <= 0) return MAGPO_OK;
+  const size_t lds = (size_t)64 * T;
+  if (lds > 24 * 1024) { set_error("magpo_gru_carry: T too large for the LDS flag table"); return MAGPO_EINVAL; }
+  const int nfull = a.NR / 64;
+  if (nfull) hipLaunchKernelGGL(k_gru_scan_fwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
+  if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_fwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
+  return check_launch("magpo_gru_carry");
 }
 
 // slab_bhn: [ceil(NR/64)][128]

@@ -203,6 +203,7 @@ class MagpoLearner:
 
     # ------------------------------------------------------------------ rollout (rec_magpo.py:126-212)
     overlap_actor_step = False  # (measured slower: the acting kernel already fills every wave slot) actor hidden-state carry on a side stream beside the guider's acting kernel
+    batched_actor_carry = True  # actor hidden-state carry as ONE scan over the finished trajectory (not T single steps)
     fused_act = True  # one launch per env step for the whole Sable acting step (csrc/act_fused.hip)
     use_graph = True  # replay the whole rollout as one HIP graph (removes ~11K host launches per rollout)
 
@@ -274,15 +275,16 @@ class MagpoLearner:
 
         for t in range(T):
             obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
-            # the actor's hidden-state carry is a pure function of (obs, done): it runs beside the guider on a side stream
-            h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
-            if side is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
+            if not self.batched_actor_carry:
+                # the actor's hidden-state carry is a pure function of (obs, done); per step it can run on a side stream
+                h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
+                if side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        self.actor.step(obs, h_in, done_prev, h_out)
+                else:
                     self.actor.step(obs, h_in, done_prev, h_out)
-            else:
-                self.actor.step(obs, h_in, done_prev, h_out)
-            g.cur = 1 - g.cur
+                g.cur = 1 - g.cur
             if fused:   # states of envs whose episode just ended read as zero inside the kernel (rec_magpo.py:164-169)
                 act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], done=done_prev)
             else:
@@ -293,6 +295,9 @@ class MagpoLearner:
                 zero_done(tr["done"][t + 1])
         if side is not None:
             main.wait_stream(side)
+        if self.batched_actor_carry:   # one scan over the finished trajectory instead of T single steps (same result)
+            self.actor.carry(tr["obs"][:T], g.policy_h[g.cur], tr["done"][:T], g.policy_h[1 - g.cur])
+            g.cur = 1 - g.cur
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])
             g.cur = 0
