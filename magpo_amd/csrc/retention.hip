@@ -259,14 +259,11 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
     if (!pre) build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, c, 1);  // contains __syncthreads
     else __syncthreads();
     const ChunkMeta& meta = sm.ch[pre ? c : 0];
-    {  // next chunk's tiles are in flight while this chunk's GEMMs run (last chunk: re-reads itself, branch-free)
-      const bool more = c + 1 < nch;
-      const int nvn = more ? min(Lt, a.T - (t0 + Lt)) * a.A : nvalid;
-      const long rn = more ? r0 + L : r0;
-      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
-      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
-      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
-    }
+    // next chunk's tiles (last chunk: re-reads itself, branch-free) are fetched one at a time between the GEMM phases
+    const bool more = c + 1 < nch;
+    const int nvn = more ? min(Lt, a.T - (t0 + Lt)) * a.A : nvalid;
+    const long rn = more ? r0 + L : r0;
+    fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
     if (a.states) store_state(a.states + ((long)seq * nch + c) * 4096, Ss);
 
     f32x16 sc, o;
@@ -287,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
       sc[i] *= lm.w[i];
     }
     __syncthreads();  // everyone done reading Qs
+    fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
 #pragma unroll
     for (int i = 0; i < 16; ++i) Qs[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr] = sc[i];
     __syncthreads();
@@ -300,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
       float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.r + (r0 + ri) * a.ldr + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
       *dst = o[i];
     }
+    fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
     // state update  S <- gamma S + (eta K)^T V
     f32x16 sn;
     const float gm = meta.gamma;
@@ -386,15 +385,12 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, c, 1);
     } else __syncthreads();
     const ChunkMeta& meta = sm.ch[pre ? c : 0];
-    {  // previous chunk (next in the reverse sweep): loads in flight during the 9 GEMMs below (chunk 0 re-reads itself)
-      const long rn = c > 0 ? r0 - L : r0;
-      const int nvn = c > 0 ? L : nvalid;
-      fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
-      fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
-      fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
-      fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, nvn, w4);
-      fetch_state(ps, a.states + ((long)seq * nch + max(c - 1, 0)) * 4096);
-    }
+    // previous chunk (next in the reverse sweep; chunk 0 re-reads itself): its five tiles are fetched one at a time between
+    // the GEMM phases below -- issued as one burst of 20 loads they would sit in front of the first MFMAs in the wave's in-order
+    // instruction stream while the memory pipeline back-pressures
+    const long rn = c > 0 ? r0 - L : r0;
+    const int nvn = c > 0 ? L : nvalid;
+    fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
 
     RP(0);
     LaneMeta lm;
@@ -418,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       }
     }
     __syncthreads();
+    fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
     RP(1);
     // dQ = dP K + beta * (dO S_c^T)
     {
@@ -435,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
         *dst = acc1[i] + lm.beta[i] * acc2[i];
       }
     }
+    fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
     RP(2);
     // dK = dP^T Q + eta * (V G^T)
     {
@@ -452,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
         *dst = acc1[i] + lm.eta[i] * acc2[i];
       }
     }
+    fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, nvn, w4);
     RP(3);
     // dV = P^T dO + eta * (K G)
     {
@@ -468,6 +467,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
         *dst = acc1[i] + lm.eta[i] * acc2[i];
       }
     }
+    fetch_state(ps, a.states + ((long)seq * nch + max(c - 1, 0)) * 4096);
     RP(4);
     // G <- gamma G + (beta Q)^T dO
     {
