@@ -118,7 +118,7 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
  *   episode just ended: their carried states read as zero, rec_magpo.py:164-169), scratch qkvg u y rep reppe hv ([N*A] rows) |
  *   xa kin1 y1 c cpe y2 xo xope hp hn logits ([N] rows) | u1 u2 ([N*A] rows) | prev [N][A] i32 | action [N][A] i32, logp, value [N][A];
  * blk_ptrs_host[21 * n_block]: qkvg_t wo_t ln1 ln2 gn_g gn_b | qkvg1_t wo1_t dln1 gn1_g gn1_b | q2_t kvg2_t wo2_t dln2 dln3 gn2_g gn2_b |
- *   scratch qkvg1 [N*A][256], q2 [N*A][64], kvg2 [N*A][192].   (*_t = transposed weights as produced by magpo_transpose_pad) */
+ *   scratch qkvg1 [N*A][256], q2 [N*A][64], kvg2 [N*A][256] (rows [k | v | - | q2 (kappa S)]).   (*_t = transposed weights as produced by magpo_transpose_pad) */
 int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs_host,
                     int nptrs, const void* const* blk_ptrs_host, int nblk_ptrs, magpo_stream_t stream);
 

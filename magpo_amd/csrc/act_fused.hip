@@ -204,14 +204,20 @@ __device__ unsigned long long g_act_prof[16];
 // ENC: ntok = A, all tokens staged from the global [q|k|v|g] rows `hist`; u rows -> global uout[(env*A + a)*64].
 // DEC: ntok = i + 1, tokens a < i staged from the global k|v history (hist rows, columns hcol..hcol+127), token i read
 //      from the wave's TQ tile; u -> LDS tile U[env].
-template <bool ENC, int NA, int NBUF, int NH>
+template <int MODE, int NA, int NBUF, int NH>
 __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* __restrict__ S0 /* head 0 of this block */, long NS,
                                          const ActArgs& a, int env0, int nvalid, int i, const float* __restrict__ hist, long ldh,
-                                         int hcol, float* __restrict__ uout, const float* __restrict__ gamma,
+                                         int hcol, float* __restrict__ uout, long ldu, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, int write_state, unsigned long long dmask) {
   const int lane = threadIdx.x, c4 = 4 * (lane & 15), rg = lane >> 4;
   const int A = a.A, nh = NH ? NH : a.nh, hs = NH ? AE / NH : a.hs, gs = NH ? AE / (NH * NH) : a.gs;   // NH = 0: run-time head count
-  const int ntok = ENC ? A : i + 1, ret_from = ENC ? 0 : i, nstage = ENC ? A : i;
+  // MODE 0 (encoder): all A tokens staged as [q|k|v|g] rows, state update + write, gated output -> global uout
+  // MODE 1 (decoder self-retention, agent i): tokens a < i staged (k|v), token i from TQ, output u_i -> LDS U, state written at the last agent
+  // MODE 2 (cross-retention pre-pass): q rows of all A agents staged, RAW q_a (kappa S) -> global uout, state untouched
+  // MODE 3 (cross-retention, after the last agent): k|v rows of all A agents staged, state update + write, no output
+  constexpr bool ENC = MODE == 0;
+  constexpr bool DO_UPD = MODE != 2, DO_OUT = MODE != 3;
+  const int ntok = MODE == 1 ? i + 1 : A, ret_from = MODE == 1 ? i : 0, nstage = MODE == 1 ? i : A;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool colin = c4 < hs, rowin = 16 * rg < hs;
   const float inv_gs = 1.0f / (float)gs;
@@ -237,6 +243,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
     for (int t = 0; t < NA; ++t) {
       if (t < nstage) {
         if (ENC) tok[t] = ld4g(hist + (row0 + t) * ldh + 4 * lane);
+        else if (MODE == 2) { if (lane < 16) tok[t] = ld4g(hist + (row0 + t) * ldh + 4 * lane); }
         else if (lane < 32) tok[t] = ld4g(hist + (row0 + t) * ldh + hcol + 4 * lane);
       }
     }
@@ -261,6 +268,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
       for (int t = 0; t < NA; ++t) {
         if (t < nstage) {
           if (ENC) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[j][t];
+          else if (MODE == 2) { if (lane < 16) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[j][t]; }
           else if (lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[j][t];
         }
       }
@@ -272,8 +280,8 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
       for (int r = 0; r < 16; ++r) { s[r].x *= decay; s[r].y *= decay; s[r].z *= decay; s[r].w *= decay; }
 #pragma unroll
       for (int t = 0; t < NA; ++t) {
-        if (t < ntok) {
-          const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
+        if (DO_UPD && t < ntok) {
+          const float* tk = (MODE != 1 || t < i) ? HK + t * QP : TQ + e * QP;
           float4 vv = *reinterpret_cast<const float4*>(tk + 128 + o + cc);   // unconditional loads (a predicated load becomes
           if (!colin) vv = z4;                                                  // an exec-masked block with its own LDS wait)
           float kk[16];
@@ -295,8 +303,8 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
       RT(3);
 #pragma unroll
       for (int t = 0; t < NA; ++t) {
-        if (t < ret_from || t >= ntok) continue;
-        const float* tk = (ENC || t < i) ? HK + t * QP : TQ + e * QP;
+        if (!DO_OUT || t < ret_from || t >= ntok) continue;
+        const float* tk = (MODE != 1 || t < i) ? HK + t * QP : TQ + e * QP;
         float4 p = z4;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -313,6 +321,10 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
         s1 = gsum(s1, gs >> 2); s2 = gsum(s2, gs >> 2);
         const float mu = s1 * inv_gs, m2 = s2 * inv_gs;
         const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
+        if (MODE == 2) {   // raw q (kappa S): the intra-step terms, GroupNorm and gate follow in registers (cross_ret)
+          if (colin && rg == 0 && live) st4g(uout + (row0 + t) * ldu + o + c4, p);
+          continue;
+        }
         const float4 g4 = *reinterpret_cast<const float4*>(tk + 192 + o + cc);
         if (colin && rg == 0 && live) {
           float4 o4;
@@ -320,7 +332,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
           o4.y = fswish(g4.y) * ((p.y - mu) * rstd * gam.y + bet.y);
           o4.z = fswish(g4.z) * ((p.z - mu) * rstd * gam.z + bet.z);
           o4.w = fswish(g4.w) * ((p.w - mu) * rstd * gam.w + bet.w);
-          if (ENC) st4g(uout + (row0 + t) * AE + o + c4, o4);
+          if (ENC) st4g(uout + (row0 + t) * ldu + o + c4, o4);
           else *reinterpret_cast<float4*>(U + e * UP + o + c4) = o4;
         }
       }
@@ -328,6 +340,72 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
     }
   }
   RT_FLUSH();
+}
+
+// ---- cross-retention of agent i in registers (feature-major rows, all envs of the wave at once) --------------------------
+//   r = P2_i + sum_{a <= i} (q_i . k_a)_head v_a ,  u = swish(g_i) * GroupNorm(r)
+// P2_i = q_i (kappa S) comes from the pre-pass (the cross-retention query is the encoder's, so it is known for every agent
+// before the decoder starts: the state is read once per step there and once more when it is updated after the last agent,
+// instead of once per agent); tokens a < i are read back from the k|v history rows (ld 256: [k | v | - | P2]).
+template <int NH, int NA>
+__device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const Row& kc, const Row& vc, const Row& gc, const Row& p2,
+                                         const Row (&hk)[NA - 1], const Row (&hv)[NA - 1], int i, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, int kq) {
+  const int nh = NH ? NH : a.nh, hs = AE / nh;
+  Row r = p2;
+#pragma unroll
+  for (int t = 0; t < NA; ++t) {
+    if (t > i) continue;
+    Row kt = kc, vt = vc;   // (value selects: a select between references would pin the arrays in scratch)
+    if (t < NA - 1) {
+      const bool old = t < i;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { kt.v[j] = old ? hk[t < NA - 1 ? t : 0].v[j] : kc.v[j]; vt.v[j] = old ? hv[t < NA - 1 ? t : 0].v[j] : vc.v[j]; }
+    }
+    float part[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d += q.v[4 * g + c] * kt.v[4 * g + c];
+      part[g] = xsum32(xsum16(d));   // over the 4 k-quarter lanes of the env: features 16 g .. 16 g + 15
+    }
+    float coef[4];
+    if (nh == 1) { const float d = (part[0] + part[1]) + (part[2] + part[3]); coef[0] = coef[1] = coef[2] = coef[3] = d; }
+    else if (nh == 2) { coef[0] = coef[1] = part[0] + part[1]; coef[2] = coef[3] = part[2] + part[3]; }
+    else { coef[0] = part[0]; coef[1] = part[1]; coef[2] = part[2]; coef[3] = part[3]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r.v[j] += coef[j >> 2] * vt.v[j];
+  }
+  // GroupNorm over groups of gs = hs / nh consecutive channels (retention.py:289-294), then the swish gate
+  float mu[4], rstd[4];
+  if (nh == 1) {
+    Row sq;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sq.v[j] = r.v[j] * r.v[j];
+    const float m1 = row_sum(r) * (1.0f / 64.0f), m2 = row_sum(sq) * (1.0f / 64.0f);
+    const float rs = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + EPSN);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { mu[g] = m1; rstd[g] = rs; }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float s1 = (r.v[4 * g] + r.v[4 * g + 1]) + (r.v[4 * g + 2] + r.v[4 * g + 3]);
+      float s2 = (r.v[4 * g] * r.v[4 * g] + r.v[4 * g + 1] * r.v[4 * g + 1]) + (r.v[4 * g + 2] * r.v[4 * g + 2] + r.v[4 * g + 3] * r.v[4 * g + 3]);
+      float inv = 0.25f;
+      if (nh == 2) { s1 = xsum32(xsum16(s1)); s2 = xsum32(xsum16(s2)); inv = 1.0f / 16.0f; }   // gs = 16: the 4 lanes of block g
+      const float m1 = s1 * inv, m2 = s2 * inv;
+      mu[g] = m1;
+      rstd[g] = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + EPSN);
+    }
+  }
+  Row u;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int n = 16 * (j >> 2) + 4 * kq + (j & 3), c = n % hs;   // channel inside the head
+    u.v[j] = fswish(gc.v[j]) * ((r.v[j] - mu[j >> 2]) * rstd[j >> 2] * gamma[c] + beta[c]);
+  }
+  return u;
 }
 
 // Optional in-kernel stage timing (debug builds only: -DMAGPO_ACT_PROF): wall-clock ticks (100 MHz) per stage class
@@ -396,7 +474,7 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
     }
     wsync();
     PROF(0);
-    ret_pass<true, NA, (EPW == 16 ? 4 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
+    ret_pass<0, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
     wsync();
     PROF(1);
     for (int t = 0; t < A; ++t) {
@@ -428,6 +506,15 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
   PROF(3);
   if (a.value_only) return;   // uniform: bootstrap value only (rec_magpo.py:202-208)
 
+  // cross-retention pre-pass: q2_a (kappa S_d2) for every agent, one state read per env and block
+  for (int b = 0; b < nb; ++b) {
+    const ActBlk& B = a.blk[b];
+    ret_pass<2, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.q2, AE, 0, B.kvg2 + 192, 256, B.gn2_g,
+                                            B.gn2_b, 0, dmask);
+  }
+  wsync();
+  PROF(1);
+
   // ---------------- autoregressive decoder (decode.py:111-153): token i of every env
   int prev = 0;   // 0 = start token, action + 1 afterwards
   for (int i = 0; i < A; ++i) {
@@ -453,7 +540,7 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
       }
       wsync();
       PROF(0);
-      ret_pass<false, NA, (EPW == 16 ? 4 : 2), NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, B.gn1_g, B.gn1_b, last, dmask);
+      ret_pass<1, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, last, dmask);
       wsync();
       PROF(1);
       Row cpe;
@@ -462,29 +549,37 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
         cpe = row_add(row_rms(row_add(row_load(XS + le * UP, kq), y1), B.dln1, kq), pe);
       }
       {
-        // cross-retention: q from the encoder (q2 row of this token), k/v/g from the decoder stream
-        if (valid) {
-          const Row q2 = row_load(B.q2 + row * AE, kq);
+        // cross-retention: q from the encoder (q2 row of this token), k/v/g from the decoder stream; everything but the
+        // pre-pass term stays in registers, so the state is not touched until the last agent has been decoded
+        // rows written by the earlier agents / the pre-pass: issued before the GEMM so that they arrive behind it
+        Row hk2[NA - 1], hv2[NA - 1];
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(TQ + env * QP + 16 * g + 4 * kq) = make_float4(q2.v[4 * g], q2.v[4 * g + 1], q2.v[4 * g + 2], q2.v[4 * g + 3]);
+        for (int t = 0; t < NA - 1; ++t) {
+          if (t < i) { hk2[t] = row_load(B.kvg2 + (ge * A + t) * 256, kq); hv2[t] = row_load(B.kvg2 + (ge * A + t) * 256 + 64, kq); }
         }
-        float* hrow = B.kvg2 + row * 192;
+        const Row p2 = row_load(B.kvg2 + row * 256 + 192, kq);
+        const Row q2 = row_load(B.q2 + row * AE, kq);
+        Row k2, v2, g2;
+        float* hrow = B.kvg2 + row * 256;
         wgemm<12>(cpe, B.kvg2_t, m, kq, [&](int g, f32x4 acc) {
           const float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
-          if (valid) {
-            *reinterpret_cast<float4*>(TQ + env * QP + 64 + 16 * g + 4 * kq) = v4;
-            if (g < 8) st4g(hrow + 16 * g + 4 * kq, v4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (g < 4) k2.v[4 * g + c] = acc[c];
+            else if (g < 8) v2.v[4 * (g - 4) + c] = acc[c];
+            else g2.v[4 * (g - 8) + c] = acc[c];
           }
+          if (valid && g < 8) st4g(hrow + 16 * g + 4 * kq, v4);   // k, v of this token: history for the later agents / the state update
         });
-      }
-      wsync();
-      PROF(0);
-      ret_pass<false, NA, (EPW == 16 ? 4 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.kvg2, 192, 0, nullptr, B.gn2_g, B.gn2_b, last, dmask);
-      wsync();
-      PROF(1);
-      {
-        const Row y2 = dense64(row_load(U + le * UP, kq), B.wo2_t, nullptr, m, kq);
+        const Row u2 = cross_ret<NH, NA>(a, q2, k2, v2, g2, p2, hk2, hv2, i, B.gn2_g, B.gn2_b, kq);
+        PROF(0);
+        if (last) {   // all A tokens are known: S <- kappa S + sum_a k_a^T v_a  (one read + one write per env)
+          wsync();
+          ret_pass<3, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, nullptr, 0, B.gn2_g,
+                                                  B.gn2_b, 1, dmask);
+          PROF(1);
+        }
+        const Row y2 = dense64(u2, B.wo2_t, nullptr, m, kq);
         const Row repi = row_load(a.rep + row * AE, kq);
         xo = row_rms(row_rms(row_add(repi, y2), B.dln2, kq), B.dln3, kq);
       }
