@@ -42,7 +42,9 @@ __device__ __forceinline__ long tok_row(int rho, int t, int T, int A) {
 // FULL = every one of the block's 64 rows is valid (all but the last block): loads and stores are then unconditional
 // straight-line code; a predicated access is an exec-masked block with its own wait and a per-element global flag load
 // sits on the step's critical path, so the reset flags of the block's rows are staged in LDS once.
-template <bool FULL>
+// TM = time-major trajectory (rollout carry: rows (t, env, agent), only the last state is written); compile-time so that the
+// training scan keeps its constant row stride and unconditional stores
+template <bool FULL, bool TM>
 __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) {
   __shared__ __align__(16) float hbuf[2][64 * HP];
   extern __shared__ unsigned char rflag[];   // [64][T] reset-before-step flags of the block's rows
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
   for (int i = tid; i < 64 * T; i += 256) {
     const int rl = i / T, t = i - rl * T;
     const int rho = min(rho0 + rl, a.NR - 1);
-    rflag[i] = a.time_major ? a.reset[(long)t * (a.NR / a.A) + rho / a.A] : a.reset[(long)(rho / a.A) * T + t];
+    rflag[i] = TM ? a.reset[(long)t * (a.NR / a.A) + rho / a.A] : a.reset[(long)(rho / a.A) * T + t];
   }
   // initial carry (with the reset of step 0 applied)
   for (int i = tid; i < 64 * (H / 4); i += 256) {
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rho < a.NR) {
       int seq = rho / a.A;
-      if (!(a.time_major ? a.reset[seq] : a.reset[(long)seq * T])) {
+      if (!(TM ? a.reset[seq] : a.reset[(long)seq * T])) {
         long src = a.h0_idx ? a.h0_idx[rho] : rho;
         v = *reinterpret_cast<const float4*>(a.h0 + src * H + 4 * c4);
       }
@@ -77,13 +79,13 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
   }
   // per-row bookkeeping (no integer division inside the scan): token row of step 0 (invalid rows shadow the last valid one)
   __shared__ long rbase[64];
-  if (tid < 64) rbase[tid] = a.time_major ? (long)min(rho0 + tid, a.NR - 1) : tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
-  const long t_stride = a.time_major ? a.NR : a.A;   // rows between consecutive steps of one recurrent row
+  if (tid < 64) rbase[tid] = TM ? (long)min(rho0 + tid, a.NR - 1) : tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
+  const long t_stride = TM ? a.NR : a.A;   // rows between consecutive steps of one recurrent row
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const float* hold = hbuf[t & 1];
     float* hnew = hbuf[(t + 1) & 1];
-#pragma unroll 1
+#pragma unroll
     for (int wr = 0; wr < 2; ++wr) {
       // issue this job's xi loads first: they are in flight under the 192 MFMAs below
       float xr[16], xz[16], xn[16];
@@ -128,8 +130,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         const float hp = hold[rl * HP + col];
         float hn_new = (1.0f - z) * n + z * hp;
         if (FULL || rho0 + rl < a.NR) {
-          if (a.hs) a.hs[row * H + col] = hn_new;
-          if (a.h_last && !more) a.h_last[(long)(rho0 + rl) * H + col] = hn_new;
+          if (!TM) a.hs[row * H + col] = hn_new;
+          if (TM && !more) a.h_last[(long)(rho0 + rl) * H + col] = hn_new;
           if (a.gates) {
             float* g = a.gates + row * (4 * H);
             g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
@@ -303,8 +305,8 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
   const size_t lds = (size_t)64 * T;   // reset flags of the block's rows
   if (lds > 24 * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
-  if (nfull) hipLaunchKernelGGL(k_gru_scan_fwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
-  if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_fwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
+  if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, false>), dim3(nfull), dim3(256), lds, st, a, 0);
+  if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, false>), dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_scan_fwd");
 }
 
@@ -318,8 +320,8 @@ extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b
   const size_t lds = (size_t)64 * T;
   if (lds > 24 * 1024) { set_error("magpo_gru_carry: T too large for the LDS flag table"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
-  if (nfull) hipLaunchKernelGGL(k_gru_scan_fwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
-  if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_fwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
+  if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, true>), dim3(nfull), dim3(256), lds, st, a, 0);
+  if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, true>), dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_carry");
 }
 
