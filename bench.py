@@ -120,12 +120,12 @@ class KernelTimer:
         roof.update(kernel=key, avg_us=round(avg_s * 1e6, 1), calls=r["calls"], traffic=None,
                     algorithmic_bytes_per_launch=round(r["bytes"] / r["calls"]))
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; same
-        # workload, profiles/r01_pmc_hbm_traffic.json).  Only attached when the kernel family matches.
+        # workload, profiles/r01_pmc_hbm_traffic.json, made by scripts/pmc_kernels.py + scripts/pmc_collect.py).  Only attached when the kernel family matches.
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
                 pmc = json.load(f)
             name = {"wgrad<2>": "k_wgrad<2>", "wgrad<1>": "k_wgrad<1>", "ret_chunk_bwd": "k_ret_chunk_bwd", "ret_chunk_fwd": "k_ret_chunk_fwd",
-                    "gru_scan_fwd": "k_gru_scan_fwd", "gru_scan_bwd": "k_gru_scan_bwd"}.get(key)
+                    "gru_scan_fwd": "k_gru_scan_fwd<true,false>", "gru_scan_bwd": "k_gru_scan_bwd<true>"}.get(key)
             if name in pmc and getattr(self, "attach_traffic", True):
                 roof["traffic"] = round(pmc[name]["total"])
         except (OSError, ValueError):
