@@ -716,6 +716,107 @@ __global__ void k_transpose_pad(const float* __restrict__ W, float* __restrict__
   Wt[i] = n < N ? W[(long)k * N + n] : 0.f;
 }
 
+// dW slab, whole-matrix form: ONE workgroup accumulates the full [KIN x NOUT] block for its row slab (wave w owns NOUT/4
+// columns, all KIN rows: KT x NT accumulator tiles of 32x32, up to 192 AGPRs), so every row of X and dY is read from HBM
+// exactly once.  k_wgrad splits a slab over (NOUT/128) x (KIN/64) workgroups that re-read the same rows and only partly meet
+// in L2 (PMC: 1.6x the algorithmic bytes), and it needs 1.5 LDS operand reads per MFMA where this form needs
+// (KT + NT) / (KT NT).  One workgroup per CU (LDS: a 64-row tile of X and of dY); the next tile's loads are issued one at
+// a time between the MFMA steps.
+template <int KT, int NT>
+__global__ __launch_bounds__(256, 1) void k_wgrad_full(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
+                                                       int R, float* __restrict__ slab, float* __restrict__ bias_slab) {
+  constexpr int KIN = 32 * KT, NOUT = 128 * NT, LDX = KIN + LDP, LDY = NOUT + LDP;
+  constexpr int NX = 64 * KIN / 4 / 256, NY = 64 * NOUT / 4 / 256;   // float4 per thread and tile
+  extern __shared__ __align__(16) float wf_smem[];
+  float* xs = wf_smem;              // [64][LDX]
+  float* ys = xs + 64 * LDX;        // [64][LDY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int g = blockIdx.x, G = gridDim.x;
+  const int ntiles = (R + 63) >> 6;
+  f32x16 acc[KT][NT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[kt][nt][i] = 0.f;
+  float bsum[(NOUT + 255) / 256];
+#pragma unroll
+  for (int j = 0; j < (NOUT + 255) / 256; ++j) bsum[j] = 0.f;
+  float4 nx[NX + NY];
+#define WF_SRC(LI, ROW0)                                                                                                    \
+  ((LI) < NX ? X + min((ROW0) + (tid + 256 * (LI)) / (KIN / 4), (long)R - 1) * (long)ldx + 4 * ((tid + 256 * (LI)) % (KIN / 4)) \
+             : dY + min((ROW0) + (tid + 256 * ((LI) - NX)) / (NOUT / 4), (long)R - 1) * (long)ldy + 4 * ((tid + 256 * ((LI) - NX)) % (NOUT / 4)))
+  {
+    const long row0 = (long)min(g, ntiles - 1) * 64;
+#pragma unroll
+    for (int li = 0; li < NX + NY; ++li) nx[li] = *reinterpret_cast<const float4*>(WF_SRC(li, row0));
+  }
+  for (int tile = g; tile < ntiles; tile += G) {
+    const long row0 = (long)tile * 64;
+    const long row0n = (long)min(tile + G, ntiles - 1) * 64;
+    __syncthreads();          // MFMAs of the previous tile have finished reading LDS
+#pragma unroll
+    for (int li = 0; li < NX + NY; ++li) {   // stash (rows past the end are zeroed; component-wise selects keep nx[] in registers)
+      float4 v = nx[li];
+      const int idx = tid + 256 * (li < NX ? li : li - NX);
+      const int r = li < NX ? idx / (KIN / 4) : idx / (NOUT / 4);
+      const int c = li < NX ? 4 * (idx % (KIN / 4)) : 4 * (idx % (NOUT / 4));
+      const bool ok = row0 + r < R;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if (li < NX) *reinterpret_cast<float4*>(&xs[r * LDX + c]) = v;
+      else *reinterpret_cast<float4*>(&ys[r * LDY + c]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int tok = 32 * h + s;
+      float av[KT], bv[NT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) av[kt] = xs[tok * LDX + 32 * kt + lr];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt] = ys[tok * LDY + 32 * NT * wave + 32 * nt + lr];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], bv[nt], acc[kt][nt], 0, 0, 0);
+      // the next tile's loads, spread over the 32 MFMA steps
+#pragma unroll
+      for (int li = 0; li < NX + NY; ++li)
+        if (li * 32 / (NX + NY) == s) nx[li] = *reinterpret_cast<const float4*>(WF_SRC(li, row0n));
+    }
+    if (bias_slab) {
+#pragma unroll
+      for (int j = 0; j < (NOUT + 255) / 256; ++j) {
+        const int col = tid + 256 * j;
+        if (col < NOUT) {
+          float sb = 0.f;
+#pragma unroll 8
+          for (int r = 0; r < 64; ++r) sb += ys[r * LDY + col];
+          bsum[j] += sb;
+        }
+      }
+    }
+  }
+#undef WF_SRC
+  float* out = slab + (long)g * KIN * NOUT;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = 32 * NT * wave + 32 * nt + lr;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) out[(long)(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h) * NOUT + n] = acc[kt][nt][i];
+    }
+  if (bias_slab) {
+#pragma unroll
+    for (int j = 0; j < (NOUT + 255) / 256; ++j) {
+      const int col = tid + 256 * j;
+      if (col < NOUT) bias_slab[(long)g * NOUT + col] = bsum[j];
+    }
+  }
+}
+
 }  // namespace magpo
 
 using namespace magpo;
@@ -837,6 +938,27 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   if ((ldx & 3) || (ldy & 3) || KIN % 64) { set_error("magpo_wgrad: bad strides / KIN"); return MAGPO_EINVAL; }
   float* slab = workspace;
   float* bslab = db ? workspace + (long)G * KIN * NOUT : nullptr;
+  static const bool use_full = []() { const char* e = getenv("MAGPO_WGRAD_FULL"); return !e || atoi(e) != 0; }();
+  if (use_full && KIN == 128 && NOUT == 384 && R >= 64 * 256) {
+    // whole-matrix form: one workgroup per CU and slab, every row read once.  Measured: 128x384 4.44 -> 4.21 ms; the narrower
+    // shapes (64x256, 128x128) lose more from one wave per SIMD than they gain from the traffic, and stay on k_wgrad
+    if (G > 256) G = 256;
+    float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
+    const size_t lds = (size_t)64 * ((KIN + LDP) + (NOUT + LDP)) * sizeof(float);
+#define LAUNCH_FULL(KT_, NT_)                                                                                                 \
+    {                                                                                                                          \
+      static bool attr = false;                                                                                                \
+      if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full<KT_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+      hipLaunchKernelGGL((k_wgrad_full<KT_, NT_>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);       \
+    }
+    if (KIN == 64 && NOUT == 128) LAUNCH_FULL(2, 1) else if (KIN == 64 && NOUT == 256) LAUNCH_FULL(2, 2) else if (KIN == 64) LAUNCH_FULL(2, 3)
+    else if (NOUT == 128) LAUNCH_FULL(4, 1) else if (NOUT == 256) LAUNCH_FULL(4, 2) else LAUNCH_FULL(4, 3)
+#undef LAUNCH_FULL
+    long P = (long)krows * NOUT;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
+    if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 63) / 64), dim3(1024), 0, stream, bsl, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
+    return check_launch("magpo_wgrad");
+  }
   int nb = NOUT >= 128 ? 2 : 1;
   // fill the chip in whole waves of workgroups: 3 (NB=2) / 4 (NB=1) resident workgroups per CU x 256 CUs
   {
