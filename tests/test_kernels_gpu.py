@@ -77,6 +77,61 @@ def test_wgrad(L, stream, KIN, NOUT, R):
     close(db, 0.5 * dY[:, :NOUT].double().sum(0), what="db")
 
 
+@pytest.mark.parametrize("KIN,NOUT,R,act", [(64, 64, 203, 0), (64, 256, 130, 1), (64, 192, 97, 0), (64, 20, 100, 0), (128, 384, 1000, 0),
+                                             (128, 128, 333, 1), (128, 96, 65, 0), (256, 64, 77, 0), (192, 64, 65, 2), (384, 128, 70, 0),
+                                             (384, 100, 31, 0)])
+def test_linear_shared_tile(L, stream, KIN, NOUT, R, act):
+    """k_linear_lds (no pre-activation copy requested): full and ragged tiles / column groups, 2- and 4-wave blocks."""
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(R, KIN, generator=g)
+    W = torch.randn(KIN, NOUT, generator=g) / math.sqrt(KIN)
+    b = torch.randn(NOUT, generator=g)
+    Wt = transpose_pad(L, stream, dev(W))
+    ld = (NOUT + 3) // 4 * 4
+    Y = torch.full((R + 1, ld), 7.0, device=DEV)   # guard row: nothing may be written past R
+    L.call("magpo_linear", dev(X), KIN, Wt, dev(b), Y, ld, None, R, KIN, NOUT, act, stream)
+    ref = X.double() @ W.double() + b.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    close(Y[:R, :NOUT], ref, what="y")
+    assert bool((Y[R] == 7.0).all()) and (ld == NOUT or bool((Y[:R, NOUT:] == 7.0).all()))
+
+
+def test_wgrad_whole_matrix(L, stream):
+    """k_wgrad_full (128 x 384, enough rows for one slab per CU) incl. the bias column sums and a ragged last tile."""
+    KIN, NOUT, R, G = 128, 384, 64 * 256 + 37, 300
+    g = torch.Generator().manual_seed(12)
+    X = torch.randn(R, KIN, generator=g) * 0.1
+    dY = torch.randn(R, NOUT, generator=g) * 0.1
+    ws = torch.empty(L.call("magpo_wgrad_workspace_floats", KIN, NOUT, G), device=DEV)
+    dW = torch.zeros(KIN, NOUT, device=DEV)
+    db = torch.zeros(NOUT, device=DEV)
+    L.call("magpo_wgrad", dev(X), KIN, dev(dY), NOUT, R, KIN, KIN, NOUT, dW, db, ws, G, 1.0, 0, stream)
+    close(dW, X.double().T @ dY.double(), what="dW")
+    close(db, dY.double().sum(0), what="db")
+
+
+def test_gru_carry_equals_stepwise_scan(L, stream):
+    """magpo_gru_carry (time-major rollout trajectory, last state only) == the sequence-major scan on the same data."""
+    N, T, A, H = 37, 9, 3, 128
+    g = torch.Generator().manual_seed(13)
+    xi_tm = torch.randn(T, N, A, 3 * H, generator=g) * 0.5            # rows (t, env, agent)
+    Wht = torch.randn(3 * H, H, generator=g) * 0.08
+    bhn = torch.randn(H, generator=g) * 0.1
+    h0 = torch.randn(N * A, H, generator=g) * 0.3
+    reset_tm = (torch.rand(T, N, generator=g) < 0.2).to(torch.uint8)
+    h_last = torch.zeros(N * A, H, device=DEV)
+    L.call("magpo_gru_carry", dev(xi_tm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last, N, T, A, stream)
+    xi_sm = xi_tm.permute(1, 0, 2, 3).contiguous()                     # rows (env, t, agent)
+    hs = torch.zeros(N * T * A, H, device=DEV)
+    L.call("magpo_gru_scan_fwd", dev(xi_sm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), None, dev(reset_tm.t().contiguous()), hs, None, None,
+           N, T, A, stream)
+    ref = hs.view(N, T, A, H)[:, T - 1].reshape(N * A, H)
+    assert torch.equal(h_last, ref)
+
+
 def _pe_table(L, st, npos=101):
     pe = torch.empty(npos, 64, device=DEV)
     L.call("magpo_pe_table", pe, npos, 64, st)
