@@ -42,7 +42,9 @@ int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key
                         float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
                         int auto_reset, magpo_stream_t stream);
 
-/* ---- dense layers on fp32 MFMA (flax nn.Dense / retention projections) ---- */
+/* ---- dense layers on fp32 MFMA (flax nn.Dense / retention projections) ----
+ * act: 0 none, 1 relu, 2 gelu(tanh), 3 swish, 4 mask: Y = (M > 0) ? XW+b : 0 with the mask M passed in the Ypre argument (same stride as Y)
+ * -- the ReLU backward fused into dX = dY W^T.  Ypre (act 0-3, nullable): receives the pre-activation. */
 int magpo_linear(const float* X, int ldx, const float* Wt, const float* bias, float* Y, int ldy, float* Ypre,
                  long R, int KIN, int NOUT, int act, magpo_stream_t stream);
 int magpo_linear_pro(int pro, const float* a, long lda, const float* y, long ldy_in, const float* s1, const float* s2,

@@ -70,8 +70,8 @@ class GruActor:
         ht = self._tp("head", v["head.kernel"], 64)      # [64][128]
         self._tp("head_nat_pad", ht, H)                   # [128][64]
 
-    def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0):
-        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, None, R, KIN, NOUT, act, self._st())
+    def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
+        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self._st())
 
     def wgrad(self, X, ldx, dY, ldy, R, KIN, NOUT, dW, db=None, krows=None):
         """dW = X^T dY, queued on the side stream (off the critical path of the backward chain)."""
@@ -136,8 +136,8 @@ class GruActor:
         t = lambda n: b.t["t_" + n]
         self.wgrad(t("y"), H, dlogits, 64, R, H, K, gv["head.kernel"], gv["head.bias"])
         dy = b.get("g_dy", (R, H))
-        self.lin(dlogits, 64, self.wt["head_nat_pad"], None, dy, H, R, 64, H)
-        L.call("magpo_relu_bwd", t("y"), dy, dy, R * H, st)
+        # dy = (dlogits @ W_head^T) masked by the forward ReLU (fused epilogue: act 4 takes the mask in the Ypre slot)
+        self.lin(dlogits, 64, self.wt["head_nat_pad"], None, dy, H, R, 64, H, act=4, Ypre=t("y"))
         self.wgrad(t("hs"), H, dy, H, R, H, H, gv["post.kernel"], gv["post.bias"])
         dhs = b.get("g_dhs", (R, H))
         self.lin(dy, H, v["post.kernel"], None, dhs, H, R, H, H)

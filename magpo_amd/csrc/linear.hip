@@ -15,7 +15,7 @@
 
 namespace magpo {
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SWISH = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SWISH = 3, ACT_MASKPOS = 4 };   // MASKPOS: y = aux > 0 ? y : 0 (ReLU backward fused into dX = dY W^T)
 
 template <int KIN>
 __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int ldx,
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_linear_wk(const float* __restrict__ X, 
 template <int KIN, int NW>
 __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict__ X, int ldx, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ Y, int ldy,
-                                                    int R, int NOUT, int act) {
+                                                    int R, int NOUT, int act, const float* __restrict__ aux) {
   constexpr int NKC = KIN / 64, PT = KIN + LDP, NT = 64 * NW, NLD = 32 * (KIN / 4) / NT;   // NLD float4 per thread and tile
   extern __shared__ __align__(16) float ll_smem[];                // 2 x [32][PT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
@@ -461,13 +461,21 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
     float* nbuf = ll_smem + (par ^ 1) * 32 * PT;     // the other buffer: nobody reads it during this tile
     LL_STASH(nbuf)
     if (colon) {
-      if (act <= ACT_RELU && (long)tile * 32 + 32 <= R && c0 + 32 <= NOUT) {
-        float* yp = Y + ((long)tile * 32 + 4 * h) * (long)ldy + n;
+      if ((act <= ACT_RELU || act == ACT_MASKPOS) && (long)tile * 32 + 32 <= R && c0 + 32 <= NOUT) {
+        const long o0 = ((long)tile * 32 + 4 * h) * (long)ldy + n;
+        if (act == ACT_MASKPOS) {   // mask values first (16 independent loads), then the stores
+          float mk[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float v = acc[i] + bv;
-          if (act == ACT_RELU) v = fmaxf(v, 0.f);
-          yp[(long)((i & 3) + 8 * (i >> 2)) * ldy] = v;
+          for (int i = 0; i < 16; ++i) mk[i] = aux[o0 + (long)((i & 3) + 8 * (i >> 2)) * ldy];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Y[o0 + (long)((i & 3) + 8 * (i >> 2)) * ldy] = mk[i] > 0.f ? acc[i] + bv : 0.f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float v = acc[i] + bv;
+            if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            Y[o0 + (long)((i & 3) + 8 * (i >> 2)) * ldy] = v;
+          }
         }
       } else if (n < NOUT) {
 #pragma unroll
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
             if (act == ACT_RELU) v = fmaxf(v, 0.f);
             else if (act == ACT_GELU) v = gelu_tanh(v);
             else if (act == ACT_SWISH) v = swishf_(v);
+            else if (act == ACT_MASKPOS) v = aux[gr * (long)ldy + n] > 0.f ? v : 0.f;
             Y[gr * (long)ldy + n] = v;
           }
         }
@@ -826,6 +835,12 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
   if (R <= 0) return MAGPO_OK;
   if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
   static const bool lds64 = []() { const char* e = getenv("MAGPO_LINEAR_LDS64"); return !e || atoi(e) != 0; }();
+  const float* aux = nullptr;
+  if (act == ACT_MASKPOS) {   // the Ypre argument carries the mask INPUT (same shape / stride as Y), nothing else is written
+    if (!Ypre) { set_error("magpo_linear: act 4 (mask) needs the mask tensor in the Ypre argument"); return MAGPO_EINVAL; }
+    aux = Ypre;
+    Ypre = nullptr;
+  }
   if ((KIN == 128 || KIN == 192 || KIN == 256 || KIN == 384 || (KIN == 64 && lds64)) && !Ypre) {
     // persistent waves: one wave per (walker, 32-column group); blocks of 4 / 2 / 1 waves so that every wave slot of
     // a CU can be filled (a 3-wave block leaves a quarter of the slots idle), about one resident wave set in total
@@ -853,8 +868,8 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_lds<K_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
           attr = true;                                                                                                  \
         }                                                                                                               \
-        if (nw == 4) hipLaunchKernelGGL((k_linear_lds<K_, 4>), g2, b2, lds, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act); \
-        else hipLaunchKernelGGL((k_linear_lds<K_, 2>), g2, b2, lds, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act); \
+        if (nw == 4) hipLaunchKernelGGL((k_linear_lds<K_, 4>), g2, b2, lds, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act, aux); \
+        else hipLaunchKernelGGL((k_linear_lds<K_, 2>), g2, b2, lds, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act, aux); \
       }
       if (KIN == 64) LAUNCH_LDS(64) else if (KIN == 128) LAUNCH_LDS(128) else if (KIN == 192) LAUNCH_LDS(192) else if (KIN == 256) LAUNCH_LDS(256) else LAUNCH_LDS(384)
 #undef LAUNCH_LDS

@@ -99,6 +99,19 @@ def test_linear_shared_tile(L, stream, KIN, NOUT, R, act):
     assert bool((Y[R] == 7.0).all()) and (ld == NOUT or bool((Y[:R, NOUT:] == 7.0).all()))
 
 
+def test_linear_relu_mask_epilogue(L, stream):
+    """act 4: dX = (dY W^T) masked by the forward activation passed in the Ypre slot (ReLU backward fused into the GEMM)."""
+    KIN, NOUT, R = 64, 128, 173
+    g = torch.Generator().manual_seed(14)
+    X = torch.randn(R, KIN, generator=g)
+    W = torch.randn(KIN, NOUT, generator=g) / 8
+    M = torch.relu(torch.randn(R, NOUT, generator=g))
+    Wt = transpose_pad(L, stream, dev(W))
+    Y = torch.zeros(R, NOUT, device=DEV)
+    L.call("magpo_linear", dev(X), KIN, Wt, None, Y, NOUT, dev(M), R, KIN, NOUT, 4, stream)
+    close(Y, (X.double() @ W.double()) * (M > 0), what="masked dX")
+
+
 def test_wgrad_whole_matrix(L, stream):
     """k_wgrad_full (128 x 384, enough rows for one slab per CU) incl. the bias column sums and a ragged last tile."""
     KIN, NOUT, R, G = 128, 384, 64 * 256 + 37, 300
