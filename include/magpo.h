@@ -64,6 +64,7 @@ int magpo_small_linear(const float* X, int ldx, int F, const float* W, const flo
 /* ---- token-local Sable rows (sable_network.py:62-71,93-137,188-217,255-319; retention.py:289-294) ---- */
 int magpo_row_grid(long R);
 int magpo_pe_table(float* pe, int npos, int E, magpo_stream_t stream);
+/* embed: z (forward) and z / dz (backward) are nullable -- the backward then recomputes the pre-activation from obs / idx (pass W) */
 int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const float* s_obs, const float* W,
                     const int* idx, int idx_stride, const float* s_ln, const float* pe, const int* pos,
                     int pos_stride, int npos, float* z, int ldz, float* xn, int ldxn, float* kin, int ldkin,

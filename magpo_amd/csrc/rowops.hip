@@ -158,7 +158,18 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
     const bool ok = row < a.R;
     float4 z = f4zero(), d = f4zero();
     if (ok) {
-      z = ld4(a.z + row * a.ldz + c4);
+      if (a.z) z = ld4(a.z + row * a.ldz + c4);
+      else if (MODE == 0) {   // pre-activation not saved by the forward: recompute it from the observation row (F <= 32 terms)
+        const float* o = a.obs + row * a.ldo;
+        float ms = 0.f;
+        for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
+        const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
+        for (int f = 0; f < a.F; ++f) {
+          const float of = o[f] * rstd * a.s_obs[f];
+          const float4 w = ld4(a.W + f * 64 + c4);
+          z.x += of * w.x; z.y += of * w.y; z.z += of * w.z; z.w += of * w.w;
+        }
+      } else z = ld4(a.W + (long)a.idx[row * a.idx_stride] * 64 + c4);   // ... or gather it from the embedding table
       d = ld4(a.d0 + row * a.ldd0 + c4);
       if (a.d1) d = f4add(d, ld4(a.d1 + row * a.ldd1 + c4));
       if (a.d2) d = f4add(d, ld4(a.d2 + row * a.ldd2 + c4));
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
     float4 dz = make_float4(dx0.x * gelu_tanh_grad(z.x), dx0.y * gelu_tanh_grad(z.y), dx0.z * gelu_tanh_grad(z.z),
                             dx0.w * gelu_tanh_grad(z.w));
     if (!ok) dz = f4zero();
-    if (ok) st4(a.dz + row * a.lddz + c4, dz);
+    if (ok && a.dz) st4(a.dz + row * a.lddz + c4, dz);
     if (MODE == 0) {
       // dW_obs[f] += o[f] * dz ; d(s_obs)[f] += (dz . W[f,:]) * obs[f] * rstd   (the obs need no gradient)
       const float* o = a.obs + (ok ? row : 0) * a.ldo;

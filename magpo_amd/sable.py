@@ -339,7 +339,7 @@ class SableGuider:
         logits = b.get("t_logits", (R, E), zero=True)
         # ---- encoder
         L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
-               self.pe, pos, 1, self.npos, g("z"), E, g("xn0"), E, g("kin0"), E, R, st)
+               self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, st)   # z is recomputed by the backward
         for k in range(nb):
             e = f"enc.block{k}."
             xn, kin, qkvg, r, u, y = g(f"xn{k}"), g(f"kin{k}"), g(f"qkvg{k}", 4 * E), g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
@@ -360,7 +360,7 @@ class SableGuider:
                value, 1, R, st)
         # ---- decoder
         L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_idx, 1, v["dec.ln.scale"], self.pe, pos, 1, self.npos,
-               g("za"), E, g("x0"), E, g("xpe0"), E, R, st)
+               None, 0, g("x0"), E, g("xpe0"), E, R, st)   # za = W_act[prev] is gathered again by the backward
         for k in range(nb):
             d = f"dec.block{k}."
             x, xpe = g(f"x{k}"), g(f"xpe{k}")
@@ -453,10 +453,8 @@ class SableGuider:
             dkin1 = g(f"dkin1_{k}")
             self.lin(dqkvg1, 4 * E, v[d + "retn1.w_qkvg"], None, dkin1, E, R, 4 * E, E)
             din0, din1 = dsum1, dkin1      # gradient of x_k (block input): residual path + key/query/value path
-        dza = g("dz")
-        za = t("za")
-        L.call("magpo_embed_bwd", 1, za, E, din0, E, din1, E, None, 0, v["dec.ln.scale"], dza, E, slab("a"), slab("w", 32 * E),
-               K + 1, None, 0, 0, None, None, None, prev_idx, 1, R, st)
+        L.call("magpo_embed_bwd", 1, None, 0, din0, E, din1, E, None, 0, v["dec.ln.scale"], None, 0, slab("a"), slab("w", 32 * E),
+               K + 1, None, 0, 0, None, v["dec.act.kernel"], None, prev_idx, 1, R, st)
         self.reduce(slab("a"), gv["dec.ln.scale"])
         self.reduce(slab("w", 32 * E), gv["dec.act.kernel"], P=(K + 1) * E, stride=32 * E)
         # ---- value head
@@ -496,9 +494,7 @@ class SableGuider:
                 first_ln = False
                 e0, e1, e2 = drepb, None, None
             else:
-                dz = g("dz")
-                z = t("z")
-                L.call("magpo_embed_bwd", 0, z, E, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], dz, E, slab("a"), slab("w", 32 * E), F,
+                L.call("magpo_embed_bwd", 0, None, 0, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], None, 0, slab("a"), slab("w", 32 * E), F,
                        obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, st)
                 self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
                 self.reduce(slab("d", 32), gv["enc.obs.norm.scale"], P=F, stride=32)
