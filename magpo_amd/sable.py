@@ -365,12 +365,12 @@ class SableGuider:
             d = f"dec.block{k}."
             x, xpe = g(f"x{k}"), g(f"xpe{k}")
             qkvg1, r1, u1, y1 = g(f"qkvg1{k}", 4 * E), g(f"r1{k}"), g(f"u1{k}"), g(f"y1{k}")
-            c, cpe, q2, kvg2, r2, u2, y2 = g(f"c{k}"), g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
+            cpe, q2, kvg2, r2, u2, y2 = g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
             self.lin(xpe, E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
             self._ret_fwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, s0[1][k], seq_env, dones, f"st_1{k}", nseq, T, 1)
             self._retpost_fwd(r1, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], u1, R)
             self.lin(u1, E, self.wt[f"wo1{k}"], None, y1, E, R, E, E)
-            L.call("magpo_resnorm_fwd", x, E, y1, E, v[d + "ln1.scale"], None, self.pe, pos, 1, self.npos, c, E, cpe, E, R, st)
+            L.call("magpo_resnorm_fwd", x, E, y1, E, v[d + "ln1.scale"], None, self.pe, pos, 1, self.npos, None, 0, cpe, E, R, st)   # only c + pe is consumed
             self.lin(reppe, E, self.wt[f"q2{k}"], None, q2, E, R, E, E)
             self.lin(cpe, E, self.wt[f"kvg2{k}"], None, kvg2, 3 * E, R, E, 3 * E)
             self._ret_fwd(q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, s0[2][k], seq_env, dones, f"st_2{k}", nseq, T, 1)
