@@ -125,6 +125,14 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
 int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs_host,
                     int nptrs, const void* const* blk_ptrs_host, int nblk_ptrs, magpo_stream_t stream);
 
+/* ---- fused training-forward segment between two retention ops (sable_network.py:62-71,188-217,277-319; retention.py:289-295; n_head = 1):
+ *   u = swish(g) * GroupNorm(r) ; y = u W_o ; o = rms(res + y) s1 [-> rms s2] ; ope = o + pe[pos] ; then the tail
+ *   tail 1 (encoder): hv = o W0 + b0, value = rms(gelu(hv)) hs . hw + hb1, q2[k] = ope Wq2[k]   tail 2: out0 = ope W0 (192 columns)
+ *   tail 3 (last decoder block): hp = o W0 + b0, hn = rms(gelu(hp)) hs, logits = hn W1 + b1 (K columns)   tail 0: none
+ * dims_host[6] = {tail, K, npos, ldg, ld0, nq2}; ptrs_host[33] (device pointers): r gp gamma beta wo_t res s1 s2 pe pos | u y o ope |
+ *   w0_t b0 out0 | hs hw hb1 value | q2_t[4] q2[4] | hn w1_t b1 logits   (o, ope, s2 and unused tail pointers may be NULL) */
+int magpo_seg_post(const int* dims_host, long R, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
+
 /* ---- K3/K8 GRU actor (base.py:121-184; flax GRUCell) ---- */
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                        const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,

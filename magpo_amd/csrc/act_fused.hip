@@ -15,14 +15,12 @@
 //     the state layout through a small per-wave LDS tile; GroupNorm + swish gate are fused behind it;
 //   * sampling: the logits never leave registers; gumbel noise from the JAX threefry stream (rl.hip: k_sample).
 // Only what later agents / the training pass need goes to (L2-resident) scratch: this step's k, v rows, obs_rep, q2.
-#include "common.hpp"
+#include "fm_rows.hpp"
 #include <stdlib.h>
 #include <string.h>
 
 namespace magpo {
 
-constexpr int AE = 64;           // embed dim
-constexpr float EPSN = 1e-6f;
 constexpr float FMIN_ = -3.4028234663852886e38f;
 constexpr int MAXB = 4;          // max blocks
 constexpr int MAXA = 8;          // max agents of the fused path (token staging registers)
@@ -50,143 +48,6 @@ struct ActArgs {
   float *xa, *kin1, *y1, *c, *cpe, *y2, *xo, *xope, *hp, *hn, *logits, *u1, *u2; int* prev;   // unused by this kernel (table layout kept)
   int* action; float* logp; float* value;
 };
-
-__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-// streaming accesses for the retention states (each byte is touched once per pass): keep them from displacing the
-// weights and the scratch rows in L2
-__device__ __forceinline__ float4 ld4nt(const float* p) {
-  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void st4nt(float* p, float4 v) {
-  const f32x4 t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
-}
-// order this wave's LDS / global writes before its later reads by other lanes (single-wave workgroup)
-__device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// LDS-only ordering inside one wave (DS ops of a wave execute in order; this only pins the compiler's schedule)
-__device__ __forceinline__ void lsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// swish gate on the hardware exp / rcp units (abs. error ~1e-7, inside the fp32 parity tolerance; cf. gru.hip)
-__device__ __forceinline__ float fswish(float x) { return x * fast_sigmoid(x); }
-
-// ---- cross-lane sums on the VALU (no LDS round trip): v_permlane{16,32}_swap for lane ^ 16 / lane ^ 32, DPP inside a 16-lane row
-__device__ __forceinline__ float xsum16(float v) {   // v[l] + v[l ^ 16]
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
-  return __int_as_float(r[0]) + __int_as_float(r[1]);
-}
-__device__ __forceinline__ float xsum32(float v) {   // v[l] + v[l ^ 32]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
-  return __int_as_float(r[0]) + __int_as_float(r[1]);
-}
-__device__ __forceinline__ float xget32(float v, int lane) {   // v[l ^ 32]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
-  return __int_as_float(lane < 32 ? r[1] : r[0]);
-}
-__device__ __forceinline__ float xget16(float v, int lane) {   // v[l ^ 16]
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
-  return __int_as_float((lane & 16) ? r[0] : r[1]);
-}
-template <int CTRL> __device__ __forceinline__ float dpp_(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-// all-reduce sum over aligned groups of GL lanes (GL = 1, 2, 4, 8, 16) of a 16-lane row
-__device__ __forceinline__ float gsum(float v, int gl) {
-  if (gl >= 16) v += dpp_<0x140>(v);   // row_mirror
-  if (gl >= 8) v += dpp_<0x141>(v);    // row_half_mirror
-  if (gl >= 4) v += dpp_<0x4E>(v);     // quad_perm [2,3,0,1]
-  if (gl >= 2) v += dpp_<0xB1>(v);     // quad_perm [1,0,3,2]
-  return v;
-}
-
-// ---- feature-major rows: reg j <-> feature 16 (j >> 2) + 4 kq + (j & 3) -------------------------------------------
-struct Row { float v[16]; };
-__device__ __forceinline__ Row row_load(const float* p /* row base */, int kq) {
-  Row r;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) { const float4 t = ld4g(p + 16 * g + 4 * kq); r.v[4 * g] = t.x; r.v[4 * g + 1] = t.y; r.v[4 * g + 2] = t.z; r.v[4 * g + 3] = t.w; }
-  return r;
-}
-__device__ __forceinline__ void row_store(float* p, int kq, const Row& r) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) st4g(p + 16 * g + 4 * kq, make_float4(r.v[4 * g], r.v[4 * g + 1], r.v[4 * g + 2], r.v[4 * g + 3]));
-}
-__device__ __forceinline__ float row_sum(const Row& r) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) s += r.v[j];
-  return xsum32(xsum16(s));
-}
-__device__ __forceinline__ Row row_add(const Row& a, const Row& b) {
-  Row r;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) r.v[j] = a.v[j] + b.v[j];
-  return r;
-}
-__device__ __forceinline__ Row row_rms(const Row& x, const float* scale, int kq) {
-  Row q;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) q.v[j] = x.v[j] * x.v[j];
-  const float rstd = rsqrtf(row_sum(q) * (1.0f / 64.0f) + EPSN);
-  const Row s = row_load(scale, kq);
-  Row r;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) r.v[j] = x.v[j] * rstd * s.v[j];
-  return r;
-}
-__device__ __forceinline__ Row row_gelu(const Row& x) {
-  Row r;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) r.v[j] = gelu_tanh(x.v[j]);
-  return r;
-}
-
-// ---- dense layer, transposed on 16x16x4 fp32 MFMA: out(g, acc) receives features 16 g + 4 kq + (0..3) of every env ------
-template <int NG, class OUT>
-__device__ __forceinline__ void wgemm(const Row& x, const float* __restrict__ Wt, int m, int kq, OUT&& out) {
-  constexpr int PD = NG < 4 ? NG : 4;
-  float4 w[PD][4];
-#pragma unroll
-  for (int p = 0; p < PD; ++p)
-#pragma unroll
-    for (int gk = 0; gk < 4; ++gk) w[p][gk] = ld4g(Wt + (long)(16 * p + m) * AE + 16 * gk + 4 * kq);
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int gk = 0; gk < 4; ++gk) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].x, x.v[4 * gk], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].y, x.v[4 * gk + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].z, x.v[4 * gk + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].w, x.v[4 * gk + 3], acc, 0, 0, 0);
-    }
-    if (g + PD < NG) {
-#pragma unroll
-      for (int gk = 0; gk < 4; ++gk) w[g % PD][gk] = ld4g(Wt + (long)(16 * (g + PD) + m) * AE + 16 * gk + 4 * kq);
-    }
-    out(g, acc);
-  }
-}
-// 64 -> 64 layer into registers (+ optional bias)
-__device__ __forceinline__ Row dense64(const Row& x, const float* __restrict__ Wt, const float* __restrict__ bias, int m, int kq) {
-  Row y;
-  wgemm<4>(x, Wt, m, kq, [&](int g, f32x4 acc) {
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) b = ld4g(bias + 16 * g + 4 * kq);
-    y.v[4 * g] = acc[0] + b.x; y.v[4 * g + 1] = acc[1] + b.y; y.v[4 * g + 2] = acc[2] + b.z; y.v[4 * g + 3] = acc[3] + b.w;
-  });
-  return y;
-}
 
 #ifdef MAGPO_ACT_PROF
 __device__ unsigned long long g_act_prof[16];

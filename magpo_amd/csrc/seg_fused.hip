@@ -1,0 +1,207 @@
+// Fused "post-retention" training-forward segments of the Sable blocks (sable_network.py:62-71, 188-217, 277-319;
+// retention.py:289-295) for gfx950.  Between two retention ops the network is token-local; the kernel-by-kernel path runs
+// 4-6 launches there (GroupNorm + gate, W_o, residual + RMSNorm, next projection / head) and re-reads every intermediate
+// from HBM.  Here one persistent wave carries 16 token rows through the whole segment in registers (feature-major rows
+// and transposed 16x16x4 fp32 MFMA layers, fm_rows.hpp); it reads the three input rows once and writes only what the
+// hand-written backward (or the next retention) consumes.  The weights of the segment stay in VGPRs across tiles.
+//   front (all segments):  u = swish(g) * GroupNorm(r) ; y = u W_o ; o = rms(res + y) s1 [-> rms(.) s2] ; ope = o + pe[pos]
+//   tail ENC  : hv = o W_v0 + b ; value = rms(gelu(hv)) s . w + b1 ; q2_k = ope W_q2[k]   (every decoder block k)
+//   tail DEC1 : kvg2 = ope W_kvg2                                                      (192 columns)
+//   tail DEC2 : (last block) hp = o W_h0 + b ; hn = rms(gelu(hp)) s ; logits = hn W_h1 + b   (K columns)
+#include "fm_rows.hpp"
+
+namespace magpo {
+
+struct SegArgs {
+  int tail;                               // 0 none, 1 ENC, 2 DEC1, 3 DEC2
+  long R; int K;
+  // front
+  const float* r; const float* gp; long ldg; const float* gamma; const float* beta;
+  const float* wo_t; const float* res; const float* s1; const float* s2;
+  const float* pe; const int* pos; int npos;
+  float* u; float* y; float* o; float* ope;            // o / ope nullable
+  // tails
+  const float* w0_t; const float* b0; float* out0; long ld0;          // ENC: vh0 -> hv ; DEC1: kvg2 (192) ; DEC2: h0 -> hp
+  const float* hs; const float* hw; const float* hb1; float* value;   // ENC: head norm scale, value weights / bias
+  const float* q2_t[4]; float* q2[4]; int nq2;                        // ENC: cross-retention queries of every decoder block
+  float* hn; const float* w1_t; const float* b1; float* logits;       // DEC2: head
+};
+
+// 64 -> 64 layer with the weight fragments already in registers (w[g][gk]: rows 16 g + m, columns 16 gk + 4 kq ..)
+__device__ __forceinline__ Row dense64_reg(const Row& x, const float4 (&w)[4][4], const float* __restrict__ bias, int kq) {
+  Row y;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][gk].x, x.v[4 * gk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][gk].y, x.v[4 * gk + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][gk].z, x.v[4 * gk + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][gk].w, x.v[4 * gk + 3], acc, 0, 0, 0);
+    }
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = ld4g(bias + 16 * g + 4 * kq);
+    y.v[4 * g] = acc[0] + b.x; y.v[4 * g + 1] = acc[1] + b.y; y.v[4 * g + 2] = acc[2] + b.z; y.v[4 * g + 3] = acc[3] + b.w;
+  }
+  return y;
+}
+__device__ __forceinline__ void load_w64(float4 (&w)[4][4], const float* __restrict__ Wt, int m, int kq) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) w[g][gk] = ld4g(Wt + (long)(16 * g + m) * AE + 16 * gk + 4 * kq);
+}
+
+// Rows past the end shadow the last valid row (same inputs, same results, same addresses): every store is unconditional, so the
+// wait for the prefetched rows at the top of a tile is vmcnt(#stores of the tile) and not a drain of the store queue.
+template <int TAIL>
+__global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
+  const int lane = threadIdx.x, m = lane & 15, kq = lane >> 4;
+  const long ntiles = (a.R + 15) >> 4;
+  float4 wo[4][4], w0[4][4], w0b[(TAIL == 2 || TAIL == 1) ? 4 : 1][4], w0c[TAIL == 2 ? 4 : 1][4];
+  load_w64(wo, a.wo_t, m, kq);
+  if (TAIL == 1 || TAIL == 3) load_w64(w0, a.w0_t, m, kq);
+  if constexpr (TAIL == 1) { if (a.nq2 > 0) load_w64(w0b, a.q2_t[0], m, kq); }   // first decoder block's query projection stays resident too
+  if (TAIL == 2) {   // the 64 -> 192 projection as three register-resident 64 -> 64 blocks (k | v | g)
+    load_w64(w0, a.w0_t, m, kq);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int gk = 0; gk < 4; ++gk) {
+        w0b[g][gk] = ld4g(a.w0_t + (long)(64 + 16 * g + m) * AE + 16 * gk + 4 * kq);
+        w0c[g][gk] = ld4g(a.w0_t + (long)(128 + 16 * g + m) * AE + 16 * gk + 4 * kq);
+      }
+  }
+  const Row gam = row_load(a.gamma, kq), bet = row_load(a.beta, kq);
+  const Row s1 = row_load(a.s1, kq);
+  // prefetch of the next tile's three input rows (rows past the end shadow the last row and are never stored)
+  auto rowc = [&](long tile) { return min(tile * 16 + m, a.R - 1); };
+  long tile = blockIdx.x;
+  Row nr, ng, nres, npe;
+  const bool want_pe = a.ope || TAIL == 1 || TAIL == 2;
+  auto pe_row = [&](long row) {
+    int p = a.pos[row];
+    p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
+    return row_load(a.pe + (long)p * AE, kq);
+  };
+  {
+    const long row = rowc(tile);
+    nr = row_load(a.r + row * AE, kq); ng = row_load(a.gp + row * a.ldg, kq); nres = row_load(a.res + row * AE, kq);
+    if (want_pe) npe = pe_row(row);
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long row = tile * 16 + m;
+    const long rw = min(row, a.R - 1);
+    const Row r = nr, g = ng, res = nres, per = npe;
+    {
+      const long nrow = rowc(min(tile + (long)gridDim.x, ntiles - 1));
+      nr = row_load(a.r + nrow * AE, kq); ng = row_load(a.gp + nrow * a.ldg, kq); nres = row_load(a.res + nrow * AE, kq);
+      if (want_pe) npe = pe_row(nrow);   // position -> table row: two dependent loads, issued a whole tile ahead
+    }
+    // GroupNorm over the whole 64-wide row (n_head = 1) and the swish gate
+    Row sq;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sq.v[j] = r.v[j] * r.v[j];
+    const float mu = row_sum(r) * (1.0f / 64.0f), m2 = row_sum(sq) * (1.0f / 64.0f);
+    const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
+    Row u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) u.v[j] = swishf_(g.v[j]) * ((r.v[j] - mu) * rstd * gam.v[j] + bet.v[j]);
+    row_store(a.u + rw * AE, kq, u);
+    const Row y = dense64_reg(u, wo, nullptr, kq);
+    row_store(a.y + rw * AE, kq, y);
+    // o = rms(res + y) s1 [-> rms s2]
+    Row o = row_add(res, y);
+    {
+      Row q;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) q.v[j] = o.v[j] * o.v[j];
+      const float rs = rsqrtf(row_sum(q) * (1.0f / 64.0f) + EPSN);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o.v[j] = o.v[j] * rs * s1.v[j];
+    }
+    if (a.s2) o = row_rms(o, a.s2, kq);
+    if (a.o) row_store(a.o + rw * AE, kq, o);
+    Row ope = o;
+    if (want_pe) {
+      ope = row_add(o, per);
+      if (a.ope) row_store(a.ope + rw * AE, kq, ope);
+    }
+    if (TAIL == 1) {          // encoder: value head + cross-retention queries
+      const Row hv = dense64_reg(o, w0, a.b0, kq);
+      row_store(a.out0 + rw * a.ld0, kq, hv);
+      const Row hn = row_rms(row_gelu(hv), a.hs, kq);
+      const Row w = row_load(a.hw, kq);
+      Row hw;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) hw.v[j] = hn.v[j] * w.v[j];
+      const float val = row_sum(hw) + a.hb1[0];
+      a.value[rw] = val;
+      if constexpr (TAIL == 1) {
+        if (a.nq2 > 0) row_store(a.q2[0] + rw * AE, kq, dense64_reg(ope, w0b, nullptr, kq));
+      }
+      for (int k = 1; k < a.nq2; ++k) {
+        const Row q2 = dense64(ope, a.q2_t[k], nullptr, m, kq);
+        row_store(a.q2[k] + rw * AE, kq, q2);
+      }
+    } else if (TAIL == 2) {   // decoder, after the self-retention: k | v | g of the cross-retention
+      float* orow = a.out0 + rw * a.ld0;
+      if constexpr (TAIL == 2) {
+        row_store(orow, kq, dense64_reg(ope, w0, nullptr, kq));
+        row_store(orow + 64, kq, dense64_reg(ope, w0b, nullptr, kq));
+        row_store(orow + 128, kq, dense64_reg(ope, w0c, nullptr, kq));
+      }
+    } else if (TAIL == 3) {   // last decoder block: logit head
+      const Row hp = dense64_reg(o, w0, a.b0, kq);
+      row_store(a.out0 + rw * a.ld0, kq, hp);
+      const Row hn = row_rms(row_gelu(hp), a.hs, kq);
+      row_store(a.hn + rw * AE, kq, hn);
+      float* lrow = a.logits + rw * AE;
+      wgemm<4>(hn, a.w1_t, m, kq, [&](int gg, f32x4 acc) {
+        float4 v4;
+        const int n0 = 16 * gg + 4 * kq;
+        v4.x = n0 < a.K ? acc[0] + a.b1[n0] : 0.f;
+        v4.y = n0 + 1 < a.K ? acc[1] + a.b1[n0 + 1] : 0.f;
+        v4.z = n0 + 2 < a.K ? acc[2] + a.b1[n0 + 2] : 0.f;
+        v4.w = n0 + 3 < a.K ? acc[3] + a.b1[n0 + 3] : 0.f;
+        st4g(lrow + n0, v4);
+      });
+    }
+  }
+}
+
+}  // namespace magpo
+
+using namespace magpo;
+
+// ptrs_host (device pointers, host array of 33): r gp gamma beta wo_t res s1 s2 pe pos | u y o ope | w0_t b0 out0 | hs hw hb1 value |
+//   q2_t[0..3] q2[0..3] | hn w1_t b1 logits.   dims_host[6] = {tail, K, npos, ldg, ld0, nq2}.
+extern "C" int magpo_seg_post(const int* dims_host, long R, const void* const* p, int nptrs, hipStream_t st) {
+  if (R <= 0) return MAGPO_OK;
+  if (nptrs != 33) { set_error("magpo_seg_post: pointer table size mismatch"); return MAGPO_EINVAL; }
+  SegArgs a;
+  a.tail = dims_host[0]; a.K = dims_host[1]; a.npos = dims_host[2]; a.ldg = dims_host[3]; a.ld0 = dims_host[4]; a.nq2 = dims_host[5];
+  a.R = R;
+  if (a.tail < 0 || a.tail > 3 || a.nq2 < 0 || a.nq2 > 4 || a.K < 1 || a.K > 64) { set_error("magpo_seg_post: bad arguments"); return MAGPO_EINVAL; }
+  int i = 0;
+  a.r = (const float*)p[i++]; a.gp = (const float*)p[i++]; a.gamma = (const float*)p[i++]; a.beta = (const float*)p[i++];
+  a.wo_t = (const float*)p[i++]; a.res = (const float*)p[i++]; a.s1 = (const float*)p[i++]; a.s2 = (const float*)p[i++];
+  a.pe = (const float*)p[i++]; a.pos = (const int*)p[i++];
+  a.u = (float*)p[i++]; a.y = (float*)p[i++]; a.o = (float*)p[i++]; a.ope = (float*)p[i++];
+  a.w0_t = (const float*)p[i++]; a.b0 = (const float*)p[i++]; a.out0 = (float*)p[i++];
+  a.hs = (const float*)p[i++]; a.hw = (const float*)p[i++]; a.hb1 = (const float*)p[i++]; a.value = (float*)p[i++];
+  for (int k = 0; k < 4; ++k) a.q2_t[k] = (const float*)p[i++];
+  for (int k = 0; k < 4; ++k) a.q2[k] = (float*)p[i++];
+  a.hn = (float*)p[i++]; a.w1_t = (const float*)p[i++]; a.b1 = (const float*)p[i++]; a.logits = (float*)p[i++];
+  const long ntiles = (R + 15) / 16;
+  long grid = 256 * 4;   // one wave per SIMD (the weights of the segment live in its registers)
+  if (grid > ntiles) grid = ntiles;
+  switch (a.tail) {
+    case 0: hipLaunchKernelGGL(k_seg_post<0>, dim3((unsigned)grid), dim3(64), 0, st, a); break;
+    case 1: hipLaunchKernelGGL(k_seg_post<1>, dim3((unsigned)grid), dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_seg_post<2>, dim3((unsigned)grid), dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_seg_post<3>, dim3((unsigned)grid), dim3(64), 0, st, a); break;
+  }
+  return check_launch("magpo_seg_post");
+}

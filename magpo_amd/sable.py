@@ -74,6 +74,8 @@ class SableGuider:
         self.wt: Dict[str, torch.Tensor] = {}
         self.b = _Bufs(device)
         self._act_tabs: Dict[tuple, tuple] = {}
+        self._seg_tabs: Dict[tuple, tuple] = {}
+        self.fused_segments = self.nh == 1   # token-local parts between retention ops as single launches (csrc/seg_fused.hip)
         # weight-gradient GEMMs run on a side stream: they are off the critical path of the backward chain
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.overlap_wgrad = False  # opt-in (bench.py --overlap): ~0.5 %, but per-kernel timings then include contention
@@ -324,6 +326,22 @@ class SableGuider:
         self.L.call("magpo_sable_act", dims.ctypes.data, kap.ctypes.data, None if keys is None else keys.ctypes.data,
                     gp.ctypes.data, int(gp.size), bp.ctypes.data, int(bp.size), self._st())
 
+    def _seg_post(self, tail, r, gp, ldg, gamma, beta, wo_t, res, s1, s2, pos, u, y, o, ope, R, w0_t=None, b0=None, out0=None, ld0=0,
+                  hs=None, hw=None, hb1=None, value=None, q2_t=(), q2=(), hn=None, w1_t=None, b1=None, logits=None):
+        """One fused launch for the token-local part between two retention ops (csrc/seg_fused.hip)."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        q2_t, q2 = list(q2_t) + [None] * (4 - len(q2_t)), list(q2) + [None] * (4 - len(q2))
+        tab = [r, gp, gamma, beta, wo_t, res, s1, s2, self.pe, pos, u, y, o, ope, w0_t, b0, out0, hs, hw, hb1, value, *q2_t, *q2, hn, w1_t, b1, logits]
+        key = (tail, R, tuple(ptr(t) for t in tab))
+        ent = self._seg_tabs.get(key)
+        if ent is None:
+            nq2 = sum(1 for t in q2 if t is not None)
+            ent = (np.array([tail, self.K, self.npos, ldg, ld0, nq2], dtype=np.int32), np.array([ptr(t) for t in tab], dtype=np.uint64))
+            if len(self._seg_tabs) > 256:
+                self._seg_tabs.clear()
+            self._seg_tabs[key] = ent
+        self.L.call("magpo_seg_post", ent[0].ctypes.data, R, ent[1].ctypes.data, int(ent[1].size), self._st())
+
     # ------------------------------------------------------------------ training forward (chunkwise form)
     def train_fwd(self, obs, prev_idx, pos, dones, s0, seq_env, nseq: int, T: int):
         """obs [R,F], prev_idx [R] (0 = start token, a+1 otherwise), pos [R] step counts, dones [nseq,T] u8,
@@ -345,6 +363,20 @@ class SableGuider:
             xn, kin, qkvg, r, u, y = g(f"xn{k}"), g(f"kin{k}"), g(f"qkvg{k}", 4 * E), g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
             self.lin(kin, E, self.wt[f"qkvg{k}"], None, qkvg, 4 * E, R, E, 4 * E)
             self._ret_fwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, s0[0][k], seq_env, dones, f"st_e{k}", nseq, T, 0)
+            if self.fused_segments and k == nb - 1:
+                # GroupNorm + gate, W_o, residual + norms, value head and the cross-retention queries of every decoder block: one launch
+                self._seg_post(1, r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], self.wt[f"wo{k}"], xn,
+                               v[e + "ln1.scale"], v[e + "ln2.scale"], pos, u, y, rep, reppe, R, w0_t=self.wt["vh0"], b0=v["enc.head.dense0.bias"],
+                               out0=hv, ld0=E, hs=v["enc.head.norm.scale"], hw=v["enc.head.dense1.kernel"], hb1=v["enc.head.dense1.bias"],
+                               value=value, q2_t=[self.wt[f"q2{j}"] for j in range(nb)], q2=[g(f"q2{j}") for j in range(nb)])
+                continue
+            if self.fused_segments:
+                repb = g(f"repb{k}")
+                self._seg_post(0, r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], self.wt[f"wo{k}"], xn,
+                               v[e + "ln1.scale"], v[e + "ln2.scale"], pos, u, y, repb, None, R)
+                L.call("magpo_resnorm_fwd", repb, E, None, 0, v["enc.ln.scale"], None, self.pe, pos, 1, self.npos,
+                       g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, st)
+                continue
             self._retpost_fwd(r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], u, R)
             self.lin(u, E, self.wt[f"wo{k}"], None, y, E, R, E, E)
             if k == nb - 1:
@@ -355,9 +387,10 @@ class SableGuider:
                 L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], None, None, 0, 0, repb, E, None, 0, R, st)
                 L.call("magpo_resnorm_fwd", repb, E, None, 0, v["enc.ln.scale"], None, self.pe, pos, 1, self.npos,
                        g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, st)
-        self.lin(rep, E, self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E, E)
-        L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
-               value, 1, R, st)
+        if not self.fused_segments:
+            self.lin(rep, E, self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E, E)
+            L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
+                   value, 1, R, st)
         # ---- decoder
         L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_idx, 1, v["dec.ln.scale"], self.pe, pos, 1, self.npos,
                None, 0, g("x0"), E, g("xpe0"), E, R, st)   # za = W_act[prev] is gathered again by the backward
@@ -368,6 +401,20 @@ class SableGuider:
             cpe, q2, kvg2, r2, u2, y2 = g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
             self.lin(xpe, E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
             self._ret_fwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, s0[1][k], seq_env, dones, f"st_1{k}", nseq, T, 1)
+            if self.fused_segments:
+                # after the self-retention: gate, W_o, residual + norm (+ pe) and the k | v | g projection of the cross-retention
+                self._seg_post(2, r1, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], self.wt[f"wo1{k}"], x,
+                               v[d + "ln1.scale"], None, pos, u1, y1, None, cpe, R, w0_t=self.wt[f"kvg2{k}"], out0=kvg2, ld0=3 * E)
+                self._ret_fwd(q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, s0[2][k], seq_env, dones, f"st_2{k}", nseq, T, 1)
+                if k == nb - 1:   # ... and after the cross-retention of the last block the logit head
+                    self._seg_post(3, r2, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], self.wt[f"wo2{k}"], rep,
+                                   v[d + "ln2.scale"], v[d + "ln3.scale"], pos, u2, y2, g(f"x{nb}"), None, R, w0_t=self.wt["h0"],
+                                   b0=v["dec.head.dense0.bias"], out0=g("hp"), ld0=E, hs=v["dec.head.norm.scale"], hn=g("hn"),
+                                   w1_t=self.wt["h1"], b1=v["dec.head.dense1.bias"], logits=logits)
+                else:
+                    self._seg_post(0, r2, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], self.wt[f"wo2{k}"], rep,
+                                   v[d + "ln2.scale"], v[d + "ln3.scale"], pos, u2, y2, g(f"x{k + 1}"), g(f"xpe{k + 1}"), R)
+                continue
             self._retpost_fwd(r1, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], u1, R)
             self.lin(u1, E, self.wt[f"wo1{k}"], None, y1, E, R, E, E)
             L.call("magpo_resnorm_fwd", x, E, y1, E, v[d + "ln1.scale"], None, self.pe, pos, 1, self.npos, None, 0, cpe, E, R, st)   # only c + pe is consumed
@@ -382,10 +429,11 @@ class SableGuider:
             else:
                 L.call("magpo_resnorm_fwd", rep, E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], self.pe, pos, 1, self.npos,
                        g(f"x{k + 1}"), E, g(f"xpe{k + 1}"), E, R, st)
-        hp, hn = g("hp"), g("hn")
-        self.lin(g(f"x{nb}"), E, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, R, E, E)
-        L.call("magpo_headmid_fwd", hp, E, v["dec.head.norm.scale"], hn, E, None, None, None, 0, R, st)
-        self.lin(hn, E, self.wt["h1"], v["dec.head.dense1.bias"], logits, E, R, E, K)
+        if not self.fused_segments:
+            hp, hn = g("hp"), g("hn")
+            self.lin(g(f"x{nb}"), E, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, R, E, E)
+            L.call("magpo_headmid_fwd", hp, E, v["dec.head.norm.scale"], hn, E, None, None, None, 0, R, st)
+            self.lin(hn, E, self.wt["h1"], v["dec.head.dense1.bias"], logits, E, R, E, K)
         return logits, value
 
     # ------------------------------------------------------------------ training backward

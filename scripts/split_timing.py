@@ -7,6 +7,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 dl = MagpoLearner(CoordSumConfig(4, 20, 100, 60), N, SystemConfig(), 'cuda', net_seed=0)
 dl.fused_act = os.environ.get('MAGPO_FUSED_ACT', '1') == '1'
 dl.batched_actor_carry = os.environ.get('MAGPO_BATCHED_CARRY', '1') == '1'
+if os.environ.get('MAGPO_FUSED_SEG') is not None: dl.guider.fused_segments = os.environ['MAGPO_FUSED_SEG'] == '1'
 dl.setup(host_split(prng_key(42), 4)[0])
 dl.update_step(); torch.cuda.synchronize()
 for it in range(2):
