@@ -27,18 +27,6 @@ struct SegArgs {
   float* hn; const float* w1_t; const float* b1; float* logits;       // DEC2: head
 };
 
-// GELU (tanh form) on the hardware exp / rcp units: one wave per SIMD makes the segment VALU-issue bound, and libm's tanhf is
-// ~40 instructions per element (abs. error of the fast form ~1e-7, far inside the fp32 parity tolerance; cf. gru.hip)
-__device__ __forceinline__ Row row_gelu_fast(const Row& x) {
-  Row r;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float v = x.v[j];
-    r.v[j] = 0.5f * v * (1.0f + fast_tanh(0.7978845608028654f * (v + 0.044715f * v * v * v)));
-  }
-  return r;
-}
-
 // 64 -> 64 layer with the weight fragments already in registers (w[g][gk]: rows 16 g + m, columns 16 gk + 4 kq ..)
 __device__ __forceinline__ Row dense64_reg(const Row& x, const float4 (&w)[4][4], const float* __restrict__ bias, int kq) {
   Row y;
@@ -143,7 +131,7 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
     if (TAIL == 1) {          // encoder: value head + cross-retention queries
       const Row hv = dense64_reg(o, w0, a.b0, kq);
       row_store(a.out0 + rw * a.ld0, kq, hv);
-      const Row hn = row_rms(row_gelu_fast(hv), a.hs, kq);
+      const Row hn = row_rms(row_gelu(hv), a.hs, kq);
       const Row w = row_load(a.hw, kq);
       Row hw;
 #pragma unroll
@@ -167,7 +155,7 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
     } else if (TAIL == 3) {   // last decoder block: logit head
       const Row hp = dense64_reg(o, w0, a.b0, kq);
       row_store(a.out0 + rw * a.ld0, kq, hp);
-      const Row hn = row_rms(row_gelu_fast(hp), a.hs, kq);
+      const Row hn = row_rms(row_gelu(hp), a.hs, kq);
       row_store(a.hn + rw * AE, kq, hn);
       float* lrow = a.logits + rw * AE;
       wgemm<4>(hn, a.w1_t, m, kq, [&](int gg, f32x4 acc) {
