@@ -27,6 +27,17 @@ struct SegArgs {
   float* hn; const float* w1_t; const float* b1; float* logits;       // DEC2: head
 };
 
+__device__ __forceinline__ Row row_rms_reg(const Row& x, const Row& s) {
+  Row q;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) q.v[j] = x.v[j] * x.v[j];
+  const float rstd = rsqrtf(row_sum(q) * (1.0f / 64.0f) + EPSN);
+  Row r;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r.v[j] = x.v[j] * rstd * s.v[j];
+  return r;
+}
+
 // 64 -> 64 layer with the weight fragments already in registers (w[g][gk]: rows 16 g + m, columns 16 gk + 4 kq ..)
 __device__ __forceinline__ Row dense64_reg(const Row& x, const float4 (&w)[4][4], const float* __restrict__ bias, int kq) {
   Row y;
@@ -59,10 +70,16 @@ template <int TAIL>
 __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
   const int lane = threadIdx.x, m = lane & 15, kq = lane >> 4;
   const long ntiles = (a.R + 15) >> 4;
-  float4 wo[4][4], w0[4][4], w0b[(TAIL == 2 || TAIL == 1) ? 4 : 1][4], w0c[TAIL == 2 ? 4 : 1][4];
+  float4 wo[4][4], w0[4][4], w0b[TAIL != 0 ? 4 : 1][4], w0c[TAIL == 2 ? 4 : 1][4];
   load_w64(wo, a.wo_t, m, kq);
   if (TAIL == 1 || TAIL == 3) load_w64(w0, a.w0_t, m, kq);
-  if constexpr (TAIL == 1) { if (a.nq2 > 0) load_w64(w0b, a.q2_t[0], m, kq); }   // first decoder block's query projection stays resident too
+  if constexpr (TAIL == 1) { if (a.nq2 > 0) load_w64(w0b, a.q2_t[0], m, kq); }
+  Row b1r;
+  if constexpr (TAIL == 3) {   // logit head weights and bias resident as well (columns >= K of W1^T are zero rows, the bias is masked)
+    load_w64(w0b, a.w1_t, m, kq);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int n = 16 * (j >> 2) + 4 * kq + (j & 3); b1r.v[j] = n < a.K ? a.b1[n] : 0.f; }
+  }   // first decoder block's query projection stays resident too
   if (TAIL == 2) {   // the 64 -> 192 projection as three register-resident 64 -> 64 blocks (k | v | g)
     load_w64(w0, a.w0_t, m, kq);
 #pragma unroll
@@ -75,6 +92,12 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
   }
   const Row gam = row_load(a.gamma, kq), bet = row_load(a.beta, kq);
   const Row s1 = row_load(a.s1, kq);
+  // every per-feature parameter row of the segment is loaded once (a load inside the tile loop is a dependent L1/L2 round trip)
+  Row s2r, hsr, hwr, b0r;
+  if (a.s2) s2r = row_load(a.s2, kq);
+  if (TAIL == 1 || TAIL == 3) { hsr = row_load(a.hs, kq); b0r = row_load(a.b0, kq); }
+  if (TAIL == 1) hwr = row_load(a.hw, kq);
+  const float hb1 = TAIL == 1 ? a.hb1[0] : 0.f;
   // prefetch of the next tile's three input rows (rows past the end shadow the last row and are never stored)
   auto rowc = [&](long tile) { return min(tile * 16 + m, a.R - 1); };
   long tile = blockIdx.x;
@@ -121,7 +144,7 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) o.v[j] = o.v[j] * rs * s1.v[j];
     }
-    if (a.s2) o = row_rms(o, a.s2, kq);
+    if (a.s2) o = row_rms_reg(o, s2r);
     if (a.o) row_store(a.o + rw * AE, kq, o);
     Row ope = o;
     if (want_pe) {
@@ -129,14 +152,13 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
       if (a.ope) row_store(a.ope + rw * AE, kq, ope);
     }
     if (TAIL == 1) {          // encoder: value head + cross-retention queries
-      const Row hv = dense64_reg(o, w0, a.b0, kq);
+      const Row hv = row_add(dense64_reg(o, w0, nullptr, kq), b0r);
       row_store(a.out0 + rw * a.ld0, kq, hv);
-      const Row hn = row_rms(row_gelu(hv), a.hs, kq);
-      const Row w = row_load(a.hw, kq);
+      const Row hn = row_rms_reg(row_gelu(hv), hsr);
       Row hw;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) hw.v[j] = hn.v[j] * w.v[j];
-      const float val = row_sum(hw) + a.hb1[0];
+      for (int j = 0; j < 16; ++j) hw.v[j] = hn.v[j] * hwr.v[j];
+      const float val = row_sum(hw) + hb1;
       a.value[rw] = val;
       if constexpr (TAIL == 1) {
         if (a.nq2 > 0) row_store(a.q2[0] + rw * AE, kq, dense64_reg(ope, w0b, nullptr, kq));
@@ -153,20 +175,16 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
         row_store(orow + 128, kq, dense64_reg(ope, w0c, nullptr, kq));
       }
     } else if (TAIL == 3) {   // last decoder block: logit head
-      const Row hp = dense64_reg(o, w0, a.b0, kq);
+      const Row hp = row_add(dense64_reg(o, w0, nullptr, kq), b0r);
       row_store(a.out0 + rw * a.ld0, kq, hp);
-      const Row hn = row_rms(row_gelu(hp), a.hs, kq);
+      const Row hn = row_rms_reg(row_gelu(hp), hsr);
       row_store(a.hn + rw * AE, kq, hn);
-      float* lrow = a.logits + rw * AE;
-      wgemm<4>(hn, a.w1_t, m, kq, [&](int gg, f32x4 acc) {
-        float4 v4;
-        const int n0 = 16 * gg + 4 * kq;
-        v4.x = n0 < a.K ? acc[0] + a.b1[n0] : 0.f;
-        v4.y = n0 + 1 < a.K ? acc[1] + a.b1[n0 + 1] : 0.f;
-        v4.z = n0 + 2 < a.K ? acc[2] + a.b1[n0 + 2] : 0.f;
-        v4.w = n0 + 3 < a.K ? acc[3] + a.b1[n0 + 3] : 0.f;
-        st4g(lrow + n0, v4);
-      });
+      if constexpr (TAIL == 3) {
+        Row lg = row_add(dense64_reg(hn, w0b, nullptr, kq), b1r);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int n = 16 * (j >> 2) + 4 * kq + (j & 3); lg.v[j] = n < a.K ? lg.v[j] : 0.f; }
+        row_store(a.logits + rw * AE, kq, lg);
+      }
     }
   }
 }
