@@ -133,6 +133,12 @@ int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_
  *   w0_t b0 out0 | hs hw hb1 value | q2_t[4] q2[4] | hn w1_t b1 logits   (o, ope, s2 and unused tail pointers may be NULL) */
 int magpo_seg_post(const int* dims_host, long R, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
 
+/* backward of that front: dsum = d(res + y) through the RMSNorm(s), du = dsum W_o^T, (dr, dg) through GroupNorm + swish gate, and the
+ * parameter-gradient rows (s1, s2, gamma, beta) as [magpo_seg_bwd_grid(R)][64] slabs.  ptrs_host[19]: a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta |
+ * dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be   (y, s2, d1, d2, slab_s2 may be NULL) */
+int magpo_seg_bwd_grid(long R);
+int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
+
 /* ---- K3/K8 GRU actor (base.py:121-184; flax GRUCell) ---- */
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                        const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,

@@ -189,6 +189,131 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
   }
 }
 
+
+// ---- backward of the front of a post-retention segment (all three sites of a block share it) -------------------------
+//   dsum = d(res + y)  from  o = rms(rms(res + y) s1) s2   with incoming d0 (+ d1 + d2)          (k_resnorm_bwd)
+//   du   = dsum W_o^T                                                                            (dense layer)
+//   dr, dg from u = swish(g) * GroupNorm(r)                                                      (k_retpost_bwd)
+// plus the four parameter-gradient rows (s1, s2, gamma, beta) as per-wave slabs.  Reads 5-7 rows, writes 3 (was 12-13 streams).
+struct SegBwdArgs {
+  long R;
+  const float* a; const float* y; const float* s1; const float* s2;
+  const float* d0; const float* d1; const float* d2;
+  const float* wo_nat;                 // W_o [64 in][64 out] natural layout = "W^T" of du = dsum W_o^T
+  const float* r; const float* gp; long ldg; const float* gamma; const float* beta;
+  float* dsum; float* dr; float* dgp; long lddg;
+  float* slab_s1; float* slab_s2; float* slab_ga; float* slab_be;   // [grid][64]
+};
+
+__global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
+  const int lane = threadIdx.x, m = lane & 15, kq = lane >> 4;
+  const long ntiles = (a.R + 15) >> 4;
+  float4 wo[4][4];
+  load_w64(wo, a.wo_nat, m, kq);
+  const Row s1 = row_load(a.s1, kq), gam = row_load(a.gamma, kq), bet = row_load(a.beta, kq);
+  Row s2;
+  if (a.s2) s2 = row_load(a.s2, kq);
+  Row ds1, ds2, dga, dbe;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ds1.v[j] = 0.f; ds2.v[j] = 0.f; dga.v[j] = 0.f; dbe.v[j] = 0.f; }
+  auto rowc = [&](long tile) { return min(tile * 16 + m, a.R - 1); };
+  Row na, ny, nd, nd1, nd2, nr, ng;   // next tile's rows: loads only here (the sums are formed when the tile is used)
+  auto fetch = [&](long row) {
+    na = row_load(a.a + row * AE, kq);
+    if (a.y) ny = row_load(a.y + row * AE, kq);
+    nd = row_load(a.d0 + row * AE, kq);
+    if (a.d1) nd1 = row_load(a.d1 + row * AE, kq);
+    if (a.d2) nd2 = row_load(a.d2 + row * AE, kq);
+    nr = row_load(a.r + row * AE, kq);
+    ng = row_load(a.gp + row * a.ldg, kq);
+  };
+  long tile = blockIdx.x;
+  fetch(rowc(tile));
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long row = tile * 16 + m;
+    const long rw = min(row, a.R - 1);
+    const float live = row < a.R ? 1.f : 0.f;   // shadow rows are stored (same values as the last row) but not accumulated
+    Row x = a.y ? row_add(na, ny) : na;
+    Row d = nd;
+    if (a.d1) d = row_add(d, nd1);
+    if (a.d2) d = row_add(d, nd2);
+    const Row r = nr, g = ng;
+    fetch(rowc(min(tile + (long)gridDim.x, ntiles - 1)));
+    // ---- residual + RMSNorm(s) backward
+    Row t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t.v[j] = x.v[j] * x.v[j];
+    const float rstd1 = rsqrtf(row_sum(t) * (1.0f / 64.0f) + EPSN);
+    Row xh1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xh1.v[j] = x.v[j] * rstd1;
+    if (a.s2) {
+      Row y1;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { y1.v[j] = xh1.v[j] * s1.v[j]; t.v[j] = y1.v[j] * y1.v[j]; }
+      const float rstd2 = rsqrtf(row_sum(t) * (1.0f / 64.0f) + EPSN);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float xh2 = y1.v[j] * rstd2;
+        ds2.v[j] += live * d.v[j] * xh2;
+        y1.v[j] = xh2;                       // y1 <- xhat2
+        d.v[j] = d.v[j] * s2.v[j];           // d <- g2
+        t.v[j] = d.v[j] * xh2;
+      }
+      const float dot2 = row_sum(t) * (1.0f / 64.0f);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d.v[j] = (d.v[j] - y1.v[j] * dot2) * rstd2;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      ds1.v[j] += live * d.v[j] * xh1.v[j];
+      d.v[j] = d.v[j] * s1.v[j];             // d <- g1
+      t.v[j] = d.v[j] * xh1.v[j];
+    }
+    const float dot1 = row_sum(t) * (1.0f / 64.0f);
+    Row dsum;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dsum.v[j] = (d.v[j] - xh1.v[j] * dot1) * rstd1;
+    row_store(a.dsum + rw * AE, kq, dsum);
+    // ---- du = dsum W_o^T, then GroupNorm + swish gate backward
+    const Row du = dense64_reg(dsum, wo, nullptr, kq);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t.v[j] = r.v[j] * r.v[j];
+    const float mu = row_sum(r) * (1.0f / 64.0f), m2 = row_sum(t) * (1.0f / 64.0f);
+    const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
+    Row xh, gg, dg;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      xh.v[j] = (r.v[j] - mu) * rstd;
+      const float rn = xh.v[j] * gam.v[j] + bet.v[j];
+      const float sg = fast_sigmoid(g.v[j]);
+      const float sw = g.v[j] * sg;                                  // swish
+      const float swg = sg * (1.0f + g.v[j] * (1.0f - sg));          // d swish / dg
+      const float drn = du.v[j] * sw;
+      dg.v[j] = du.v[j] * rn * swg;
+      dga.v[j] += live * drn * xh.v[j];
+      dbe.v[j] += live * drn;
+      gg.v[j] = drn * gam.v[j];
+      t.v[j] = gg.v[j] * xh.v[j];
+    }
+    const float mg = row_sum(gg) * (1.0f / 64.0f), mgx = row_sum(t) * (1.0f / 64.0f);
+    Row dx;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dx.v[j] = (gg.v[j] - mg - xh.v[j] * mgx) * rstd;
+    row_store(a.dr + rw * AE, kq, dx);
+    row_store(a.dgp + rw * a.lddg, kq, dg);
+  }
+  // per-wave parameter-gradient rows: sum over the 16 row slots of the wave (DPP all-reduce inside each 16-lane row), one slab row each
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ds1.v[j] = gsum(ds1.v[j], 16); ds2.v[j] = gsum(ds2.v[j], 16); dga.v[j] = gsum(dga.v[j], 16); dbe.v[j] = gsum(dbe.v[j], 16); }
+  if (m == 0) {
+    row_store(a.slab_s1 + (long)blockIdx.x * AE, kq, ds1);
+    if (a.s2) row_store(a.slab_s2 + (long)blockIdx.x * AE, kq, ds2);
+    row_store(a.slab_ga + (long)blockIdx.x * AE, kq, dga);
+    row_store(a.slab_be + (long)blockIdx.x * AE, kq, dbe);
+  }
+}
+
 }  // namespace magpo
 
 using namespace magpo;
@@ -222,4 +347,24 @@ extern "C" int magpo_seg_post(const int* dims_host, long R, const void* const* p
     default: hipLaunchKernelGGL(k_seg_post<3>, dim3((unsigned)grid), dim3(64), 0, st, a); break;
   }
   return check_launch("magpo_seg_post");
+}
+
+// Number of slab rows magpo_seg_bwd writes for R rows (= its grid size).
+extern "C" int magpo_seg_bwd_grid(long R) { const long nt = (R + 15) / 16; return (int)(nt < 1024 ? (nt < 1 ? 1 : nt) : 1024); }
+
+// ptrs_host[19] (device pointers): a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta | dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be
+// (y, s2, d1, d2, slab_s2 may be NULL); ldg / lddg: row strides of gp / dgp.  Slabs: [magpo_seg_bwd_grid(R)][64].
+extern "C" int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* p, int nptrs, hipStream_t st) {
+  if (R <= 0) return MAGPO_OK;
+  if (nptrs != 19) { set_error("magpo_seg_bwd: pointer table size mismatch"); return MAGPO_EINVAL; }
+  SegBwdArgs a;
+  a.R = R; a.ldg = ldg; a.lddg = lddg;
+  int i = 0;
+  a.a = (const float*)p[i++]; a.y = (const float*)p[i++]; a.s1 = (const float*)p[i++]; a.s2 = (const float*)p[i++];
+  a.d0 = (const float*)p[i++]; a.d1 = (const float*)p[i++]; a.d2 = (const float*)p[i++]; a.wo_nat = (const float*)p[i++];
+  a.r = (const float*)p[i++]; a.gp = (const float*)p[i++]; a.gamma = (const float*)p[i++]; a.beta = (const float*)p[i++];
+  a.dsum = (float*)p[i++]; a.dr = (float*)p[i++]; a.dgp = (float*)p[i++];
+  a.slab_s1 = (float*)p[i++]; a.slab_s2 = (float*)p[i++]; a.slab_ga = (float*)p[i++]; a.slab_be = (float*)p[i++];
+  hipLaunchKernelGGL(k_seg_bwd, dim3((unsigned)magpo_seg_bwd_grid(R)), dim3(64), 0, st, a);
+  return check_launch("magpo_seg_bwd");
 }

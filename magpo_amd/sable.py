@@ -342,6 +342,25 @@ class SableGuider:
             self._seg_tabs[key] = ent
         self.L.call("magpo_seg_post", ent[0].ctypes.data, R, ent[1].ctypes.data, int(ent[1].size), self._st())
 
+    def _seg_bwd(self, a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, ldg, pfx, dsum, dr, dgp, lddg, R, g_s1, g_s2, acc_s1=False):
+        """Backward of the front of a post-retention segment in one launch (csrc/seg_fused.hip: k_seg_bwd): d(res + y) through the
+        RMSNorm(s), dsum W_o^T, GroupNorm + gate backward, and the four parameter-gradient rows (reduced from per-wave slabs)."""
+        v, gv, b = self.v, self.gv, self.b
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        G = self.L.call("magpo_seg_bwd_grid", R)
+        sl = [b.get(f"sb_{i}", (G, E)) for i in range(4)]
+        tab = [a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, v[pfx + "gn.scale"], v[pfx + "gn.bias"], dsum, dr, dgp, sl[0], sl[1] if s2 is not None else None, sl[2], sl[3]]
+        key = ("bwd", R, ldg, lddg, tuple(ptr(t) for t in tab))
+        ent = self._seg_tabs.get(key)
+        if ent is None:
+            ent = np.array([ptr(t) for t in tab], dtype=np.uint64)
+            self._seg_tabs[key] = ent
+        self.L.call("magpo_seg_bwd", R, ldg, lddg, ent.ctypes.data, int(ent.size), self._st())
+        self.reduce(sl[0], g_s1, accumulate=acc_s1)
+        if s2 is not None:
+            self.reduce(sl[1], g_s2)
+        self.reduce(sl[2], gv[pfx + "gn.scale"]); self.reduce(sl[3], gv[pfx + "gn.bias"])
+
     # ------------------------------------------------------------------ training forward (chunkwise form)
     def train_fwd(self, obs, prev_idx, pos, dones, s0, seq_env, nseq: int, T: int):
         """obs [R,F], prev_idx [R] (0 = start token, a+1 otherwise), pos [R] step counts, dones [nseq,T] u8,
@@ -464,15 +483,20 @@ class SableGuider:
         for k in reversed(range(nb)):
             d = f"dec.block{k}."
             dsum2 = g(f"dsum2_{k}")
-            L.call("magpo_resnorm_bwd", t("rep"), E, t(f"y2{k}"), E, v[d + "ln2.scale"], v[d + "ln3.scale"], din0, E, din1, E if din1 is not None else 0,
-                   None, 0, dsum2, E, slab("a"), slab("b"), R, st)
-            self.reduce(slab("a"), gv[d + "ln2.scale"]); self.reduce(slab("b"), gv[d + "ln3.scale"])
-            self.wgrad(t(f"u2{k}"), E, dsum2, E, R, E, E, gv[d + "retn2.w_o"])
-            du2 = g("du")
-            self.lin(dsum2, E, v[d + "retn2.w_o"], None, du2, E, R, E, E)
             dr2 = g("dr"); dq2 = g(f"dq2_{k}"); dkvg2 = g(f"dkvg2_{k}", 3 * E)
             kvg2 = t(f"kvg2{k}")
-            self._retpost_bwd(t(f"r2{k}"), kvg2[:, 2 * E:], 3 * E, d + "retn2.", du2, dr2, dkvg2[:, 2 * E:], 3 * E, R, slab("a"), slab("b"))
+            if self.fused_segments:
+                self._seg_bwd(t("rep"), t(f"y2{k}"), v[d + "ln2.scale"], v[d + "ln3.scale"], din0, din1, None, v[d + "retn2.w_o"], t(f"r2{k}"),
+                              kvg2[:, 2 * E:], 3 * E, d + "retn2.", dsum2, dr2, dkvg2[:, 2 * E:], 3 * E, R, gv[d + "ln2.scale"], gv[d + "ln3.scale"])
+                self.wgrad(t(f"u2{k}"), E, dsum2, E, R, E, E, gv[d + "retn2.w_o"])
+            else:
+                L.call("magpo_resnorm_bwd", t("rep"), E, t(f"y2{k}"), E, v[d + "ln2.scale"], v[d + "ln3.scale"], din0, E, din1, E if din1 is not None else 0,
+                       None, 0, dsum2, E, slab("a"), slab("b"), R, st)
+                self.reduce(slab("a"), gv[d + "ln2.scale"]); self.reduce(slab("b"), gv[d + "ln3.scale"])
+                self.wgrad(t(f"u2{k}"), E, dsum2, E, R, E, E, gv[d + "retn2.w_o"])
+                du2 = g("du")
+                self.lin(dsum2, E, v[d + "retn2.w_o"], None, du2, E, R, E, E)
+                self._retpost_bwd(t(f"r2{k}"), kvg2[:, 2 * E:], 3 * E, d + "retn2.", du2, dr2, dkvg2[:, 2 * E:], 3 * E, R, slab("a"), slab("b"))
             self._ret_bwd(t(f"q2{k}"), E, kvg2, 3 * E, kvg2[:, E:], 3 * E, dr2, dq2, E, dkvg2, 3 * E, dkvg2[:, E:], 3 * E, dones,
                           f"st_2{k}", nseq, T, 1)
             self.wgrad(t("reppe"), E, dq2, E, R, E, E, gv[d + "retn2.w_q"])
@@ -486,15 +510,20 @@ class SableGuider:
                 self.add_(drep_q, dreppe); self.add_(drep_r, dsum2)
             # self-retention: c = rms(x_k + y1) * ln1
             dsum1 = g(f"dsum1_{k}")
-            L.call("magpo_resnorm_bwd", t(f"x{k}"), E, t(f"y1{k}"), E, v[d + "ln1.scale"], None, dcpe, E, None, 0, None, 0, dsum1, E,
-                   slab("a"), None, R, st)
-            self.reduce(slab("a"), gv[d + "ln1.scale"])
-            self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
-            du1 = g("du")
-            self.lin(dsum1, E, v[d + "retn1.w_o"], None, du1, E, R, E, E)
             dr1 = g("dr"); dqkvg1 = g(f"dqkvg1_{k}", 4 * E)
             qkvg1 = t(f"qkvg1{k}")
-            self._retpost_bwd(t(f"r1{k}"), qkvg1[:, 3 * E:], 4 * E, d + "retn1.", du1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
+            if self.fused_segments:
+                self._seg_bwd(t(f"x{k}"), t(f"y1{k}"), v[d + "ln1.scale"], None, dcpe, None, None, v[d + "retn1.w_o"], t(f"r1{k}"),
+                              qkvg1[:, 3 * E:], 4 * E, d + "retn1.", dsum1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, gv[d + "ln1.scale"], None)
+                self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
+            else:
+                L.call("magpo_resnorm_bwd", t(f"x{k}"), E, t(f"y1{k}"), E, v[d + "ln1.scale"], None, dcpe, E, None, 0, None, 0, dsum1, E,
+                       slab("a"), None, R, st)
+                self.reduce(slab("a"), gv[d + "ln1.scale"])
+                self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
+                du1 = g("du")
+                self.lin(dsum1, E, v[d + "retn1.w_o"], None, du1, E, R, E, E)
+                self._retpost_bwd(t(f"r1{k}"), qkvg1[:, 3 * E:], 4 * E, d + "retn1.", du1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
             self._ret_bwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, dr1, dqkvg1, 4 * E, dqkvg1[:, E:], 4 * E,
                           dqkvg1[:, 2 * E:], 4 * E, dones, f"st_1{k}", nseq, T, 1)
             self.wgrad(t(f"xpe{k}"), E, dqkvg1, 4 * E, R, E, 4 * E, gv[d + "retn1.w_qkvg"])
@@ -520,15 +549,20 @@ class SableGuider:
         for k in reversed(range(nb)):
             e = f"enc.block{k}."
             dsum0 = g(f"dsum0_{k}")
-            L.call("magpo_resnorm_bwd", t(f"xn{k}"), E, t(f"y{k}"), E, v[e + "ln1.scale"], v[e + "ln2.scale"], e0, E, e1, E if e1 is not None else 0,
-                   e2, E if e2 is not None else 0, dsum0, E, slab("a"), slab("b"), R, st)
-            self.reduce(slab("a"), gv[e + "ln1.scale"]); self.reduce(slab("b"), gv[e + "ln2.scale"])
-            self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
-            du = g("du")
-            self.lin(dsum0, E, v[e + "retn.w_o"], None, du, E, R, E, E)
             dr = g("dr"); dqkvg = g(f"dqkvg_{k}", 4 * E)
             qkvg = t(f"qkvg{k}")
-            self._retpost_bwd(t(f"r{k}"), qkvg[:, 3 * E:], 4 * E, e + "retn.", du, dr, dqkvg[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
+            if self.fused_segments:
+                self._seg_bwd(t(f"xn{k}"), t(f"y{k}"), v[e + "ln1.scale"], v[e + "ln2.scale"], e0, e1, e2, v[e + "retn.w_o"], t(f"r{k}"),
+                              qkvg[:, 3 * E:], 4 * E, e + "retn.", dsum0, dr, dqkvg[:, 3 * E:], 4 * E, R, gv[e + "ln1.scale"], gv[e + "ln2.scale"])
+                self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
+            else:
+                L.call("magpo_resnorm_bwd", t(f"xn{k}"), E, t(f"y{k}"), E, v[e + "ln1.scale"], v[e + "ln2.scale"], e0, E, e1, E if e1 is not None else 0,
+                       e2, E if e2 is not None else 0, dsum0, E, slab("a"), slab("b"), R, st)
+                self.reduce(slab("a"), gv[e + "ln1.scale"]); self.reduce(slab("b"), gv[e + "ln2.scale"])
+                self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
+                du = g("du")
+                self.lin(dsum0, E, v[e + "retn.w_o"], None, du, E, R, E, E)
+                self._retpost_bwd(t(f"r{k}"), qkvg[:, 3 * E:], 4 * E, e + "retn.", du, dr, dqkvg[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
             self._ret_bwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, dr, dqkvg, 4 * E, dqkvg[:, E:], 4 * E, dqkvg[:, 2 * E:], 4 * E,
                           dones, f"st_e{k}", nseq, T, 0)
             self.wgrad(t(f"kin{k}"), E, dqkvg, 4 * E, R, E, 4 * E, gv[e + "retn.w_qkvg"])
