@@ -45,12 +45,17 @@ class KernelTimer:
             R, KIN, NOUT = a[7], a[8], a[9]
             if R < self.min_rows:
                 return None
-            return f"linear_k{KIN}", 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
+            if a[6] is None or a[10] == 4:   # no pre-activation copy (act 4: the slot carries the mask): shared-tile kernel
+                key = f"k_linear_lds<{KIN},{4 if ((NOUT + 31) // 32) % 4 == 0 else 2}>"
+            else:
+                key = f"k_linear_w<{KIN}>"
+            return key, 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
         if name == "magpo_wgrad":
             R, KIN, NOUT = a[4], a[5], a[7]
             if R < self.min_rows:
                 return None
-            return ("wgrad<2>" if NOUT >= 128 else "wgrad<1>"), 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
+            key = "k_wgrad_full<4,3>" if (KIN == 128 and NOUT == 384 and R >= 64 * 256) else ("k_wgrad<2>" if NOUT >= 128 else "k_wgrad<1>")
+            return key, 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
         if name in ("magpo_retention_chunk_fwd", "magpo_retention_chunk_bwd"):
             fwd = name.endswith("fwd")
             nseq, T, A = (a[13], a[14], a[15]) if fwd else (a[16], a[17], a[18])
@@ -59,23 +64,26 @@ class KernelTimer:
             gemms = 4 if fwd else 9
             rows = nseq * T * A
             byts = 4.0 * rows * 64 * (4 if fwd else 7) + 4.0 * nseq * nch * 4096
-            return ("ret_chunk_fwd" if fwd else "ret_chunk_bwd"), byts, gemms * 2.0 * 64 ** 3 * nseq * nch
+            return ("k_ret_chunk_fwd" if fwd else "k_ret_chunk_bwd"), byts, gemms * 2.0 * 64 ** 3 * nseq * nch
         if name == "magpo_retention_recurrent":
             nenv, ntok, wr = a[10], a[11], a[14]
-            return "ret_recurrent", 4.0 * nenv * ((2 if wr else 1) * 4096 + 4 * ntok * 64), 4.0 * nenv * ntok * 4096 + 2.0 * nenv * 4096
+            return "k_ret_recurrent", 4.0 * nenv * ((2 if wr else 1) * 4096 + 4 * ntok * 64), 4.0 * nenv * ntok * 4096 + 2.0 * nenv * 4096
         if name == "magpo_gru_scan_fwd":
             nseq, T, A = a[9], a[10], a[11]
             if T == 1:
                 return None
             rows = nseq * T * A
-            return "gru_scan_fwd", 4.0 * rows * (384 + 128 + 512 + 128), 2.0 * rows * 128 * 384
+            return "k_gru_scan_fwd<true,false>", 4.0 * rows * (384 + 128 + 512 + 128), 2.0 * rows * 128 * 384
         if name == "magpo_gru_scan_bwd":
             nseq, T, A = a[8], a[9], a[10]
             rows = nseq * T * A
-            return "gru_scan_bwd", 4.0 * rows * (512 + 128 + 128 + 768), 2.0 * rows * 384 * 128
+            return "k_gru_scan_bwd<true>", 4.0 * rows * (512 + 128 + 128 + 768), 2.0 * rows * 384 * 128
+        if name == "magpo_seg_bwd":
+            R = a[0]
+            return "k_seg_bwd", 4.0 * R * 64 * 9, 2.0 * R * 64 * 64
         if name == "magpo_loss_fwd_bwd":
             R, K = a[19], a[20]
-            return "loss", 4.0 * R * (4 * K + 8), 60.0 * R * K
+            return "k_magpo_loss", 4.0 * R * (4 * K + 8), 60.0 * R * K
         return None
 
     def begin(self, name, args):
@@ -124,8 +132,7 @@ class KernelTimer:
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
                 pmc = json.load(f)
-            name = {"wgrad<2>": "k_wgrad<2>", "wgrad<1>": "k_wgrad<1>", "ret_chunk_bwd": "k_ret_chunk_bwd", "ret_chunk_fwd": "k_ret_chunk_fwd",
-                    "gru_scan_fwd": "k_gru_scan_fwd<true,false>", "gru_scan_bwd": "k_gru_scan_bwd<true>"}.get(key)
+            name = key   # timer keys are the rocprof kernel names (template arguments without spaces)
             if name in pmc and getattr(self, "attach_traffic", True):
                 roof["traffic"] = round(pmc[name]["total"])
         except (OSError, ValueError):
