@@ -29,31 +29,37 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-// reduce over groups of 16 consecutive lanes
+// all-reduce sum over aligned groups of 16 consecutive lanes (= one DPP row): row mirrors + quad permutes on the VALU,
+// no LDS round trip (a __shfl_xor is a ds_bpermute)
+template <int CTRL> __device__ __forceinline__ float dpp_mov_(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float sum16(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_mov_<0x140>(v);   // row_mirror
+  v += dpp_mov_<0x141>(v);   // row_half_mirror
+  v += dpp_mov_<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_<0xB1>(v);    // quad_perm [1,0,3,2]
   return v;
 }
 
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// hardware exp2 / rcp based variants for the GRU gates (abs. error ~1e-7, far inside the fp32 parity tolerance)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ float gelu_tanh(float x) {
   // jax.nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
   const float c = 0.7978845608028654f;
   float u = c * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  return 0.5f * x * (1.0f + fast_tanh(u));   // hardware exp / rcp (abs. error ~1e-7): the row kernels that use it are VALU-bound with libm's tanhf
 }
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
   const float c = 0.7978845608028654f;
   float x2 = x * x;
   float u = c * (x + 0.044715f * x * x2);
-  float t = tanhf(u);
+  float t = fast_tanh(u);
   float du = c * (1.0f + 3.0f * 0.044715f * x2);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-// hardware exp2 / rcp based variants for the GRU gates (abs. error ~1e-7, far inside the fp32 parity tolerance)
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float swish_grad(float x) {
   float s = sigmoidf_(x);

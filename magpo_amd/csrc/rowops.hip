@@ -93,7 +93,21 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
     const bool ok = row < a.R;
     float4 z = f4zero();
     if (ok) {
-      if (mode == 0) {
+      if (mode == 0 && a.F <= 8) {   // small observation: every load of the row issued together (no dependent run-time loop)
+        const float* o = a.obs + row * a.ldo;
+        float of[8], ms = 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) { of[f] = f < a.F ? o[f] : 0.f; ms += of[f] * of[f]; }
+        const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          if (f < a.F) {
+            const float on = of[f] * rstd * a.s_obs[f];
+            const float4 w = ld4(a.W + f * 64 + c4);
+            z.x += on * w.x; z.y += on * w.y; z.z += on * w.z; z.w += on * w.w;
+          }
+        }
+      } else if (mode == 0) {
         const float* o = a.obs + row * a.ldo;
         float ms = 0.f;
         for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
@@ -149,25 +163,39 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
 #pragma unroll
   for (int f = 0; f < NR; ++f) wacc[f] = f4zero();
   float dsobs[MODE == 0 ? NR : 1];
+  // MODE 0: the small encoder's parameters live in registers (a load inside a run-time loop over F is a dependent L1 round trip per
+  // feature: the kernel spent ~7 us per row group in such loops)
+  float sob[MODE == 0 ? NR : 1];
+  float4 wob[MODE == 0 ? NR : 1];
   if (MODE == 0) {
 #pragma unroll
-    for (int f = 0; f < NR; ++f) dsobs[f] = 0.f;
+    for (int f = 0; f < NR; ++f) {
+      dsobs[f] = 0.f;
+      sob[f] = f < a.F ? a.s_obs[f] : 0.f;
+      wob[f] = f < a.F ? ld4(a.W + f * 64 + c4) : f4zero();
+    }
   }
   for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < a.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
     const long row = base + wave * 4 + (lane >> 4);
     const bool ok = row < a.R;
     float4 z = f4zero(), d = f4zero();
+    float of[MODE == 0 ? NR : 1];   // MODE 0: normalised observation features of this row (all loads issued together)
+    if (MODE == 0) {
+      const float* o = a.obs + (ok ? row : 0) * a.ldo;
+      float ms = 0.f;
+#pragma unroll
+      for (int f = 0; f < NR; ++f) { of[f] = f < a.F ? o[f] : 0.f; ms += of[f] * of[f]; }
+      const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
+#pragma unroll
+      for (int f = 0; f < NR; ++f) of[f] *= rstd;
+    }
     if (ok) {
       if (a.z) z = ld4(a.z + row * a.ldz + c4);
-      else if (MODE == 0) {   // pre-activation not saved by the forward: recompute it from the observation row (F <= 32 terms)
-        const float* o = a.obs + row * a.ldo;
-        float ms = 0.f;
-        for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
-        const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
-        for (int f = 0; f < a.F; ++f) {
-          const float of = o[f] * rstd * a.s_obs[f];
-          const float4 w = ld4(a.W + f * 64 + c4);
-          z.x += of * w.x; z.y += of * w.y; z.z += of * w.z; z.w += of * w.w;
+      else if (MODE == 0) {   // pre-activation not saved by the forward: recompute it from the observation row
+#pragma unroll
+        for (int f = 0; f < NR; ++f) {
+          const float on = of[f] * sob[f];
+          z.x += on * wob[f].x; z.y += on * wob[f].y; z.z += on * wob[f].z; z.w += on * wob[f].w;
         }
       } else z = ld4(a.W + (long)a.idx[row * a.idx_stride] * 64 + c4);   // ... or gather it from the embedding table
       d = ld4(a.d0 + row * a.ldd0 + c4);
@@ -183,20 +211,12 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
     if (ok && a.dz) st4(a.dz + row * a.lddz + c4, dz);
     if (MODE == 0) {
       // dW_obs[f] += o[f] * dz ; d(s_obs)[f] += (dz . W[f,:]) * obs[f] * rstd   (the obs need no gradient)
-      const float* o = a.obs + (ok ? row : 0) * a.ldo;
-      float ms = 0.f;
-      for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
-      const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
 #pragma unroll
       for (int f = 0; f < NR; ++f) {
-        if (f < a.F) {
-          const float of = o[f] * rstd;
-          const float on = of * a.s_obs[f];
-          wacc[f].x += on * dz.x; wacc[f].y += on * dz.y; wacc[f].z += on * dz.z; wacc[f].w += on * dz.w;
-          const float4 w = ld4(a.W + f * 64 + c4);
-          float dof = sum16(f4sum(f4mul(dz, w)));
-          if ((lane & 15) == 0) dsobs[f] += dof * of;
-        }
+        const float on = of[f] * sob[f];
+        wacc[f].x += on * dz.x; wacc[f].y += on * dz.y; wacc[f].z += on * dz.z; wacc[f].w += on * dz.w;
+        const float dof = sum16(f4sum(f4mul(dz, wob[f])));
+        dsobs[f] += dof * of[f];     // every lane of the row keeps the same partial; lane 0 of the row group publishes it
       }
     } else {
       const int id = ok ? a.idx[row * a.idx_stride] : -1;
