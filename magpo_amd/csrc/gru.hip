@@ -284,10 +284,22 @@ __global__ void k_small_linear(const float* __restrict__ X, int ldx, int F, cons
   int c4 = 4 * (int)(i - row * n4);
   float4 acc = *reinterpret_cast<const float4*>(b + c4);
   const float* x = X + row * ldx;
-  for (int f = 0; f < F; ++f) {
-    const float xv = x[f];
-    const float4 w = *reinterpret_cast<const float4*>(W + (long)f * N + c4);
-    acc.x += xv * w.x; acc.y += xv * w.y; acc.z += xv * w.z; acc.w += xv * w.w;
+  if (F <= 8) {   // all loads of the row issued together (a run-time loop makes them dependent round trips)
+    float xv[8];
+    float4 w[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      xv[f] = f < F ? x[f] : 0.f;
+      w[f] = f < F ? *reinterpret_cast<const float4*>(W + (long)f * N + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { acc.x += xv[f] * w[f].x; acc.y += xv[f] * w[f].y; acc.z += xv[f] * w[f].z; acc.w += xv[f] * w[f].w; }
+  } else {
+    for (int f = 0; f < F; ++f) {
+      const float xv = x[f];
+      const float4 w = *reinterpret_cast<const float4*>(W + (long)f * N + c4);
+      acc.x += xv * w.x; acc.y += xv * w.y; acc.z += xv * w.z; acc.w += xv * w.w;
+    }
   }
   if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
   *reinterpret_cast<float4*>(Y + row * ldy + c4) = acc;

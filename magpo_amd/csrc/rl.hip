@@ -188,13 +188,23 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
     const long rr = ok ? r : 0;
     float xg[4], xa[4];
     bool legal[4];
+    // one unconditional float4 per lane and operand when the rows are padded to 64 columns (a predicated load per element is an
+    // exec-masked block with its own wait); the K / mask selection happens on the loaded values
+    const bool vec = a.ldg >= 64 && a.lda >= 64 && ((a.ldg | a.lda) & 3) == 0;
+    float4 vg = make_float4(0.f, 0.f, 0.f, 0.f), va = vg;
+    if (vec) {
+      vg = *reinterpret_cast<const float4*>(a.g_logits + rr * a.ldg + c4);
+      va = *reinterpret_cast<const float4*>(a.a_logits + rr * a.lda + c4);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = c4 + j;
       const bool in = k < a.K;
-      legal[j] = in && (!a.mask || a.mask[rr * a.K + k]);
-      xg[j] = in ? (legal[j] ? a.g_logits[rr * a.ldg + k] : FMIN) : -INFINITY;
-      xa[j] = in ? (legal[j] ? a.a_logits[rr * a.lda + k] : FMIN) : -INFINITY;
+      legal[j] = in && (!a.mask || a.mask[rr * a.K + (in ? k : 0)]);
+      const float lg = vec ? (j == 0 ? vg.x : (j == 1 ? vg.y : (j == 2 ? vg.z : vg.w))) : (in ? a.g_logits[rr * a.ldg + k] : 0.f);
+      const float la = vec ? (j == 0 ? va.x : (j == 1 ? va.y : (j == 2 ? va.z : va.w))) : (in ? a.a_logits[rr * a.lda + k] : 0.f);
+      xg[j] = in ? (legal[j] ? lg : FMIN) : -INFINITY;
+      xa[j] = in ? (legal[j] ? la : FMIN) : -INFINITY;
     }
     const float mg = max16(fmaxf(fmaxf(xg[0], xg[1]), fmaxf(xg[2], xg[3])));
     const float ma = max16(fmaxf(fmaxf(xa[0], xa[1]), fmaxf(xa[2], xa[3])));
