@@ -148,3 +148,31 @@ def test_fused_act_equals_kernel_composition(A, K, N, nb, nh):
     close(b.last_val, a.last_val, 1e-5, 1e-6, "last_val")
     for x, y in zip(a.sable_hs, b.sable_hs):
         close(y, x, 1e-5, 1e-6, "sable state")
+
+
+@pytest.mark.parametrize("A,K,N,T,nb", [(4, 20, 12, 16, 1), (3, 10, 7, 9, 2)])
+def test_fused_segments_equal_kernel_composition(A, K, N, T, nb):
+    """k_seg_post / k_seg_bwd (token-local parts between the retention ops as single launches) against the kernel-by-kernel
+    training path: same data, same parameters -> same losses and gradients to fp32 rounding (ragged row counts included)."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    sysc = SystemConfig(rollout_length=T, ppo_epochs=1, num_minibatches=1)
+    key = host_split(prng_key(21), 4)[0]
+    ls = []
+    for fused in (False, True):
+        l = MagpoLearner(CoordSumConfig(A, K, 7, 3 * K), N, sysc, "cuda", net_seed=3, wgrad_groups=4, n_block=nb)
+        l.guider.fused_segments = fused
+        l.use_graph = False
+        l.setup(key)
+        l.rollout()
+        env_idx = torch.arange(N, device="cuda", dtype=torch.int32)
+        agent_perm = torch.arange(A, device="cuda", dtype=torch.int32)
+        l.minibatch_grads(env_idx, agent_perm)
+        torch.cuda.synchronize()
+        ls.append(l)
+    a, b = ls
+    assert torch.equal(a.traj["action"], b.traj["action"])
+    close(b.loss_out, a.loss_out, 1e-5, 1e-6, "losses")
+    ga, gb = a.guider.grads, b.guider.grads
+    scale = float(ga.abs().max())
+    assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-7, "guider gradients differ between the fused and the composed path"
+    close(b.actor.grads, a.actor.grads, 1e-5, 1e-7, "actor gradients")
