@@ -305,6 +305,42 @@ __global__ void k_small_linear(const float* __restrict__ X, int ldx, int F, cons
   *reinterpret_cast<float4*>(Y + row * ldy + c4) = acc;
 }
 
+// N = 128, F <= 8: one thread owns a float4 column slot for RPT rows, so the weight rows are loaded once per RPT outputs
+// (the one-row kernel issues 8 weight requests per 16-byte store and is L1-request bound at ~2 TB/s).
+template <int RPT>
+__global__ __launch_bounds__(256) void k_small_linear128(const float* __restrict__ X, int ldx, int F, const float* __restrict__ W,
+                                                         const float* __restrict__ b, float* __restrict__ Y, int ldy, long R, int relu) {
+  const int c4 = 4 * (threadIdx.x & 31), slot = threadIdx.x >> 5;
+  const long row0 = (long)blockIdx.x * (8 * RPT) + slot;
+  float4 w[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int fc = f < F ? f : 0;
+    const float4 t = *reinterpret_cast<const float4*>(W + fc * 128 + c4);
+    const float m = f < F ? 1.f : 0.f;
+    w[f] = make_float4(t.x * m, t.y * m, t.z * m, t.w * m);
+  }
+  const float4 bias = *reinterpret_cast<const float4*>(b + c4);
+  float xv[RPT][8];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    long row = row0 + 8 * j;
+    row = row < R ? row : R - 1;
+    const float* x = X + row * ldx;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) xv[j][f] = x[f < F ? f : 0];
+  }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    float4 acc = bias;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { acc.x += xv[j][f] * w[f].x; acc.y += xv[j][f] * w[f].y; acc.z += xv[j][f] * w[f].z; acc.w += xv[j][f] * w[f].w; }
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    const long row = row0 + 8 * j;
+    if (row < R) *reinterpret_cast<float4*>(Y + row * ldy + c4) = acc;
+  }
+}
+
 }  // namespace magpo
 
 using namespace magpo;
@@ -360,6 +396,11 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
 extern "C" int magpo_small_linear(const float* X, int ldx, int F, const float* W, const float* b, float* Y, int ldy, int N,
                                   long R, int relu, hipStream_t st) {
   if (N & 3) { set_error("magpo_small_linear: N must be a multiple of 4"); return MAGPO_EINVAL; }
+  if (N == 128 && F <= 8 && R >= 4096) {
+    constexpr int RPT = 4;
+    hipLaunchKernelGGL(k_small_linear128<RPT>, dim3((unsigned)((R + 8 * RPT - 1) / (8 * RPT))), dim3(256), 0, st, X, ldx, F, W, b, Y, ldy, R, relu);
+    return check_launch("magpo_small_linear");
+  }
   long n = R * (N / 4);
   hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, ldx, F, W, b, Y, ldy, N, R, relu);
   return check_launch("magpo_small_linear");

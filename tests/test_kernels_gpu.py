@@ -145,6 +145,22 @@ def test_gru_carry_equals_stepwise_scan(L, stream):
     assert torch.equal(h_last, ref)
 
 
+@pytest.mark.parametrize("F,R,relu", [(5, 100, 1), (5, 5003, 1), (8, 4096, 0), (3, 4133, 1)])
+def test_small_linear(L, stream, F, R, relu):
+    """Actor pre-torso Dense(F -> 128) (+ReLU): the one-row kernel (small R) and the 4-rows-per-thread kernel (R >= 4096)."""
+    g = torch.Generator().manual_seed(F * 1000 + R)
+    X = torch.randn(R, F, generator=g)
+    W = torch.randn(F, 128, generator=g) * 0.4
+    b = torch.randn(128, generator=g) * 0.1
+    Y = torch.full((R + 1, 128), -7.0, device=DEV)
+    L.call("magpo_small_linear", dev(X), F, F, dev(W), dev(b), Y, 128, 128, R, relu, stream)
+    ref = X.double() @ W.double() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    close(Y[:R], ref, what="small_linear")
+    assert (Y[R] == -7.0).all()            # nothing written past the last row
+
+
 def _pe_table(L, st, npos=101):
     pe = torch.empty(npos, 64, device=DEV)
     L.call("magpo_pe_table", pe, npos, 64, st)
