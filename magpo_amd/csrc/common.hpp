@@ -15,6 +15,18 @@ namespace magpo {
 void set_error(const char* msg);
 int check_launch(const char* what);
 
+// Grid of a grid-stride kernel: at most `want` blocks, and never more than are co-resident on the device (a partial
+// second round of blocks would leave most CUs idle while the stragglers finish).
+template <typename K>
+inline unsigned resident_grid(K kernel, int threads, long want) {
+  int per_cu = 0, dev = 0, ncu = 256;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  const long cap = (long)per_cu * ncu;
+  return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
 // Row pitch (floats) of a 64-column LDS tile: +4 keeps 16-B alignment and makes the
 // row-per-lane ds_read_b128 pattern conflict-free (bank = 4*row + c mod 64).
 constexpr int LDP = 4;
@@ -23,6 +35,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// Sum of part[q + stride * i], i < nb, over one wave (lane-strided partial sums, then a fixed butterfly): the
+// deterministic final stage of the two-level double-precision reductions.
+__device__ __forceinline__ double wave_sum_strided(const double* __restrict__ part, int nb, int stride, int q) {
+  double s = 0.0;
+  for (int i = threadIdx.x & 63; i < nb; i += 64) s += part[(long)stride * i + q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -305,39 +305,48 @@ __global__ void k_small_linear(const float* __restrict__ X, int ldx, int F, cons
   *reinterpret_cast<float4*>(Y + row * ldy + c4) = acc;
 }
 
-// N = 128, F <= 8: one thread owns a float4 column slot for RPT rows, so the weight rows are loaded once per RPT outputs
-// (the one-row kernel issues 8 weight requests per 16-byte store and is L1-request bound at ~2 TB/s).
-template <int RPT>
+// N = 128, F <= 8: 32 rows per block iteration.  The weight rows stay in registers, the observation tile arrives as one
+// coalesced load per thread through double-buffered LDS (fetched one iteration ahead), so a 16-byte store costs a
+// quarter of a memory request instead of the ~16 of the one-row kernel.
 __global__ __launch_bounds__(256) void k_small_linear128(const float* __restrict__ X, int ldx, int F, const float* __restrict__ W,
                                                          const float* __restrict__ b, float* __restrict__ Y, int ldy, long R, int relu) {
-  const int c4 = 4 * (threadIdx.x & 31), slot = threadIdx.x >> 5;
-  const long row0 = (long)blockIdx.x * (8 * RPT) + slot;
+  __shared__ float xs[2][256];
+  const int t = threadIdx.x, c4 = 4 * (t & 31), slot = t >> 5;
   float4 w[8];
 #pragma unroll
   for (int f = 0; f < 8; ++f) {
-    const int fc = f < F ? f : 0;
-    const float4 t = *reinterpret_cast<const float4*>(W + fc * 128 + c4);
+    const float4 v = *reinterpret_cast<const float4*>(W + (f < F ? f : 0) * 128 + c4);
     const float m = f < F ? 1.f : 0.f;
-    w[f] = make_float4(t.x * m, t.y * m, t.z * m, t.w * m);
+    w[f] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
   }
   const float4 bias = *reinterpret_cast<const float4*>(b + c4);
-  float xv[RPT][8];
+  const long stride = (long)gridDim.x * 32;
+  long base = (long)blockIdx.x * 32;
+  if (base >= R) return;
+  const int fx = (t & 7) < F ? (t & 7) : 0;
+  auto fetch = [&](long bs) {
+    long r = bs + (t >> 3);
+    r = r < R ? r : R - 1;
+    return X[r * ldx + fx];
+  };
+  float xn = fetch(base);
+  for (int it = 0; base < R; base += stride, it ^= 1) {
+    xs[it][t] = xn;
+    __syncthreads();
+    if (base + stride < R) xn = fetch(base + stride);
 #pragma unroll
-  for (int j = 0; j < RPT; ++j) {
-    long row = row0 + 8 * j;
-    row = row < R ? row : R - 1;
-    const float* x = X + row * ldx;
+    for (int j = 0; j < 4; ++j) {
+      const int lrow = slot + 8 * j;
+      const float4 xa = *reinterpret_cast<const float4*>(&xs[it][lrow * 8]);
+      const float4 xb = *reinterpret_cast<const float4*>(&xs[it][lrow * 8 + 4]);
+      const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+      float4 acc = bias;
 #pragma unroll
-    for (int f = 0; f < 8; ++f) xv[j][f] = x[f < F ? f : 0];
-  }
-#pragma unroll
-  for (int j = 0; j < RPT; ++j) {
-    float4 acc = bias;
-#pragma unroll
-    for (int f = 0; f < 8; ++f) { acc.x += xv[j][f] * w[f].x; acc.y += xv[j][f] * w[f].y; acc.z += xv[j][f] * w[f].z; acc.w += xv[j][f] * w[f].w; }
-    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    const long row = row0 + 8 * j;
-    if (row < R) *reinterpret_cast<float4*>(Y + row * ldy + c4) = acc;
+      for (int f = 0; f < 8; ++f) { acc.x += xv[f] * w[f].x; acc.y += xv[f] * w[f].y; acc.z += xv[f] * w[f].z; acc.w += xv[f] * w[f].w; }
+      if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+      const long row = base + lrow;
+      if (row < R) *reinterpret_cast<float4*>(Y + row * ldy + c4) = acc;
+    }
   }
 }
 
@@ -397,8 +406,9 @@ extern "C" int magpo_small_linear(const float* X, int ldx, int F, const float* W
                                   long R, int relu, hipStream_t st) {
   if (N & 3) { set_error("magpo_small_linear: N must be a multiple of 4"); return MAGPO_EINVAL; }
   if (N == 128 && F <= 8 && R >= 4096) {
-    constexpr int RPT = 4;
-    hipLaunchKernelGGL(k_small_linear128<RPT>, dim3((unsigned)((R + 8 * RPT - 1) / (8 * RPT))), dim3(256), 0, st, X, ldx, F, W, b, Y, ldy, R, relu);
+    const long nb = (R + 31) / 32;
+    static const unsigned cap = resident_grid(k_small_linear128, 256, 1L << 30);
+    hipLaunchKernelGGL(k_small_linear128, dim3(nb < (long)cap ? (unsigned)nb : cap), dim3(256), 0, st, X, ldx, F, W, b, Y, ldy, R, relu);
     return check_launch("magpo_small_linear");
   }
   long n = R * (N / 4);

@@ -21,9 +21,9 @@ __global__ void k_sumsq_partial(const float* __restrict__ g, long n, float gscal
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
 __global__ void k_sumsq_final(const double* __restrict__ part, int nb, float* __restrict__ gnorm) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0;
-  for (int i = 0; i < nb; ++i) s += part[i];
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const double s = wave_sum_strided(part, nb, 1, 0);
+  if (threadIdx.x != 0) return;
   gnorm[0] = (float)sqrt(s);
 }
 // g <- g * gscale (mean over groups); clip; adam.  bc1 = 1 - b1^count, bc2 = 1 - b2^count (fp32, from host).

@@ -142,9 +142,9 @@ __global__ void k_moments_partial(const float* __restrict__ x, long n, double* _
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0][0]; part[2 * blockIdx.x + 1] = sh[1][0]; }
 }
 __global__ void k_moments_final(const double* __restrict__ part, int nb, long n, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0, s2 = 0.0;
-  for (int i = 0; i < nb; ++i) { s += part[2 * i]; s2 += part[2 * i + 1]; }
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const double s = wave_sum_strided(part, nb, 2, 0), s2 = wave_sum_strided(part, nb, 2, 1);
+  if (threadIdx.x != 0) return;
   const double mean = s / (double)n;
   double var = s2 / (double)n - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -289,10 +289,11 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
 // out: [total, value_loss, actor_loss, guider_loss, kl_loss, entropy, actor_kl, total_guider, total_actor]
 __global__ void k_loss_final(const double* __restrict__ part, int nb, float inv_R, float ent_coef, float vf_coef, float alpha,
                              float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < nb; ++i)
-    for (int q = 0; q < 6; ++q) s[q] += part[8 * i + q];
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  double s[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) s[q] = wave_sum_strided(part, nb, 8, q);
+  if (threadIdx.x != 0) return;
   const float pg = (float)(s[0] * inv_R), klm = (float)(s[1] * inv_R), ent = (float)(s[2] * inv_R);
   const float vl = (float)(s[3] * inv_R), apl = (float)(s[4] * inv_R), kl = (float)(s[5] * inv_R);
   const float tg = pg + klm - ent_coef * ent + vf_coef * vl;

@@ -85,29 +85,57 @@ struct EmbedArgs {
   long R;
 };
 
+// Small inputs of one embedding row, fetched one grid-stride iteration ahead of their use.
+struct EmbedIn { float of[8]; int p; int idx; };
+
+__device__ __forceinline__ EmbedIn embed_fetch(const EmbedArgs& a, int mode, long row) {
+  EmbedIn in;
+  row = row < a.R ? row : a.R - 1;
+  in.p = a.pos[row * a.pos_stride];
+  in.idx = 0;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) in.of[f] = 0.f;
+  if (mode == 0) {
+    if (a.F <= 8) {
+      const float* o = a.obs + row * a.ldo;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) in.of[f] = o[f < a.F ? f : 0];
+    }
+  } else {
+    in.idx = a.idx[row * a.idx_stride];
+  }
+  return in;
+}
+
 __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
   const float4 sln = ld4(a.s_ln + c4);
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < a.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  const long stride = (long)gridDim.x * ROWS_PER_BLOCK;
+  const long lrow = wave * 4 + (lane >> 4);
+  long base = (long)blockIdx.x * ROWS_PER_BLOCK;
+  if (base >= a.R) return;
+  EmbedIn nx = embed_fetch(a, mode, base + lrow);
+  for (; base < a.R; base += stride) {
+    const long row = base + lrow;
     const bool ok = row < a.R;
+    const EmbedIn in = nx;
+    if (base + stride < a.R) nx = embed_fetch(a, mode, base + stride + lrow);
     float4 z = f4zero();
-    if (ok) {
-      if (mode == 0 && a.F <= 8) {   // small observation: every load of the row issued together (no dependent run-time loop)
-        const float* o = a.obs + row * a.ldo;
-        float of[8], ms = 0.f;
+    if (mode == 0 && a.F <= 8) {   // small observation: every load of the row issued together (no dependent run-time loop)
+      float ms = 0.f;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) { of[f] = f < a.F ? o[f] : 0.f; ms += of[f] * of[f]; }
-        const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
+      for (int f = 0; f < 8; ++f) ms += f < a.F ? in.of[f] * in.of[f] : 0.f;
+      const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          if (f < a.F) {
-            const float on = of[f] * rstd * a.s_obs[f];
-            const float4 w = ld4(a.W + f * 64 + c4);
-            z.x += on * w.x; z.y += on * w.y; z.z += on * w.z; z.w += on * w.w;
-          }
+      for (int f = 0; f < 8; ++f) {
+        if (f < a.F) {
+          const float on = in.of[f] * rstd * a.s_obs[f];
+          const float4 w = ld4(a.W + f * 64 + c4);
+          z.x += on * w.x; z.y += on * w.y; z.z += on * w.z; z.w += on * w.w;
         }
-      } else if (mode == 0) {
+      }
+    } else if (mode == 0) {
+      if (ok) {
         const float* o = a.obs + row * a.ldo;
         float ms = 0.f;
         for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
@@ -117,19 +145,105 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
           const float4 w = ld4(a.W + f * 64 + c4);
           z.x += of * w.x; z.y += of * w.y; z.z += of * w.z; z.w += of * w.w;
         }
-      } else {
-        z = ld4(a.W + (long)a.idx[row * a.idx_stride] * 64 + c4);
       }
+    } else {
+      z = ld4(a.W + (long)in.idx * 64 + c4);
     }
     float4 x0 = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
     RmsFwd n = rms_fwd(x0, sln);
+    int p = in.p;
+    p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
+    const float4 pe = ld4(a.pe + (long)p * 64 + c4);
     if (ok) {
-      int p = a.pos[row * a.pos_stride];
-      p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
-      const float4 pe = ld4(a.pe + (long)p * 64 + c4);
       if (a.z) st4(a.z + row * a.ldz + c4, z);
       st4(a.xn + row * a.ldxn + c4, n.y);
       st4(a.kin + row * a.ldkin + c4, f4add(n.y, pe));
+    }
+  }
+}
+
+// F <= 8 (mode 0) / action rows (mode 1): 64 rows per block iteration.  The per-row inputs (observation, position,
+// action index) arrive as one coalesced tile through double-buffered LDS, fetched one iteration ahead, and the small
+// weight stays in registers, so an output row costs one table load and two stores instead of ~19 memory requests.
+constexpr int EMB_ROWS = 64;
+template <int MODE>
+__global__ __launch_bounds__(256) void k_embed_fwd_tile(EmbedArgs a) {
+  __shared__ float xs[2][EMB_ROWS * 8];
+  __shared__ int ps[2][EMB_ROWS];
+  __shared__ int is[2][EMB_ROWS];
+  const int t = threadIdx.x, c4 = 4 * (t & 15), slot = t >> 4;
+  const float4 sln = ld4(a.s_ln + c4);
+  float4 w[8];
+  float so[8];
+  if (MODE == 0) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int fc = f < a.F ? f : 0;
+      w[f] = ld4(a.W + fc * 64 + c4);
+      so[f] = a.s_obs[fc];
+    }
+  }
+  const long stride = (long)gridDim.x * EMB_ROWS;
+  long base = (long)blockIdx.x * EMB_ROWS;
+  if (base >= a.R) return;
+  float x0 = 0.f, x1 = 0.f;
+  int pn = 0;
+  auto fetch = [&](long b) {
+    if (MODE == 0) {
+      long r0 = b + (t >> 3), r1 = r0 + 32;
+      r0 = r0 < a.R ? r0 : a.R - 1;
+      r1 = r1 < a.R ? r1 : a.R - 1;
+      const int f = (t & 7) < a.F ? (t & 7) : 0;
+      x0 = a.obs[r0 * a.ldo + f];
+      x1 = a.obs[r1 * a.ldo + f];
+    }
+    if (t < 2 * EMB_ROWS) {
+      long r = b + (t & (EMB_ROWS - 1));
+      r = r < a.R ? r : a.R - 1;
+      if (t < EMB_ROWS) pn = a.pos[r * a.pos_stride];
+      else if (MODE == 1) pn = a.idx[r * a.idx_stride];
+    }
+  };
+  fetch(base);
+  for (int it = 0; base < a.R; base += stride, it ^= 1) {
+    if (MODE == 0) { xs[it][t] = x0; xs[it][t + 256] = x1; }
+    if (t < EMB_ROWS) ps[it][t] = pn;
+    else if (MODE == 1 && t < 2 * EMB_ROWS) is[it][t - EMB_ROWS] = pn;
+    __syncthreads();
+    if (base + stride < a.R) fetch(base + stride);
+#pragma unroll
+    for (int j = 0; j < EMB_ROWS / 16; ++j) {
+      const int lrow = slot + 16 * j;
+      const long row = base + lrow;
+      float4 z = f4zero();
+      if (MODE == 0) {
+        const float4 xa = *reinterpret_cast<const float4*>(&xs[it][lrow * 8]);
+        const float4 xb = *reinterpret_cast<const float4*>(&xs[it][lrow * 8 + 4]);
+        const float of[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        float ms = 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) ms += f < a.F ? of[f] * of[f] : 0.f;
+        const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          if (f < a.F) {
+            const float on = of[f] * rstd * so[f];
+            z.x += on * w[f].x; z.y += on * w[f].y; z.z += on * w[f].z; z.w += on * w[f].w;
+          }
+        }
+      } else {
+        z = ld4(a.W + (long)is[it][lrow] * 64 + c4);
+      }
+      const float4 g0 = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
+      const RmsFwd n = rms_fwd(g0, sln);
+      int p = ps[it][lrow];
+      p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
+      const float4 pe = ld4(a.pe + (long)p * 64 + c4);
+      if (row < a.R) {
+        if (a.z) st4(a.z + row * a.ldz + c4, z);
+        st4(a.xn + row * a.ldxn + c4, n.y);
+        st4(a.kin + row * a.ldkin + c4, f4add(n.y, pe));
+      }
     }
   }
 }
@@ -550,6 +664,15 @@ extern "C" int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const
                                long R, hipStream_t st) {
   if (mode == 0 && F > 1024) { set_error("magpo_embed_fwd: F too large"); return MAGPO_EINVAL; }
   EmbedArgs a{obs, ldo, F, s_obs, W, idx, idx_stride, s_ln, pe, pos, pos_stride, npos, z, xn, kin, ldz, ldxn, ldkin, R};
+  if (mode == 1 || F <= 8) {
+    const long nb = (R + EMB_ROWS - 1) / EMB_ROWS;
+    static const unsigned cap0 = resident_grid(k_embed_fwd_tile<0>, 256, 1L << 30), cap1 = resident_grid(k_embed_fwd_tile<1>, 256, 1L << 30);
+    const unsigned cap = mode == 0 ? cap0 : cap1;
+    const dim3 grid(nb < (long)cap ? (unsigned)nb : cap);
+    if (mode == 0) hipLaunchKernelGGL(k_embed_fwd_tile<0>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_embed_fwd_tile<1>, grid, dim3(256), 0, st, a);
+    return check_launch("magpo_embed_fwd");
+  }
   hipLaunchKernelGGL(k_embed_fwd, dim3(row_grid(R)), dim3(256), 0, st, a, mode);
   return check_launch("magpo_embed_fwd");
 }

@@ -1,5 +1,5 @@
 """Per-kernel micro-benchmarks at the bench shapes (R = 8192 seqs x 128 steps x 4 agents rows), HIP-event timed.
-usage: python scripts/kbench.py [wgrad] [linear] [ret] [gru]"""
+usage: python scripts/kbench.py [wgrad] [linear] [ret] [gru] [rows]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -55,3 +55,22 @@ if "gru" in which:
     dhs = torch.randn(R, H, device=dev, generator=g) * 0.1
     dxi = torch.empty(R, 3 * H, device=dev); dhh = torch.empty(R, 3 * H, device=dev); slab = torch.empty((nseq * A + 63) // 64, H, device=dev)
     timeit("gru_scan_bwd", lambda: L.call("magpo_gru_scan_bwd", gates, hprev, reset, dhs, Wh, dxi, dhh, slab, nseq, T, A, st), 2.0 * R * H * 3 * H, 0)
+if "rows" in which:
+    F, K = 5, 20
+    obs = torch.randn(R, F, device=dev, generator=g)
+    W = torch.randn(F, 128, device=dev, generator=g); b = torch.zeros(128, device=dev); Y = torch.empty(R, 128, device=dev)
+    timeit("small_linear 5->128", lambda: L.call("magpo_small_linear", obs, F, F, W, b, Y, 128, 128, R, 1, st), 0, 4.0 * R * (F + 128))
+    pe = torch.empty(101, 64, device=dev); L.call("magpo_pe_table", pe, 101, 64, st)
+    sobs = torch.ones(F, device=dev); Wo = torch.randn(F, 64, device=dev, generator=g); sln = torch.ones(64, device=dev)
+    pos = torch.randint(0, 100, (nseq * T,), device=dev, generator=g, dtype=torch.int32).repeat_interleave(A)
+    idx = torch.randint(0, K + 1, (R,), device=dev, generator=g, dtype=torch.int32); Wa = torch.randn(K + 1, 64, device=dev, generator=g)
+    xn = torch.empty(R, 64, device=dev); kin = torch.empty(R, 64, device=dev)
+    timeit("embed_fwd obs", lambda: L.call("magpo_embed_fwd", 0, obs, F, F, sobs, Wo, None, 0, sln, pe, pos, 1, 101, None, 64, xn, 64, kin, 64, R, st),
+           0, 4.0 * R * (F + 1 + 128))
+    timeit("embed_fwd act", lambda: L.call("magpo_embed_fwd", 1, None, 0, 0, None, Wa, idx, 1, sln, pe, pos, 1, 101, None, 64, xn, 64, kin, 64, R, st),
+           0, 4.0 * R * (2 + 128))
+    ws = torch.empty(8 * 1024, device=dev, dtype=torch.float64); out = torch.empty(2, device=dev); adv = torch.randn(R, device=dev, generator=g)
+    timeit("adv_moments", lambda: L.call("magpo_adv_moments", adv, R, ws, out, st), 0, 4.0 * R)
+    timeit("torch fill (write-only ref)", lambda: Y.fill_(1.0), 0, 4.0 * R * 128)
+    Y2 = torch.empty_like(Y)
+    timeit("torch copy (read+write ref)", lambda: Y2.copy_(Y), 0, 8.0 * R * 128)

@@ -145,9 +145,9 @@ def test_gru_carry_equals_stepwise_scan(L, stream):
     assert torch.equal(h_last, ref)
 
 
-@pytest.mark.parametrize("F,R,relu", [(5, 100, 1), (5, 5003, 1), (8, 4096, 0), (3, 4133, 1)])
+@pytest.mark.parametrize("F,R,relu", [(5, 100, 1), (5, 5003, 1), (8, 4096, 0), (3, 4096 * 32 * 2 + 4133, 1)])
 def test_small_linear(L, stream, F, R, relu):
-    """Actor pre-torso Dense(F -> 128) (+ReLU): the one-row kernel (small R) and the 4-rows-per-thread kernel (R >= 4096)."""
+    """Actor pre-torso Dense(F -> 128) (+ReLU): the one-row kernel (small R) and the tiled grid-stride kernel (R >= 4096)."""
     g = torch.Generator().manual_seed(F * 1000 + R)
     X = torch.randn(R, F, generator=g)
     W = torch.randn(F, 128, generator=g) * 0.4
@@ -215,6 +215,27 @@ def test_embed_fwd_bwd(L, stream, mode):
     close(dW, Wd.grad, 1e-4, 1e-5, "dW")
     if mode == 0:
         close(_slabsum(slab_sobs)[:F], so.grad, 1e-4, 1e-5, "ds_obs")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_embed_fwd_grid_stride(L, stream, mode):
+    """More rows than one pass of the grid: the prefetched, double-buffered input tiles of the embedding kernel."""
+    g = torch.Generator().manual_seed(31 + mode)
+    R, F, K = 2048 * 64 * 2 + 777, 5, 20
+    pe = _pe_table(L, stream)
+    pos = torch.randint(0, 101, (R,), generator=g, dtype=torch.int32)
+    s_ln = 1 + 0.1 * torch.randn(64, generator=g)
+    obs = torch.randint(0, 60, (R, F), generator=g).float()
+    s_obs = 1 + 0.1 * torch.randn(F, generator=g)
+    W = torch.randn(F if mode == 0 else K + 1, 64, generator=g) * 0.5
+    idx = torch.randint(0, K + 1, (R,), generator=g, dtype=torch.int32)
+    xn = torch.empty(R + 1, 64, device=DEV).fill_(-7.0); kin = torch.empty(R + 1, 64, device=DEV).fill_(-7.0)
+    L.call("magpo_embed_fwd", mode, dev(obs), F, F, dev(s_obs), dev(W), dev(idx), 1, dev(s_ln), pe, dev(pos), 1, 101,
+           None, 64, xn, 64, kin, 64, R, stream)
+    zr = onets.rmsnorm(obs.double(), s_obs.double()) @ W.double() if mode == 0 else W.double()[idx.long()]
+    xnr = onets.rmsnorm(onets.gelu(zr), s_ln.double())
+    close(xn[:R], xnr, what="xn"); close(kin[:R], xnr + pe.cpu().double()[pos.long()], what="kin")
+    assert (xn[R] == -7.0).all() and (kin[R] == -7.0).all()
 
 
 def test_retpost_resnorm_headmid(L, stream):
