@@ -65,8 +65,10 @@ __device__ __forceinline__ float sum16(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // hardware exp2 / rcp based variants for the GRU gates (abs. error ~1e-7, far inside the fp32 parity tolerance)
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// v_rcp_f32 (1 ulp) directly: `__frcp_rn` / `1.0f / x` compile to the ~10-instruction IEEE division sequence
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_rcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ float gelu_tanh(float x) {
   // jax.nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
   const float c = 0.7978845608028654f;

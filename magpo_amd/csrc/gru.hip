@@ -32,6 +32,17 @@ struct GruArgs {
   float* h_last;          // [NR][H] state after the last step (nullable)
 };
 
+#ifdef MAGPO_GRU_PROF
+__device__ unsigned long long g_gru_prof[8];
+#define GP_DECL() unsigned long long gp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long gp_last = clock64();
+#define GP(k) do { unsigned long long t_ = clock64(); gp_acc[k] += t_ - gp_last; gp_last = t_; } while (0)
+#define GP_FLUSH() do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_gru_prof[k_], gp_acc[k_]); } } while (0)
+#else
+#define GP_DECL()
+#define GP(k)
+#define GP_FLUSH()
+#endif
+
 __device__ __forceinline__ long tok_row(int rho, int t, int T, int A) {
   int seq = rho / A, ag = rho - seq * A;
   return ((long)seq * T + t) * A + ag;
@@ -82,11 +93,13 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
   if (tid < 64) rbase[tid] = TM ? (long)min(rho0 + tid, a.NR - 1) : tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
   const long t_stride = TM ? a.NR : a.A;   // rows between consecutive steps of one recurrent row
   __syncthreads();
+  GP_DECL();
   for (int t = 0; t < T; ++t) {
     const float* hold = hbuf[t & 1];
     float* hnew = hbuf[(t + 1) & 1];
 #pragma unroll
     for (int wr = 0; wr < 2; ++wr) {
+      GP(6);
       // issue this job's xi loads first: they are in flight under the 192 MFMAs below
       float xr[16], xz[16], xn[16];
       long rowi[16];
@@ -98,6 +111,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         const float* x = a.xi + row * G3;
         xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
       }
+      GP(0 + 3 * wr);
       f32x16 ar, az, an;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { ar[i] = 0.f; az[i] = 0.f; an[i] = 0.f; }
@@ -118,6 +132,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         az = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[1][u].w, az, 0, 0, 0);
         an = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[2][u].w, an, 0, 0, 0);
       }
+      GP(1 + 3 * wr);
       const bool more = t + 1 < T;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -141,9 +156,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         if (more && rflag[rl * T + t + 1]) hn_new = 0.f;
         hnew[rl * HP + col] = hn_new;
       }
+      GP(2 + 3 * wr);
     }
     __syncthreads();
+    GP(7);
   }
+  GP_FLUSH();
 }
 
 struct GruBwdArgs {
@@ -415,3 +433,11 @@ extern "C" int magpo_small_linear(const float* X, int ldx, int F, const float* W
   hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, ldx, F, W, b, Y, ldy, N, R, relu);
   return check_launch("magpo_small_linear");
 }
+
+#ifdef MAGPO_GRU_PROF
+extern "C" int magpo_debug_gru_prof(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_gru_prof), sizeof(unsigned long long) * 8) != hipSuccess) return MAGPO_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_gru_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
+  return MAGPO_OK;
+}
+#endif
