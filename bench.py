@@ -73,7 +73,7 @@ class KernelTimer:
             if T == 1:
                 return None
             rows = nseq * T * A
-            return "k_gru_scan_fwd<true,false>", 4.0 * rows * (384 + 128 + 512 + 128), 2.0 * rows * 128 * 384
+            return "k_gru_scan_fwd<true,0>", 4.0 * rows * (384 + 128 + 512 + 128), 2.0 * rows * 128 * 384
         if name == "magpo_gru_scan_bwd":
             nseq, T, A = a[8], a[9], a[10]
             rows = nseq * T * A

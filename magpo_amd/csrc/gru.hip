@@ -53,10 +53,12 @@ __device__ __forceinline__ long tok_row(int rho, int t, int T, int A) {
 // FULL = every one of the block's 64 rows is valid (all but the last block): loads and stores are then unconditional
 // straight-line code; a predicated access is an exec-masked block with its own wait and a per-element global flag load
 // sits on the step's critical path, so the reset flags of the block's rows are staged in LDS once.
-// TM = time-major trajectory (rollout carry: rows (t, env, agent), only the last state is written); compile-time so that the
-// training scan keeps its constant row stride and unconditional stores
-template <bool FULL, bool TM>
+// MODE (compile-time, so that the training scan is branch-free with a constant row stride): 0 = training scan, h / gates /
+// h_prev of every step saved; 1 = time-major trajectory (rollout carry: rows (t, env, agent), only the last state is
+// written); 2 = any of the save buffers may be NULL (acting step)
+template <bool FULL, int MODE>
 __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) {
+  constexpr bool TM = MODE == 1;
   __shared__ __align__(16) float hbuf[2][64 * HP];
   extern __shared__ unsigned char rflag[];   // [64][T] reset-before-step flags of the block's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
@@ -111,6 +113,16 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         const float* x = a.xi + row * G3;
         xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
       }
+      // carry values and next-step reset flags of the job's rows: LDS round trips hidden under the MFMAs as well
+      float hpv[16];
+      unsigned char rf[16];
+      const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        hpv[i] = hold[rl * HP + col];
+        rf[i] = rflag[rl * T + tn];
+      }
       GP(0 + 3 * wr);
       f32x16 ar, az, an;
 #pragma unroll
@@ -142,19 +154,26 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         const float r = fast_sigmoid(xr[i] + ar[i]);
         const float z = fast_sigmoid(xz[i] + az[i]);
         const float n = fast_tanh(xn[i] + r * hb);
-        const float hp = hold[rl * HP + col];
+        const float hp = hpv[i];
         float hn_new = (1.0f - z) * n + z * hp;
         if (FULL || rho0 + rl < a.NR) {
-          if (!TM) a.hs[row * H + col] = hn_new;
-          if (TM && !more) a.h_last[(long)(rho0 + rl) * H + col] = hn_new;
-          if (a.gates) {
+          if (MODE == 0) {
+            a.hs[row * H + col] = hn_new;
             float* g = a.gates + row * (4 * H);
             g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
+            a.hprev[row * H + col] = hp;
+          } else if (MODE == 1) {
+            if (!more) a.h_last[(long)(rho0 + rl) * H + col] = hn_new;
+          } else {
+            if (a.hs) a.hs[row * H + col] = hn_new;
+            if (a.gates) {
+              float* g = a.gates + row * (4 * H);
+              g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
+            }
+            if (a.hprev) a.hprev[row * H + col] = hp;
           }
-          if (a.hprev) a.hprev[row * H + col] = hp;
         }
-        if (more && rflag[rl * T + t + 1]) hn_new = 0.f;
-        hnew[rl * HP + col] = hn_new;
+        hnew[rl * HP + col] = (more & (rf[i] != 0)) ? 0.f : hn_new;
       }
       GP(2 + 3 * wr);
     }
@@ -380,8 +399,13 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
   const size_t lds = (size_t)64 * T;   // reset flags of the block's rows
   if (lds > 24 * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
-  if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, false>), dim3(nfull), dim3(256), lds, st, a, 0);
-  if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, false>), dim3(1), dim3(256), lds, st, a, nfull);
+  if (hs && gates && hprev) {
+    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 0>), dim3(nfull), dim3(256), lds, st, a, 0);
+    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 0>), dim3(1), dim3(256), lds, st, a, nfull);
+  } else {
+    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 2>), dim3(nfull), dim3(256), lds, st, a, 0);
+    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 2>), dim3(1), dim3(256), lds, st, a, nfull);
+  }
   return check_launch("magpo_gru_scan_fwd");
 }
 
@@ -395,8 +419,8 @@ extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b
   const size_t lds = (size_t)64 * T;
   if (lds > 24 * 1024) { set_error("magpo_gru_carry: T too large for the LDS flag table"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
-  if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, true>), dim3(nfull), dim3(256), lds, st, a, 0);
-  if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, true>), dim3(1), dim3(256), lds, st, a, nfull);
+  if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 1>), dim3(nfull), dim3(256), lds, st, a, 0);
+  if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 1>), dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_carry");
 }
 
