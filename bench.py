@@ -54,7 +54,11 @@ class KernelTimer:
             R, KIN, NOUT = a[4], a[5], a[7]
             if R < self.min_rows:
                 return None
-            key = "k_wgrad_full<4,3>" if (KIN == 128 and NOUT == 384 and R >= 64 * 256) else ("k_wgrad<2>" if NOUT >= 128 else "k_wgrad<1>")
+            full = R >= 64 * 256 and ((KIN, NOUT) == (128, 384) or (R % 64 == 0 and (KIN, NOUT) in ((128, 128), (64, 256))))
+            if full:
+                key = f"k_wgrad_full{'_x' if R % 64 == 0 else ''}<{KIN // 32},{NOUT // 128}>"
+            else:
+                key = "k_wgrad<2>" if NOUT >= 128 else "k_wgrad<1>"
             return key, 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
         if name in ("magpo_retention_chunk_fwd", "magpo_retention_chunk_bwd"):
             fwd = name.endswith("fwd")

@@ -826,6 +826,118 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_full(const float* __restrict__
   }
 }
 
+// k_wgrad_full for R % 64 == 0 (every tile full: no clamps, no zero-fill selects).  Differences that matter per tile:
+//  * tile loads are `uniform base (SGPR) + per-thread 32-bit offset`: the generic form spent ~10 VALU instructions (64-bit
+//    multiplies, selects) per load on addresses, and f32 MFMA time and VALU time add up;
+//  * the LDS operand reads of k-step s+1 are issued before the MFMAs of step s (two register sets): the compiler's own order
+//    was read -> wait -> MFMA, exposing one LDS latency per step;
+//  * the bias column sums are accumulated from the registers at stash time (each thread owns fixed columns of dY), not by
+//    re-reading the dY tile from LDS.
+template <int KT, int NT>
+__global__ __launch_bounds__(256, 1) void k_wgrad_full_x(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
+                                                         int R, float* __restrict__ slab, float* __restrict__ bias_slab) {
+  constexpr int KIN = 32 * KT, NOUT = 128 * NT, LDX = KIN + LDP, LDY = NOUT + LDP;
+  constexpr int TX = KIN / 4, RPX = 256 / TX, NX = 64 / RPX;   // X: TX threads per row, RPX rows per pass, NX passes
+  constexpr int NY = 8 * NT;                                   // dY: pass (rr, j) = rows 8 rr + (tid >> 5), float4 column 32 j + (tid & 31)
+  extern __shared__ __align__(16) float wf_smem[];
+  float* xs = wf_smem;              // [64][LDX]
+  float* ys = xs + 64 * LDX;        // [64][LDY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int g = blockIdx.x, G = gridDim.x;
+  const int ntiles = R >> 6;
+  f32x16 acc[KT][NT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[kt][nt][i] = 0.f;
+  float4 bsum[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned xoff = (unsigned)(tid / TX) * (unsigned)ldx + 4u * (unsigned)(tid % TX);
+  const unsigned yoff = (unsigned)(tid >> 5) * (unsigned)ldy + 4u * (unsigned)(tid & 31);
+  float* xsw = xs + (tid / TX) * LDX + 4 * (tid % TX);
+  float* ysw = ys + (tid >> 5) * LDY + 4 * (tid & 31);
+  float4 nxx[NX], nxy[NY];
+#define WFX_LOADX(LI, ROW0) nxx[LI] = *reinterpret_cast<const float4*>(X + ((ROW0) + (LI) * RPX) * (long)ldx + xoff)
+#define WFX_LOADY(LI, ROW0) nxy[LI] = *reinterpret_cast<const float4*>(dY + ((ROW0) + 8 * ((LI) / NT)) * (long)ldy + 128 * ((LI) % NT) + yoff)
+  {
+    const long row0 = (long)min(g, ntiles - 1) * 64;
+#pragma unroll
+    for (int li = 0; li < NX; ++li) { WFX_LOADX(li, row0); }
+#pragma unroll
+    for (int li = 0; li < NY; ++li) { WFX_LOADY(li, row0); }
+  }
+  const float* xr = xs + (32 * h) * LDX + lr;
+  const float* yr = ys + (32 * h) * LDY + 32 * NT * wave + lr;
+  for (int tile = g; tile < ntiles; tile += G) {
+    const long row0n = (long)min(tile + G, ntiles - 1) * 64;
+    __syncthreads();          // MFMAs of the previous tile have finished reading LDS
+#pragma unroll
+    for (int li = 0; li < NX; ++li) {   // component-wise: a whole-float4 copy out of the array leaves it in scratch
+      const float4 v = nxx[li];
+      *reinterpret_cast<float4*>(xsw + li * RPX * LDX) = make_float4(v.x, v.y, v.z, v.w);
+    }
+#pragma unroll
+    for (int li = 0; li < NY; ++li) {
+      const float4 v = nxy[li];
+      *reinterpret_cast<float4*>(ysw + 8 * (li / NT) * LDY + 128 * (li % NT)) = v;
+      bsum[li % NT].x += v.x; bsum[li % NT].y += v.y; bsum[li % NT].z += v.z; bsum[li % NT].w += v.w;
+    }
+    __syncthreads();
+    float av[2][KT], bv[2][NT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) av[0][kt] = xr[32 * kt];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[0][nt] = yr[32 * nt];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      if (s + 1 < 32) {       // operands of the next k-step: their LDS latency passes under this step's MFMAs
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) av[(s + 1) & 1][kt] = xr[(s + 1) * LDX + 32 * kt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[(s + 1) & 1][nt] = yr[(s + 1) * LDY + 32 * nt];
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][kt], bv[s & 1][nt], acc[kt][nt], 0, 0, 0);
+      // the next tile's loads, spread over the 32 MFMA steps
+#pragma unroll
+      for (int li = 0; li < NY; ++li)
+        if (li * 32 / (NX + NY) == s) { WFX_LOADY(li, row0n); }
+#pragma unroll
+      for (int li = 0; li < NX; ++li)
+        if ((NY + li) * 32 / (NX + NY) == s) { WFX_LOADX(li, row0n); }
+    }
+  }
+#undef WFX_LOADX
+#undef WFX_LOADY
+  float* out = slab + (long)g * KIN * NOUT;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = 32 * NT * wave + 32 * nt + lr;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) out[(long)(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h) * NOUT + n] = acc[kt][nt][i];
+    }
+  if (bias_slab) {   // fold the 8 row groups' partial column sums through LDS (the tiles are dead now)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(&wf_smem[(tid >> 5) * NOUT + 128 * j + 4 * (tid & 31)]) = bsum[j];
+    __syncthreads();
+    for (int col = tid; col < NOUT; col += 256) {
+      float sb = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sb += wf_smem[q * NOUT + col];
+      bias_slab[(long)g * NOUT + col] = sb;
+    }
+  }
+}
+
 }  // namespace magpo
 
 using namespace magpo;
@@ -954,17 +1066,25 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   float* slab = workspace;
   float* bslab = db ? workspace + (long)G * KIN * NOUT : nullptr;
   static const bool use_full = []() { const char* e = getenv("MAGPO_WGRAD_FULL"); return !e || atoi(e) != 0; }();
-  if (use_full && KIN == 128 && NOUT == 384 && R >= 64 * 256) {
-    // whole-matrix form: one workgroup per CU and slab, every row read once.  Measured: 128x384 4.44 -> 4.21 ms; the narrower
-    // shapes (64x256, 128x128) lose more from one wave per SIMD than they gain from the traffic, and stay on k_wgrad
-    if (G > 256) G = 256;
+  static const bool use_x = []() { const char* e = getenv("MAGPO_WGRAD_FULL_X"); return !e || atoi(e) != 0; }();
+  // whole-matrix form: one workgroup per slab accumulates the full KIN x NOUT block, every row read once.  128x384 always
+  // (k_wgrad_full, or k_wgrad_full_x when every tile is full); with full tiles also 128x128 (two workgroups per CU: 1.53 ->
+  // 1.30 ms) and 64x256 (1.84 -> 1.76 ms).  Other shapes stay on the split kernel k_wgrad.
+  const bool exact = R % 64 == 0 && use_x;
+  const bool full_shape = (KIN == 128 && NOUT == 384) || (exact && ((KIN == 128 && NOUT == 128) || (KIN == 64 && NOUT == 256)));
+  if (use_full && full_shape && R >= 64 * 256) {
+    const int gcap = (KIN == 128 && NOUT == 128) ? 512 : 256;
+    if (G > gcap) G = gcap;
     float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
     const size_t lds = (size_t)64 * ((KIN + LDP) + (NOUT + LDP)) * sizeof(float);
 #define LAUNCH_FULL(KT_, NT_)                                                                                                 \
     {                                                                                                                          \
       static bool attr = false;                                                                                                \
       if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full<KT_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
-      hipLaunchKernelGGL((k_wgrad_full<KT_, NT_>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);       \
+      static bool attrx = false;                                                                                               \
+      if (!attrx) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_x<KT_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attrx = true; } \
+      if (R % 64 == 0 && use_x) hipLaunchKernelGGL((k_wgrad_full_x<KT_, NT_>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl); \
+      else hipLaunchKernelGGL((k_wgrad_full<KT_, NT_>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);  \
     }
     if (KIN == 64 && NOUT == 128) LAUNCH_FULL(2, 1) else if (KIN == 64 && NOUT == 256) LAUNCH_FULL(2, 2) else if (KIN == 64) LAUNCH_FULL(2, 3)
     else if (NOUT == 128) LAUNCH_FULL(4, 1) else if (NOUT == 256) LAUNCH_FULL(4, 2) else LAUNCH_FULL(4, 3)

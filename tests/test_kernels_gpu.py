@@ -112,9 +112,11 @@ def test_linear_relu_mask_epilogue(L, stream):
     close(Y, (X.double() @ W.double()) * (M > 0), what="masked dX")
 
 
-def test_wgrad_whole_matrix(L, stream):
-    """k_wgrad_full (128 x 384, enough rows for one slab per CU) incl. the bias column sums and a ragged last tile."""
-    KIN, NOUT, R, G = 128, 384, 64 * 256 + 37, 300
+@pytest.mark.parametrize("KIN,NOUT,R,G", [(128, 384, 64 * 256 + 37, 200), (128, 384, 64 * 300, 200), (128, 128, 64 * 600, 512),
+                                          (64, 256, 64 * 300, 256)])
+def test_wgrad_whole_matrix(L, stream, KIN, NOUT, R, G):
+    """Whole-matrix weight gradient (enough rows for one slab per CU) incl. the bias column sums: k_wgrad_full with a ragged
+    last tile, k_wgrad_full_x when every tile is full (more tiles than slabs, so the prefetch pipeline runs)."""
     g = torch.Generator().manual_seed(12)
     X = torch.randn(R, KIN, generator=g) * 0.1
     dY = torch.randn(R, NOUT, generator=g) * 0.1
