@@ -425,11 +425,30 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
   const float bv = (bias && n < NOUT) ? bias[n] : 0.f;
   const int ntiles = (R + 31) >> 5;
   float4 pre[NLD];
+  // UB (the one-wave-per-SIMD widths): uniform tile base in scalar registers + per-thread 32-bit offsets computed once.  The
+  // generic form spends ~10 VALU instructions per load / store on 64-bit addresses and clamps, and f32 MFMA and VALU time
+  // add up; at KIN <= 128 the extra registers would cost a wave of occupancy, which matters more there.
+  constexpr bool UB = KIN >= 192;
+  unsigned xr[UB ? NLD : 1], xc[UB ? NLD : 1], so[UB ? 16 : 1];
+  if constexpr (UB) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) { xr[j] = (unsigned)((tid + NT * j) / (KIN / 4)); xc[j] = 4u * (unsigned)((tid + NT * j) % (KIN / 4)); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) so[i] = (unsigned)((i & 3) + 8 * (i >> 2) + 4 * h) * (unsigned)ldy + (unsigned)n;
+  }
 #define LL_FETCH(TILE)                                                                                   \
-  _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                      \
-    const int idx = tid + NT * j;                                                                        \
-    const long row = min((long)(TILE) * 32 + idx / (KIN / 4), (long)R - 1);                               \
-    pre[j] = *reinterpret_cast<const float4*>(X + row * (long)ldx + 4 * (idx % (KIN / 4)));              \
+  if constexpr (UB) {                                                                                    \
+    const long r0_ = (long)(TILE) * 32;                                                                  \
+    const float* xb_ = X + r0_ * ldx;                                                                    \
+    const unsigned rmax_ = (unsigned)min(31L, (long)R - 1 - r0_);   /* rows past the end re-read the last valid one */ \
+    _Pragma("unroll") for (int j = 0; j < NLD; ++j)                                                      \
+      pre[j] = *reinterpret_cast<const float4*>(xb_ + (min(xr[j], rmax_) * (unsigned)ldx + xc[j]));      \
+  } else {                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                    \
+      const int idx = tid + NT * j;                                                                      \
+      const long row = min((long)(TILE) * 32 + idx / (KIN / 4), (long)R - 1);                             \
+      pre[j] = *reinterpret_cast<const float4*>(X + row * (long)ldx + 4 * (idx % (KIN / 4)));            \
+    }                                                                                                    \
   }
 #define LL_STASH(BUF)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                      \
@@ -463,7 +482,23 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
     if (colon) {
       if ((act <= ACT_RELU || act == ACT_MASKPOS) && (long)tile * 32 + 32 <= R && c0 + 32 <= NOUT) {
         const long o0 = ((long)tile * 32 + 4 * h) * (long)ldy + n;
-        if (act == ACT_MASKPOS) {   // mask values first (16 independent loads), then the stores
+        if constexpr (UB) {
+          float* yt = Y + (long)tile * 32 * ldy;
+          if (act == ACT_MASKPOS) {
+            const float* mt = aux + (long)tile * 32 * ldy;
+            float mk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mk[i] = mt[so[i]];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yt[so[i]] = mk[i] > 0.f ? acc[i] + bv : 0.f;
+          } else if (act == ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yt[so[i]] = fmaxf(acc[i] + bv, 0.f);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yt[so[i]] = acc[i] + bv;
+          }
+        } else if (act == ACT_MASKPOS) {   // mask values first (16 independent loads), then the stores
           float mk[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) mk[i] = aux[o0 + (long)((i & 3) + 8 * (i >> 2)) * ldy];
