@@ -67,6 +67,12 @@ __device__ __forceinline__ void store_state(float* __restrict__ dst, const float
 struct TileRegs { float4 v[4]; };
 __device__ __forceinline__ void fetch_tile(TileRegs& t, const float* __restrict__ src, long ld, int nvalid, int w4) {
   // unconditional loads from clamped addresses (a predicated load is an exec-masked block); stash_tile zero-fills
+  if (nvalid == 64 && w4 == 16) {   // uniform: full tile = scalar row-block base + ONE per-thread 32-bit offset (no 64-bit address VALU)
+    const unsigned toff = (unsigned)(threadIdx.x >> 4) * (unsigned)ld + 4u * (threadIdx.x & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.v[j] = *reinterpret_cast<const float4*>(src + 16 * j * ld + toff);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = threadIdx.x + 256 * j;
@@ -134,6 +140,24 @@ __device__ __forceinline__ void mma_cc(f32x16& acc, const float* __restrict__ ta
     float a = ta[kk * TL + acol];
     if (scale) a *= scale[kk];
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, tb[kk * TL + bcol], acc, 0, 0, 0);
+  }
+}
+// The 16 accumulator rows of a lane to out[(r0 + row)][32 wc + lr].  Full tiles (uniform): scalar row base per element + one
+// per-lane 32-bit offset; otherwise always 16 stores per lane, invalid elements to the trash tile (no exec-masked blocks).
+// f32 MFMA time and VALU time add up, and the generic 64-bit address of a store costs ~8 VALU instructions.
+__device__ __forceinline__ void store_acc_rows(float* __restrict__ out, long r0, long ld, const float (&v)[16], bool full, int nvalid, int hs,
+                                               int wr, int wc, int lr, int h, float* __restrict__ trash) {
+  if (full) {
+    const unsigned loff = (unsigned)(32 * wr + 4 * h) * (unsigned)ld + (unsigned)(32 * wc + lr);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) (out + (r0 + (i & 3) + 8 * (i >> 2)) * ld)[loff] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ri = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+      float* dst = (ri < nvalid && 32 * wc + lr < hs) ? out + (r0 + ri) * ld + 32 * wc + lr : trash + ri * 64 + 32 * wc + lr;
+      *dst = v[i];
+    }
   }
 }
 __device__ __forceinline__ void acc_zero(f32x16& a) {
@@ -292,11 +316,11 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
       Frag pa = load_rowfrag(Qs, 32 * wr + lr, h);
       mma_rc(o, pa, Vs, 32 * wc + lr, h);      // P V
     }
+    {
+      float ov[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
-      const int ri = 32 * wr + acc_row(i, h);
-      float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.r + (r0 + ri) * a.ldr + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
-      *dst = o[i];
+      for (int i = 0; i < 16; ++i) ov[i] = o[i];
+      store_acc_rows(a.r, r0, a.ldr, ov, full, nvalid, a.hs, wr, wc, lr, h, g_ret_trash);
     }
     fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
     // state update  S <- gamma S + (eta K)^T V
@@ -425,12 +449,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       mma_rc(acc1, dpa, Ks, 32 * wc + lr, h);
       Frag sb = load_rowfrag(Ss, 32 * wc + lr, h);
       mma_rr(acc2, doa, sb);
+      float ov[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
-        const int ri = 32 * wr + acc_row(i, h);
-        float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.dq + (r0 + ri) * a.lddq + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
-        *dst = acc1[i] + lm.beta[i] * acc2[i];
-      }
+      for (int i = 0; i < 16; ++i) ov[i] = acc1[i] + lm.beta[i] * acc2[i];
+      store_acc_rows(a.dq, r0, a.lddq, ov, full, nvalid, a.hs, wr, wc, lr, h, g_ret_trash);
     }
     fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
     RP(2);
@@ -443,12 +465,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       Frag va = load_rowfrag(Vs, 32 * wr + lr, h);
       Frag gb = load_rowfrag(Gs, 32 * wc + lr, h);
       mma_rr(acc2, va, gb);
+      float ov[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
-        const int ri = 32 * wr + acc_row(i, h);
-        float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.dk + (r0 + ri) * a.lddk + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
-        *dst = acc1[i] + lm.eta[i] * acc2[i];
-      }
+      for (int i = 0; i < 16; ++i) ov[i] = acc1[i] + lm.eta[i] * acc2[i];
+      store_acc_rows(a.dk, r0, a.lddk, ov, full, nvalid, a.hs, wr, wc, lr, h, g_ret_trash);
     }
     fetch_tile(pd, a.dr + rn * a.lddr, a.lddr, nvn, w4);
     RP(3);
@@ -460,12 +480,10 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       mma_cc(acc1, Ps, 32 * wr + lr, Ds, 32 * wc + lr, h, nullptr);
       Frag ka = load_rowfrag(Ks, 32 * wr + lr, h);
       mma_rc(acc2, ka, Gs, 32 * wc + lr, h);
+      float ov[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {   // always 16 stores per lane (invalid elements go to the trash tile)
-        const int ri = 32 * wr + acc_row(i, h);
-        float* dst = (full || (ri < nvalid && 32 * wc + lr < a.hs)) ? a.dv + (r0 + ri) * a.lddv + 32 * wc + lr : g_ret_trash + ri * 64 + 32 * wc + lr;
-        *dst = acc1[i] + lm.eta[i] * acc2[i];
-      }
+      for (int i = 0; i < 16; ++i) ov[i] = acc1[i] + lm.eta[i] * acc2[i];
+      store_acc_rows(a.dv, r0, a.lddv, ov, full, nvalid, a.hs, wr, wc, lr, h, g_ret_trash);
     }
     fetch_state(ps, a.states + ((long)seq * nch + max(c - 1, 0)) * 4096);
     RP(4);
