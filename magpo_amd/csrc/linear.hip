@@ -429,6 +429,11 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
   // generic form spends ~10 VALU instructions per load / store on 64-bit addresses and clamps, and f32 MFMA and VALU time
   // add up; at KIN <= 128 the extra registers would cost a wave of occupancy, which matters more there.
   constexpr bool UB = KIN >= 192;
+  // LITE (KIN == 64, four waves per SIMD): the same idea without per-thread tables -- the row part of a store address is a
+  // scalar, loads are min(local row, last valid row) * ldx + column.  (At KIN == 128 either form costs a wave of occupancy
+  // and was slower: 128->384 3.92 -> 4.10 ms.)
+  constexpr bool LITE = KIN == 64;
+  const unsigned lt_r = (unsigned)(tid / (KIN / 4)), lt_c = 4u * (unsigned)(tid % (KIN / 4)), lt_o = (unsigned)(4 * h) * (unsigned)ldy + (unsigned)n;
   unsigned xr[UB ? NLD : 1], xc[UB ? NLD : 1], so[UB ? 16 : 1];
   if constexpr (UB) {
 #pragma unroll
@@ -437,7 +442,13 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
     for (int i = 0; i < 16; ++i) so[i] = (unsigned)((i & 3) + 8 * (i >> 2) + 4 * h) * (unsigned)ldy + (unsigned)n;
   }
 #define LL_FETCH(TILE)                                                                                   \
-  if constexpr (UB) {                                                                                    \
+  if constexpr (LITE) {                                                                                  \
+    const long r0_ = (long)(TILE) * 32;                                                                  \
+    const float* xb_ = X + r0_ * ldx;                                                                    \
+    const unsigned rmax_ = (unsigned)min(31L, (long)R - 1 - r0_);                                        \
+    _Pragma("unroll") for (int j = 0; j < NLD; ++j)                                                      \
+      pre[j] = *reinterpret_cast<const float4*>(xb_ + (min(lt_r + (unsigned)(j * (NT / (KIN / 4))), rmax_) * (unsigned)ldx + lt_c)); \
+  } else if constexpr (UB) {                                                                             \
     const long r0_ = (long)(TILE) * 32;                                                                  \
     const float* xb_ = X + r0_ * ldx;                                                                    \
     const unsigned rmax_ = (unsigned)min(31L, (long)R - 1 - r0_);   /* rows past the end re-read the last valid one */ \
@@ -482,7 +493,23 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
     if (colon) {
       if ((act <= ACT_RELU || act == ACT_MASKPOS) && (long)tile * 32 + 32 <= R && c0 + 32 <= NOUT) {
         const long o0 = ((long)tile * 32 + 4 * h) * (long)ldy + n;
-        if constexpr (UB) {
+        if constexpr (LITE) {
+#define LL_ROWP(P, I) ((P) + ((long)tile * 32 + ((I) & 3) + 8 * ((I) >> 2)) * ldy)
+          if (act == ACT_MASKPOS) {
+            float mk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mk[i] = LL_ROWP(aux, i)[lt_o];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) LL_ROWP(Y, i)[lt_o] = mk[i] > 0.f ? acc[i] + bv : 0.f;
+          } else if (act == ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) LL_ROWP(Y, i)[lt_o] = fmaxf(acc[i] + bv, 0.f);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) LL_ROWP(Y, i)[lt_o] = acc[i] + bv;
+          }
+#undef LL_ROWP
+        } else if constexpr (UB) {
           float* yt = Y + (long)tile * 32 * ldy;
           if (act == ACT_MASKPOS) {
             const float* mt = aux + (long)tile * 32 * ldy;
