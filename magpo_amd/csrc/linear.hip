@@ -457,8 +457,8 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
   } else {                                                                                               \
     _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                    \
       const int idx = tid + NT * j;                                                                      \
-      const long row = min((long)(TILE) * 32 + idx / (KIN / 4), (long)R - 1);                             \
-      pre[j] = *reinterpret_cast<const float4*>(X + row * (long)ldx + 4 * (idx % (KIN / 4)));            \
+      const int row = min((int)(TILE) * 32 + idx / (KIN / 4), R - 1);   /* 32-bit clamp, one 64-bit multiply-add */ \
+      pre[j] = *reinterpret_cast<const float4*>(X + (long)row * ldx + 4 * (idx % (KIN / 4)));            \
     }                                                                                                    \
   }
 #define LL_STASH(BUF)                                                                                    \
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
     const int ry = tid / YR, cy = 4 * (tid % YR);    // dY: float4 j is row ry + (256 / YR) j
     const float* xb = X + kb * 64 + cx;
     const float* yb = dY + c0 + cy;
-#define WG_LOADX(J, ROW0) nx[J] = *reinterpret_cast<const float4*>(xb + min((ROW0) + rx + 16 * (J), (long)R - 1) * (long)ldx)
-#define WG_LOADY(J, ROW0) nx[4 + (J)] = *reinterpret_cast<const float4*>(yb + min((ROW0) + ry + (256 / YR) * (J), (long)R - 1) * (long)ldy)
+#define WG_LOADX(J, ROW0) nx[J] = *reinterpret_cast<const float4*>(xb + (long)min((int)(ROW0) + rx + 16 * (J), R - 1) * ldx)
+#define WG_LOADY(J, ROW0) nx[4 + (J)] = *reinterpret_cast<const float4*>(yb + (long)min((int)(ROW0) + ry + (256 / YR) * (J), R - 1) * ldy)
     {
       const long row0 = (long)min(g, ntiles - 1) * 64;
 #pragma unroll
