@@ -55,8 +55,12 @@ class KernelTimer:
             if R < self.min_rows:
                 return None
             full = R >= 64 * 256 and ((KIN, NOUT) == (128, 384) or (R % 64 == 0 and (KIN, NOUT) in ((128, 128), (64, 256))))
-            if full:
-                key = f"k_wgrad_full{'_x' if R % 64 == 0 else ''}<{KIN // 32},{NOUT // 128}>"
+            if R >= 64 * 256 and R % 64 == 0 and (KIN, NOUT) == (64, 192):
+                key = "k_wgrad_full_192"
+            elif full and R % 64 == 0:
+                key = f"k_wgrad_full_x<{KIN // 32},{NOUT // 128},{0 if (KIN, NOUT) == (64, 256) else 4}>"
+            elif full:
+                key = f"k_wgrad_full<{KIN // 32},{NOUT // 128}>"
             else:
                 key = "k_wgrad<2>" if NOUT >= 128 else "k_wgrad<1>"
             return key, 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT

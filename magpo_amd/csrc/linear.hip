@@ -895,10 +895,11 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_full(const float* __restrict__
 //    was read -> wait -> MFMA, exposing one LDS latency per step;
 //  * the bias column sums are accumulated from the registers at stash time (each thread owns fixed columns of dY), not by
 //    re-reading the dY tile from LDS.
-template <int KT, int NT>
+template <int KT, int NT, int PAD = LDP>   // PAD 0: the operand reads here are column-consecutive (no row-per-lane reads), so the
+                                           // tiles need no pad; 64x256 then takes exactly 80 KB and two workgroups share a CU
 __global__ __launch_bounds__(256, 1) void k_wgrad_full_x(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
                                                          int R, float* __restrict__ slab, float* __restrict__ bias_slab) {
-  constexpr int KIN = 32 * KT, NOUT = 128 * NT, LDX = KIN + LDP, LDY = NOUT + LDP;
+  constexpr int KIN = 32 * KT, NOUT = 128 * NT, LDX = KIN + PAD, LDY = NOUT + PAD;
   constexpr int TX = KIN / 4, RPX = 256 / TX, NX = 64 / RPX;   // X: TX threads per row, RPX rows per pass, NX passes
   constexpr int NY = 8 * NT;                                   // dY: pass (rr, j) = rows 8 rr + (tid >> 5), float4 column 32 j + (tid & 31)
   extern __shared__ __align__(16) float wf_smem[];
@@ -995,6 +996,101 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_full_x(const float* __restrict
       float sb = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) sb += wf_smem[q * NOUT + col];
+      bias_slab[(long)g * NOUT + col] = sb;
+    }
+  }
+}
+
+// Whole-matrix weight gradient for 64 x 192 (the retention K/V/G projection of the cross site), every tile full: the same
+// pipeline as k_wgrad_full_x on a 2 x 2 wave grid (wave = (k half, column half): 32 weight rows x 96 columns, 3 accumulator
+// tiles).  The split kernel reads X twice for this shape (column blocks 128 + 64) and needs 1.5 LDS operand reads per MFMA.
+__global__ __launch_bounds__(256, 2) void k_wgrad_full_192(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
+                                                           int R, float* __restrict__ slab, float* __restrict__ bias_slab) {
+  constexpr int KIN = 64, NOUT = 192, LDX = KIN + LDP, LDY = NOUT + LDP, NX = 4, NY = 12;
+  extern __shared__ __align__(16) float wf_smem[];
+  float* xs = wf_smem;              // [64][LDX]
+  float* ys = xs + 64 * LDX;        // [64][LDY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int wk = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.x, G = gridDim.x;
+  const int ntiles = R >> 6;
+  f32x16 acc[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+  float4 bsum[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // X: 16 threads per row, 16 rows per pass; dY: pass (rr, j) = rows 16 rr + (tid >> 4), float4 column 16 j + (tid & 15)
+  const unsigned xoff = (unsigned)(tid >> 4) * (unsigned)ldx + 4u * (unsigned)(tid & 15);
+  const unsigned yoff = (unsigned)(tid >> 4) * (unsigned)ldy + 4u * (unsigned)(tid & 15);
+  float* xsw = xs + (tid >> 4) * LDX + 4 * (tid & 15);
+  float* ysw = ys + (tid >> 4) * LDY + 4 * (tid & 15);
+  float4 nxx[NX], nxy[NY];
+#define W192_LOADX(LI, ROW0) nxx[LI] = *reinterpret_cast<const float4*>(X + ((ROW0) + 16 * (LI)) * (long)ldx + xoff)
+#define W192_LOADY(LI, ROW0) nxy[LI] = *reinterpret_cast<const float4*>(dY + ((ROW0) + 16 * ((LI) / 3)) * (long)ldy + 64 * ((LI) % 3) + yoff)
+  {
+    const long row0 = (long)min(g, ntiles - 1) * 64;
+#pragma unroll
+    for (int li = 0; li < NX; ++li) { W192_LOADX(li, row0); }
+#pragma unroll
+    for (int li = 0; li < NY; ++li) { W192_LOADY(li, row0); }
+  }
+  const float* xr = xs + (32 * h) * LDX + 32 * wk + lr;
+  const float* yr = ys + (32 * h) * LDY + 96 * wn + lr;
+  for (int tile = g; tile < ntiles; tile += G) {
+    const long row0n = (long)min(tile + G, ntiles - 1) * 64;
+    __syncthreads();          // MFMAs of the previous tile have finished reading LDS
+#pragma unroll
+    for (int li = 0; li < NX; ++li) {   // component-wise: a whole-float4 copy out of the array leaves it in scratch
+      const float4 v = nxx[li];
+      *reinterpret_cast<float4*>(xsw + 16 * li * LDX) = make_float4(v.x, v.y, v.z, v.w);
+    }
+#pragma unroll
+    for (int li = 0; li < NY; ++li) {
+      const float4 v = nxy[li];
+      *reinterpret_cast<float4*>(ysw + 16 * (li / 3) * LDY + 64 * (li % 3)) = v;
+      bsum[li % 3].x += v.x; bsum[li % 3].y += v.y; bsum[li % 3].z += v.z; bsum[li % 3].w += v.w;
+    }
+    __syncthreads();
+    float av[2], bv[2][3];
+    av[0] = xr[0];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) bv[0][nt] = yr[32 * nt];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      if (s + 1 < 32) {
+        av[(s + 1) & 1] = xr[(s + 1) * LDX];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) bv[(s + 1) & 1][nt] = yr[(s + 1) * LDY + 32 * nt];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][nt], acc[nt], 0, 0, 0);
+      if ((s & 1) == 0) {   // the next tile's 16 loads, one every second MFMA step
+        const int li = s >> 1;
+        if (li < NY) { W192_LOADY(li < NY ? li : 0, row0n); } else { W192_LOADX(li >= NY ? li - NY : 0, row0n); }
+      }
+    }
+  }
+#undef W192_LOADX
+#undef W192_LOADY
+  float* out = slab + (long)g * KIN * NOUT;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    const int n = 96 * wn + 32 * nt + lr;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[(long)(32 * wk + (i & 3) + 8 * (i >> 2) + 4 * h) * NOUT + n] = acc[nt][i];
+  }
+  if (bias_slab) {   // fold the 16 row groups' partial column sums through LDS (the tiles are dead now)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<float4*>(&wf_smem[(tid >> 4) * NOUT + 64 * j + 4 * (tid & 15)]) = bsum[j];
+    __syncthreads();
+    for (int col = tid; col < NOUT; col += 256) {
+      float sb = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sb += wf_smem[q * NOUT + col];
       bias_slab[(long)g * NOUT + col] = sb;
     }
   }
@@ -1133,6 +1229,31 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   // (k_wgrad_full, or k_wgrad_full_x when every tile is full); with full tiles also 128x128 (two workgroups per CU: 1.53 ->
   // 1.30 ms) and 64x256 (1.84 -> 1.76 ms).  Other shapes stay on the split kernel k_wgrad.
   const bool exact = R % 64 == 0 && use_x;
+  static const bool use_pad0 = []() { const char* e = getenv("MAGPO_WGRAD_PAD0"); return !e || atoi(e) != 0; }();
+  if (use_full && exact && use_pad0 && KIN == 64 && NOUT == 256 && R >= 64 * 256) {
+    if (G > 512) G = 512;
+    float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
+    const size_t lds = (size_t)64 * (KIN + NOUT) * sizeof(float);
+    static bool attrp = false;
+    if (!attrp) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_x<2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attrp = true; }
+    hipLaunchKernelGGL((k_wgrad_full_x<2, 2, 0>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);
+    long P = (long)krows * NOUT;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
+    if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 63) / 64), dim3(1024), 0, stream, bsl, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
+    return check_launch("magpo_wgrad");
+  }
+  if (use_full && exact && KIN == 64 && NOUT == 192 && R >= 64 * 256) {
+    if (G > 512) G = 512;
+    float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
+    const size_t lds = (size_t)64 * ((KIN + LDP) + (NOUT + LDP)) * sizeof(float);
+    static bool attr192 = false;
+    if (!attr192) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_192), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr192 = true; }
+    hipLaunchKernelGGL(k_wgrad_full_192, dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);
+    long P = (long)krows * NOUT;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
+    if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 63) / 64), dim3(1024), 0, stream, bsl, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
+    return check_launch("magpo_wgrad");
+  }
   const bool full_shape = (KIN == 128 && NOUT == 384) || (exact && ((KIN == 128 && NOUT == 128) || (KIN == 64 && NOUT == 256)));
   if (use_full && full_shape && R >= 64 * 256) {
     const int gcap = (KIN == 128 && NOUT == 128) ? 512 : 256;

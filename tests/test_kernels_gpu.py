@@ -113,7 +113,7 @@ def test_linear_relu_mask_epilogue(L, stream):
 
 
 @pytest.mark.parametrize("KIN,NOUT,R,G", [(128, 384, 64 * 256 + 37, 200), (128, 384, 64 * 300, 200), (128, 128, 64 * 600, 512),
-                                          (64, 256, 64 * 300, 256)])
+                                          (64, 256, 64 * 300, 256), (64, 192, 64 * 700, 512)])
 def test_wgrad_whole_matrix(L, stream, KIN, NOUT, R, G):
     """Whole-matrix weight gradient (enough rows for one slab per CU) incl. the bias column sums: k_wgrad_full with a ragged
     last tile, k_wgrad_full_x when every tile is full (more tiles than slabs, so the prefetch pipeline runs)."""
