@@ -1001,43 +1001,50 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_full_x(const float* __restrict
   }
 }
 
-// Whole-matrix weight gradient for 64 x 192 (the retention K/V/G projection of the cross site), every tile full: the same
-// pipeline as k_wgrad_full_x on a 2 x 2 wave grid (wave = (k half, column half): 32 weight rows x 96 columns, 3 accumulator
-// tiles).  The split kernel reads X twice for this shape (column blocks 128 + 64) and needs 1.5 LDS operand reads per MFMA.
-__global__ __launch_bounds__(256, 2) void k_wgrad_full_192(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
-                                                           int R, float* __restrict__ slab, float* __restrict__ bias_slab) {
-  constexpr int KIN = 64, NOUT = 192, LDX = KIN + LDP, LDY = NOUT + LDP, NX = 4, NY = 12;
+// Whole-matrix weight gradient on a 2 x 2 wave grid, every tile full: a workgroup accumulates (64 KTW) weight rows x 192 columns
+// (wave = (k half, column half): 32 KTW rows x 96 columns, KTW x 3 accumulator tiles); blockIdx.y selects the 192-column block.
+//   KTW = 1: 64 x 192 (the retention K/V/G projection of the cross site) -- the split kernel reads X twice for this shape;
+//   KTW = 2: 128 x 384 as two column halves: X is read twice (+25 % bytes), but the tiles take 80 KB and the accumulators
+//            96 registers, so TWO workgroups share a CU and one's barrier / stash phases run under the other's MFMAs.
+// Same pipeline as k_wgrad_full_x (uniform-base tile loads, operands one k-step ahead, bias sums at stash time), unpadded tiles.
+template <int KTW>
+__global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
+                                                         int R, int NOUT, float* __restrict__ slab, float* __restrict__ bias_slab) {
+  constexpr int KIN = 64 * KTW, NB = 192, LDX = KIN, LDY = NB, TX = KIN / 4, RPX = 256 / TX, NX = 64 / RPX, NY = 12;
   extern __shared__ __align__(16) float wf_smem[];
   float* xs = wf_smem;              // [64][LDX]
   float* ys = xs + 64 * LDX;        // [64][LDY]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int wk = wave >> 1, wn = wave & 1;
-  const int g = blockIdx.x, G = gridDim.x;
+  const int g = blockIdx.x, G = gridDim.x, cb = NB * blockIdx.y;
   const int ntiles = R >> 6;
-  f32x16 acc[3];
+  dY += cb;
+  f32x16 acc[KTW][3];
 #pragma unroll
-  for (int nt = 0; nt < 3; ++nt)
+  for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[kt][nt][i] = 0.f;
   float4 bsum[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // X: 16 threads per row, 16 rows per pass; dY: pass (rr, j) = rows 16 rr + (tid >> 4), float4 column 16 j + (tid & 15)
-  const unsigned xoff = (unsigned)(tid >> 4) * (unsigned)ldx + 4u * (unsigned)(tid & 15);
+  // X: TX threads per row, RPX rows per pass; dY: pass (rr, j) = rows 16 rr + (tid >> 4), float4 column 16 j + (tid & 15)
+  const unsigned xoff = (unsigned)(tid / TX) * (unsigned)ldx + 4u * (unsigned)(tid % TX);
   const unsigned yoff = (unsigned)(tid >> 4) * (unsigned)ldy + 4u * (unsigned)(tid & 15);
-  float* xsw = xs + (tid >> 4) * LDX + 4 * (tid & 15);
+  float* xsw = xs + (tid / TX) * LDX + 4 * (tid % TX);
   float* ysw = ys + (tid >> 4) * LDY + 4 * (tid & 15);
   float4 nxx[NX], nxy[NY];
-#define W192_LOADX(LI, ROW0) nxx[LI] = *reinterpret_cast<const float4*>(X + ((ROW0) + 16 * (LI)) * (long)ldx + xoff)
-#define W192_LOADY(LI, ROW0) nxy[LI] = *reinterpret_cast<const float4*>(dY + ((ROW0) + 16 * ((LI) / 3)) * (long)ldy + 64 * ((LI) % 3) + yoff)
+#define WG_LOADXG(LI, ROW0) nxx[LI] = *reinterpret_cast<const float4*>(X + ((ROW0) + RPX * (LI)) * (long)ldx + xoff)
+#define WG_LOADYG(LI, ROW0) nxy[LI] = *reinterpret_cast<const float4*>(dY + ((ROW0) + 16 * ((LI) / 3)) * (long)ldy + 64 * ((LI) % 3) + yoff)
   {
     const long row0 = (long)min(g, ntiles - 1) * 64;
 #pragma unroll
-    for (int li = 0; li < NX; ++li) { W192_LOADX(li, row0); }
+    for (int li = 0; li < NX; ++li) { WG_LOADXG(li, row0); }
 #pragma unroll
-    for (int li = 0; li < NY; ++li) { W192_LOADY(li, row0); }
+    for (int li = 0; li < NY; ++li) { WG_LOADYG(li, row0); }
   }
-  const float* xr = xs + (32 * h) * LDX + 32 * wk + lr;
+  const float* xr = xs + (32 * h) * LDX + 32 * KTW * wk + lr;
   const float* yr = ys + (32 * h) * LDY + 96 * wn + lr;
   for (int tile = g; tile < ntiles; tile += G) {
     const long row0n = (long)min(tile + G, ntiles - 1) * 64;
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_192(const float* __restri
 #pragma unroll
     for (int li = 0; li < NX; ++li) {   // component-wise: a whole-float4 copy out of the array leaves it in scratch
       const float4 v = nxx[li];
-      *reinterpret_cast<float4*>(xsw + 16 * li * LDX) = make_float4(v.x, v.y, v.z, v.w);
+      *reinterpret_cast<float4*>(xsw + RPX * li * LDX) = make_float4(v.x, v.y, v.z, v.w);
     }
 #pragma unroll
     for (int li = 0; li < NY; ++li) {
@@ -1054,44 +1061,54 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_192(const float* __restri
       bsum[li % 3].x += v.x; bsum[li % 3].y += v.y; bsum[li % 3].z += v.z; bsum[li % 3].w += v.w;
     }
     __syncthreads();
-    float av[2], bv[2][3];
-    av[0] = xr[0];
+    float av[2][KTW], bv[2][3];
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) av[0][kt] = xr[32 * kt];
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) bv[0][nt] = yr[32 * nt];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
       if (s + 1 < 32) {
-        av[(s + 1) & 1] = xr[(s + 1) * LDX];
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) av[(s + 1) & 1][kt] = xr[(s + 1) * LDX + 32 * kt];
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) bv[(s + 1) & 1][nt] = yr[(s + 1) * LDY + 32 * nt];
       }
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][nt], acc[nt], 0, 0, 0);
-      if ((s & 1) == 0) {   // the next tile's 16 loads, one every second MFMA step
-        const int li = s >> 1;
-        if (li < NY) { W192_LOADY(li < NY ? li : 0, row0n); } else { W192_LOADX(li >= NY ? li - NY : 0, row0n); }
-      }
+      for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][kt], bv[s & 1][nt], acc[kt][nt], 0, 0, 0);
+      // the next tile's loads, one per MFMA step
+#pragma unroll
+      for (int li = 0; li < NY; ++li)
+        if (li == s) { WG_LOADYG(li, row0n); }
+#pragma unroll
+      for (int li = 0; li < NX; ++li)
+        if (NY + li == s) { WG_LOADXG(li, row0n); }
     }
   }
-#undef W192_LOADX
-#undef W192_LOADY
-  float* out = slab + (long)g * KIN * NOUT;
+#undef WG_LOADXG
+#undef WG_LOADYG
+  float* out = slab + (long)g * KIN * NOUT + cb;
 #pragma unroll
-  for (int nt = 0; nt < 3; ++nt) {
-    const int n = 96 * wn + 32 * nt + lr;
+  for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) out[(long)(32 * wk + (i & 3) + 8 * (i >> 2) + 4 * h) * NOUT + n] = acc[nt][i];
-  }
+    for (int nt = 0; nt < 3; ++nt) {
+      const int n = 96 * wn + 32 * nt + lr;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) out[(long)(32 * KTW * wk + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h) * NOUT + n] = acc[kt][nt][i];
+    }
   if (bias_slab) {   // fold the 16 row groups' partial column sums through LDS (the tiles are dead now)
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *reinterpret_cast<float4*>(&wf_smem[(tid >> 4) * NOUT + 64 * j + 4 * (tid & 15)]) = bsum[j];
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<float4*>(&wf_smem[(tid >> 4) * NB + 64 * j + 4 * (tid & 15)]) = bsum[j];
     __syncthreads();
-    for (int col = tid; col < NOUT; col += 256) {
+    for (int col = tid; col < NB; col += 256) {
       float sb = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sb += wf_smem[q * NOUT + col];
-      bias_slab[(long)g * NOUT + col] = sb;
+      for (int q = 0; q < 16; ++q) sb += wf_smem[q * NB + col];
+      bias_slab[(long)g * NOUT + cb + col] = sb;
     }
   }
 }
@@ -1242,13 +1259,23 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
     if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 63) / 64), dim3(1024), 0, stream, bsl, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
     return check_launch("magpo_wgrad");
   }
-  if (use_full && exact && KIN == 64 && NOUT == 192 && R >= 64 * 256) {
-    if (G > 512) G = 512;
+  // 128 x 384 on this kernel (two column halves, two workgroups per CU) measured 3.57 vs 3.63 ms for k_wgrad_full_x<4,3> while
+  // reading X twice: within noise, so the one-pass kernel stays the default (MAGPO_WGRAD_G2=1 selects this one)
+  static const int use_g2 = []() { const char* e = getenv("MAGPO_WGRAD_G2"); return e ? atoi(e) : 0; }();
+  if (use_full && exact && R >= 64 * 256 && ((KIN == 64 && NOUT == 192) || (use_g2 && KIN == 128 && NOUT == 384))) {
+    const int gy = NOUT / 192;
+    const int gcap = 512 / gy;                    // two workgroups per CU in total
+    if (G > gcap) G = gcap;
     float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
-    const size_t lds = (size_t)64 * ((KIN + LDP) + (NOUT + LDP)) * sizeof(float);
-    static bool attr192 = false;
-    if (!attr192) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_192), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr192 = true; }
-    hipLaunchKernelGGL(k_wgrad_full_192, dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);
+    const size_t lds = (size_t)64 * (KIN + 192) * sizeof(float);
+    static bool attrg = false;
+    if (!attrg) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_g<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (64 + 192) * 4);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_g<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (128 + 192) * 4);
+      attrg = true;
+    }
+    if (KIN == 64) hipLaunchKernelGGL(k_wgrad_full_g<1>, dim3(G, gy), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, NOUT, slab, bsl);
+    else hipLaunchKernelGGL(k_wgrad_full_g<2>, dim3(G, gy), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, NOUT, slab, bsl);
     long P = (long)krows * NOUT;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
     if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 63) / 64), dim3(1024), 0, stream, bsl, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
