@@ -650,8 +650,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
         // one load of the next tile every second MFMA step (after unrolling, s and the register index are constants)
         if ((s & 1) && (s >> 1) < 4 + 4 * NB) {
           const int li = s >> 1;
-          const float* src = li < 4 ? xb + (long)min((int)row0n + rx + 16 * li, R - 1) * ldx
-                                    : yb + (long)min((int)row0n + ry + (256 / YR) * (li - 4), R - 1) * ldy;
+          const float* src = li < 4 ? xb + min(row0n + rx + 16 * li, (long)R - 1) * (long)ldx
+                                    : yb + min(row0n + ry + (256 / YR) * (li - 4), (long)R - 1) * (long)ldy;
           nx[li] = *reinterpret_cast<const float4*>(src);
         }
       }
