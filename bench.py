@@ -55,8 +55,8 @@ class KernelTimer:
             if R < self.min_rows:
                 return None
             full = R >= 64 * 256 and ((KIN, NOUT) == (128, 384) or (R % 64 == 0 and (KIN, NOUT) in ((128, 128), (64, 256))))
-            if R >= 64 * 256 and R % 64 == 0 and (KIN, NOUT) == (64, 192):
-                key = "k_wgrad_full_g<1>"
+            if R >= 64 * 256 and R % 64 == 0 and (KIN, NOUT) in ((64, 192), (128, 128)):
+                key = f"k_wgrad_full_g<{KIN // 64},{3 if NOUT == 192 else 2}>"
             elif full and R % 64 == 0:
                 key = f"k_wgrad_full_x<{KIN // 32},{NOUT // 128},{0 if (KIN, NOUT) == (64, 256) else 4}>"
             elif full:

@@ -1001,16 +1001,16 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_full_x(const float* __restrict
   }
 }
 
-// Whole-matrix weight gradient on a 2 x 2 wave grid, every tile full: a workgroup accumulates (64 KTW) weight rows x 192 columns
-// (wave = (k half, column half): 32 KTW rows x 96 columns, KTW x 3 accumulator tiles); blockIdx.y selects the 192-column block.
+// Whole-matrix weight gradient on a 2 x 2 wave grid, every tile full: a workgroup accumulates (64 KTW) weight rows x (64 NTW)
+// columns (wave = (k half, column half): 32 KTW rows x 32 NTW columns, KTW x NTW accumulator tiles); blockIdx.y selects the column block.
 //   KTW = 1: 64 x 192 (the retention K/V/G projection of the cross site) -- the split kernel reads X twice for this shape;
 //   KTW = 2: 128 x 384 as two column halves: X is read twice (+25 % bytes), but the tiles take 80 KB and the accumulators
 //            96 registers, so TWO workgroups share a CU and one's barrier / stash phases run under the other's MFMAs.
 // Same pipeline as k_wgrad_full_x (uniform-base tile loads, operands one k-step ahead, bias sums at stash time), unpadded tiles.
-template <int KTW>
+template <int KTW, int NTW>
 __global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
                                                          int R, int NOUT, float* __restrict__ slab, float* __restrict__ bias_slab) {
-  constexpr int KIN = 64 * KTW, NB = 192, LDX = KIN, LDY = NB, TX = KIN / 4, RPX = 256 / TX, NX = 64 / RPX, NY = 12;
+  constexpr int KIN = 64 * KTW, NB = 64 * NTW, LDX = KIN, LDY = NB, TX = KIN / 4, RPX = 256 / TX, NX = 64 / RPX, NY = 4 * NTW;
   extern __shared__ __align__(16) float wf_smem[];
   float* xs = wf_smem;              // [64][LDX]
   float* ys = xs + 64 * LDX;        // [64][LDY]
@@ -1019,16 +1019,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict
   const int g = blockIdx.x, G = gridDim.x, cb = NB * blockIdx.y;
   const int ntiles = R >> 6;
   dY += cb;
-  f32x16 acc[KTW][3];
+  f32x16 acc[KTW][NTW];
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[kt][nt][i] = 0.f;
-  float4 bsum[3];
+  float4 bsum[NTW];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < NTW; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   // X: TX threads per row, RPX rows per pass; dY: pass (rr, j) = rows 16 rr + (tid >> 4), float4 column 16 j + (tid & 15)
   const unsigned xoff = (unsigned)(tid / TX) * (unsigned)ldx + 4u * (unsigned)(tid % TX);
   const unsigned yoff = (unsigned)(tid >> 4) * (unsigned)ldy + 4u * (unsigned)(tid & 15);
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict
   float* ysw = ys + (tid >> 4) * LDY + 4 * (tid & 15);
   float4 nxx[NX], nxy[NY];
 #define WG_LOADXG(LI, ROW0) nxx[LI] = *reinterpret_cast<const float4*>(X + ((ROW0) + RPX * (LI)) * (long)ldx + xoff)
-#define WG_LOADYG(LI, ROW0) nxy[LI] = *reinterpret_cast<const float4*>(dY + ((ROW0) + 16 * ((LI) / 3)) * (long)ldy + 64 * ((LI) % 3) + yoff)
+#define WG_LOADYG(LI, ROW0) nxy[LI] = *reinterpret_cast<const float4*>(dY + ((ROW0) + 16 * ((LI) / NTW)) * (long)ldy + 64 * ((LI) % NTW) + yoff)
   {
     const long row0 = (long)min(g, ntiles - 1) * 64;
 #pragma unroll
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict
     for (int li = 0; li < NY; ++li) { WG_LOADYG(li, row0); }
   }
   const float* xr = xs + (32 * h) * LDX + 32 * KTW * wk + lr;
-  const float* yr = ys + (32 * h) * LDY + 96 * wn + lr;
+  const float* yr = ys + (32 * h) * LDY + 32 * NTW * wn + lr;
   for (int tile = g; tile < ntiles; tile += G) {
     const long row0n = (long)min(tile + G, ntiles - 1) * 64;
     __syncthreads();          // MFMAs of the previous tile have finished reading LDS
@@ -1057,27 +1057,27 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict
 #pragma unroll
     for (int li = 0; li < NY; ++li) {
       const float4 v = nxy[li];
-      *reinterpret_cast<float4*>(ysw + 16 * (li / 3) * LDY + 64 * (li % 3)) = v;
-      bsum[li % 3].x += v.x; bsum[li % 3].y += v.y; bsum[li % 3].z += v.z; bsum[li % 3].w += v.w;
+      *reinterpret_cast<float4*>(ysw + 16 * (li / NTW) * LDY + 64 * (li % NTW)) = v;
+      bsum[li % NTW].x += v.x; bsum[li % NTW].y += v.y; bsum[li % NTW].z += v.z; bsum[li % NTW].w += v.w;
     }
     __syncthreads();
-    float av[2][KTW], bv[2][3];
+    float av[2][KTW], bv[2][NTW];
 #pragma unroll
     for (int kt = 0; kt < KTW; ++kt) av[0][kt] = xr[32 * kt];
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) bv[0][nt] = yr[32 * nt];
+    for (int nt = 0; nt < NTW; ++nt) bv[0][nt] = yr[32 * nt];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
       if (s + 1 < 32) {
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt) av[(s + 1) & 1][kt] = xr[(s + 1) * LDX + 32 * kt];
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) bv[(s + 1) & 1][nt] = yr[(s + 1) * LDY + 32 * nt];
+        for (int nt = 0; nt < NTW; ++nt) bv[(s + 1) & 1][nt] = yr[(s + 1) * LDY + 32 * nt];
       }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
           acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][kt], bv[s & 1][nt], acc[kt][nt], 0, 0, 0);
       // the next tile's loads, one per MFMA step
 #pragma unroll
@@ -1094,15 +1094,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-      const int n = 96 * wn + 32 * nt + lr;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int n = 32 * NTW * wn + 32 * nt + lr;
 #pragma unroll
       for (int i = 0; i < 16; ++i) out[(long)(32 * KTW * wk + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h) * NOUT + n] = acc[kt][nt][i];
     }
   if (bias_slab) {   // fold the 16 row groups' partial column sums through LDS (the tiles are dead now)
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *reinterpret_cast<float4*>(&wf_smem[(tid >> 4) * NB + 64 * j + 4 * (tid & 15)]) = bsum[j];
+    for (int j = 0; j < NTW; ++j) *reinterpret_cast<float4*>(&wf_smem[(tid >> 4) * NB + 64 * j + 4 * (tid & 15)]) = bsum[j];
     __syncthreads();
     for (int col = tid; col < NB; col += 256) {
       float sb = 0.f;
@@ -1247,7 +1247,8 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   // 1.30 ms) and 64x256 (1.84 -> 1.76 ms).  Other shapes stay on the split kernel k_wgrad.
   const bool exact = R % 64 == 0 && use_x;
   static const bool use_pad0 = []() { const char* e = getenv("MAGPO_WGRAD_PAD0"); return !e || atoi(e) != 0; }();
-  if (use_full && exact && use_pad0 && KIN == 64 && NOUT == 256 && R >= 64 * 256) {
+  static const int g_alt = []() { const char* e = getenv("MAGPO_WGRAD_GALT"); return e ? atoi(e) : 0; }();   // experiments (bit mask): 1 = 64x64 on the wave-grid kernel (0.43 vs 0.40 ms), 2 = 64x256 (1.63 vs 1.64 ms)
+  if (use_full && exact && use_pad0 && !(g_alt & 2) && KIN == 64 && NOUT == 256 && R >= 64 * 256) {
     if (G > 512) G = 512;
     float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
     const size_t lds = (size_t)64 * (KIN + NOUT) * sizeof(float);
@@ -1262,20 +1263,28 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   // 128 x 384 on this kernel (two column halves, two workgroups per CU) measured 3.57 vs 3.63 ms for k_wgrad_full_x<4,3> while
   // reading X twice: within noise, so the one-pass kernel stays the default (MAGPO_WGRAD_G2=1 selects this one)
   static const int use_g2 = []() { const char* e = getenv("MAGPO_WGRAD_G2"); return e ? atoi(e) : 0; }();
-  if (use_full && exact && R >= 64 * 256 && ((KIN == 64 && NOUT == 192) || (use_g2 && KIN == 128 && NOUT == 384))) {
-    const int gy = NOUT / 192;
-    const int gcap = 512 / gy;                    // two workgroups per CU in total
+  int gk = 0, gn = 0;   // (KTW, NTW) of the 2 x 2 wave-grid kernel, 0 = not this kernel
+  if (KIN == 64 && NOUT == 192) { gk = 1; gn = 3; }
+  else if (use_g2 && KIN == 128 && NOUT == 384) { gk = 2; gn = 3; }
+  else if ((g_alt & 1) && KIN == 64 && NOUT == 64) { gk = 1; gn = 1; }
+  else if ((g_alt & 2) && KIN == 64 && NOUT == 256) { gk = 1; gn = 4; }
+  else if (KIN == 128 && NOUT == 128) { gk = 2; gn = 2; }        // 1.23 vs 1.32 ms for k_wgrad_full_x<4,1>
+  if (use_full && exact && R >= 64 * 256 && gk) {
+    const int nbk = 64 * gn, gy = NOUT / nbk;
+    const size_t lds = (size_t)64 * (KIN + nbk) * sizeof(float);
+    const int per_cu = lds <= 32 * 1024 ? 4 : (lds <= 40 * 1024 ? 3 : 2);   // resident workgroups per CU (LDS; launch bound 2 waves / SIMD for the wide ones)
+    const int gcap = 256 * per_cu / gy;
     if (G > gcap) G = gcap;
     float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
-    const size_t lds = (size_t)64 * (KIN + 192) * sizeof(float);
-    static bool attrg = false;
-    if (!attrg) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_g<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (64 + 192) * 4);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_g<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (128 + 192) * 4);
-      attrg = true;
+#define LAUNCH_G(K_, N_)                                                                                                      \
+    {                                                                                                                          \
+      static bool attr = false;                                                                                                \
+      if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_g<K_, N_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (64 * K_ + 64 * N_) * 4); attr = true; } \
+      hipLaunchKernelGGL((k_wgrad_full_g<K_, N_>), dim3(G, gy), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, NOUT, slab, bsl); \
     }
-    if (KIN == 64) hipLaunchKernelGGL(k_wgrad_full_g<1>, dim3(G, gy), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, NOUT, slab, bsl);
-    else hipLaunchKernelGGL(k_wgrad_full_g<2>, dim3(G, gy), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, NOUT, slab, bsl);
+    if (gk == 1 && gn == 3) LAUNCH_G(1, 3) else if (gk == 2 && gn == 3) LAUNCH_G(2, 3) else if (gk == 1 && gn == 1) LAUNCH_G(1, 1)
+    else if (gk == 1 && gn == 4) LAUNCH_G(1, 4) else LAUNCH_G(2, 2)
+#undef LAUNCH_G
     long P = (long)krows * NOUT;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, stream, slab, dW, G, P, (long)KIN * NOUT, scale, accumulate);
     if (db) hipLaunchKernelGGL(k_reduce_slabs, dim3((NOUT + 63) / 64), dim3(1024), 0, stream, bsl, db, G, (long)NOUT, (long)NOUT, scale, accumulate);
