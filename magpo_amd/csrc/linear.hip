@@ -1144,6 +1144,11 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
       const int nw = (ncg % 4 == 0) ? 4 : 2;
       const int gy = (ncg + nw - 1) / nw;
       long wk2 = 2048 / nw;   // about 2 waves per SIMD; LDS 2 x 32 x (KIN + 4) floats per block
+      // several column blocks per row walker: all of them co-resident (walkers x column blocks <= resident workgroups), so the
+      // column blocks of a walker -- same XCD, since the walker count is a multiple of 8 -- read a tile at about the same
+      // time and the re-reads hit that XCD's L2 instead of HBM (in a second round they would come from HBM again)
+      static const long lds_wk_div = []() { const char* e = getenv("MAGPO_LINEAR_WKDIV"); return e ? atol(e) : 2L; }();
+      if (gy >= 3 && lds_wk_div > 1) wk2 /= lds_wk_div;
       if (wk2 > ntiles) wk2 = ntiles;
       dim3 g2((unsigned)wk2, (unsigned)gy), b2(64 * nw);
       const size_t lds = (size_t)2 * 32 * (KIN + LDP) * sizeof(float);
