@@ -139,7 +139,9 @@ int magpo_seg_post(const int* dims_host, long R, const void* const* ptrs_host, i
 int magpo_seg_bwd_grid(long R);
 int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
 
-/* ---- K3/K8 GRU actor (base.py:121-184; flax GRUCell) ---- */
+/* ---- K3/K8 GRU actor (base.py:121-184; flax GRUCell) ----
+ * gates [R][512] is an opaque save-for-backward buffer written by magpo_gru_scan_fwd and read by magpo_gru_scan_bwd
+ * ((r, z, n, h W_hn + b_hn) interleaved per hidden column). */
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                        const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
                        magpo_stream_t stream);

@@ -25,7 +25,7 @@ struct GruArgs {
   const int* h0_idx;      // [NR] row of h0 per recurrent row (nullable: identity)
   const unsigned char* reset;  // [nseq][T] reset-before-step flags
   float* hs;              // [R][H] h after each step
-  float* gates;           // [R][4H] r | z | n | (h W_hn + b_hn)   (nullable: acting)
+  float* gates;           // [R][4H] (r, z, n, h W_hn + b_hn) interleaved per hidden column: opaque to the host (nullable: acting)
   float* hprev;           // [R][H] reset-applied state each step started from (nullable: acting)
   int T, A, NR;           // NR = nseq * A recurrent rows
   int time_major;         // 0: rows (seq, t, agent), reset [nseq][T];  1: rows (t, seq, agent), reset [T][nseq] (rollout trajectory)
@@ -159,16 +159,14 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         if (FULL || rho0 + rl < a.NR) {
           if (MODE == 0) {
             a.hs[row * H + col] = hn_new;
-            float* g = a.gates + row * (4 * H);
-            g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
+            *reinterpret_cast<float4*>(a.gates + row * (4 * H) + 4 * col) = make_float4(r, z, n, hb);   // one 16-byte store per element
             a.hprev[row * H + col] = hp;
           } else if (MODE == 1) {
             if (!more) a.h_last[(long)(rho0 + rl) * H + col] = hn_new;
           } else {
             if (a.hs) a.hs[row * H + col] = hn_new;
             if (a.gates) {
-              float* g = a.gates + row * (4 * H);
-              g[col] = r; g[H + col] = z; g[2 * H + col] = n; g[3 * H + col] = hb;
+              *reinterpret_cast<float4*>(a.gates + row * (4 * H) + 4 * col) = make_float4(r, z, n, hb);
             }
             if (a.hprev) a.hprev[row * H + col] = hp;
           }
@@ -184,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
 }
 
 struct GruBwdArgs {
-  const float* gates;     // [R][4H]
+  const float* gates;     // [R][4H] as written by the forward scan: (r, z, n, hb) per hidden column
   const float* hprev;     // [R][H] from the forward
   const unsigned char* reset;
   const float* dhs;       // [R][H] dL/dh_t from the post-torso path
@@ -231,9 +229,11 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
         const int rl = rg + 8 * k;
         const long row = rbase[rl] + (long)t * a.A;
         rowv[k] = row;
-        const float* g = a.gates + row * (4 * H) + c4;
-        gr[k] = *reinterpret_cast<const float4*>(g); gz[k] = *reinterpret_cast<const float4*>(g + H);
-        gn[k] = *reinterpret_cast<const float4*>(g + 2 * H); gh[k] = *reinterpret_cast<const float4*>(g + 3 * H);
+        const float* g = a.gates + row * (4 * H) + 4 * c4;   // (r, z, n, hb) of columns c4 .. c4 + 3: 64 contiguous bytes
+        const float4 q0 = *reinterpret_cast<const float4*>(g), q1 = *reinterpret_cast<const float4*>(g + 4);
+        const float4 q2 = *reinterpret_cast<const float4*>(g + 8), q3 = *reinterpret_cast<const float4*>(g + 12);
+        gr[k] = make_float4(q0.x, q1.x, q2.x, q3.x); gz[k] = make_float4(q0.y, q1.y, q2.y, q3.y);
+        gn[k] = make_float4(q0.z, q1.z, q2.z, q3.z); gh[k] = make_float4(q0.w, q1.w, q2.w, q3.w);
         hp[k] = *reinterpret_cast<const float4*>(a.hprev + row * H + c4);
         dh[k] = *reinterpret_cast<const float4*>(a.dhs + row * H + c4);
       }
