@@ -191,7 +191,7 @@ def main():
                     help="coordsum-4ag = BASELINE.json configs[1] (headline); coordsum-8x15 = configs[4] per GPU (registered 8x15-100, n_block=2, 8 minibatches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (+3 %%; kernel timings then include contention)")
+    ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
