@@ -170,9 +170,12 @@ __device__ __forceinline__ float min_grad_weight(float l1, float l2, bool first)
   if (l1 == l2) return 0.5f;
   return ((l1 < l2) == first) ? 1.f : 0.f;
 }
+// all-reduce max over aligned groups of 16 lanes (one DPP row) on the VALU (a __shfl_xor is an LDS round trip); max is exact in any order
 __device__ __forceinline__ float max16(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_mov_<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_mov_<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_mov_<0x141>(v));   // row_half_mirror
+  v = fmaxf(v, dpp_mov_<0x140>(v));   // row_mirror
   return v;
 }
 
@@ -191,20 +194,31 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
     // one unconditional float4 per lane and operand when the rows are padded to 64 columns (a predicated load per element is an
     // exec-masked block with its own wait); the K / mask selection happens on the loaded values
     const bool vec = a.ldg >= 64 && a.lda >= 64 && ((a.ldg | a.lda) & 3) == 0;
-    float4 vg = make_float4(0.f, 0.f, 0.f, 0.f), va = vg;
-    if (vec) {
-      vg = *reinterpret_cast<const float4*>(a.g_logits + rr * a.ldg + c4);
-      va = *reinterpret_cast<const float4*>(a.a_logits + rr * a.lda + c4);
+    float lgv[4], lav[4];
+    if (vec) {   // uniform branch: the element-wise (predicated) loads below are compiled only into the narrow-row path
+      const float4 vg = *reinterpret_cast<const float4*>(a.g_logits + rr * a.ldg + c4);
+      const float4 va = *reinterpret_cast<const float4*>(a.a_logits + rr * a.lda + c4);
+      lgv[0] = vg.x; lgv[1] = vg.y; lgv[2] = vg.z; lgv[3] = vg.w;
+      lav[0] = va.x; lav[1] = va.y; lav[2] = va.z; lav[3] = va.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = c4 + j < a.K;
+        lgv[j] = in ? a.g_logits[rr * a.ldg + c4 + j] : 0.f;
+        lav[j] = in ? a.a_logits[rr * a.lda + c4 + j] : 0.f;
+      }
+    }
+    unsigned char mk[4] = {1, 1, 1, 1};
+    if (a.mask) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mk[j] = a.mask[rr * a.K + (c4 + j < a.K ? c4 + j : 0)];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k = c4 + j;
-      const bool in = k < a.K;
-      legal[j] = in && (!a.mask || a.mask[rr * a.K + (in ? k : 0)]);
-      const float lg = vec ? (j == 0 ? vg.x : (j == 1 ? vg.y : (j == 2 ? vg.z : vg.w))) : (in ? a.g_logits[rr * a.ldg + k] : 0.f);
-      const float la = vec ? (j == 0 ? va.x : (j == 1 ? va.y : (j == 2 ? va.z : va.w))) : (in ? a.a_logits[rr * a.lda + k] : 0.f);
-      xg[j] = in ? (legal[j] ? lg : FMIN) : -INFINITY;
-      xa[j] = in ? (legal[j] ? la : FMIN) : -INFINITY;
+      const bool in = c4 + j < a.K;
+      legal[j] = in && mk[j];
+      xg[j] = in ? (legal[j] ? lgv[j] : FMIN) : -INFINITY;
+      xa[j] = in ? (legal[j] ? lav[j] : FMIN) : -INFINITY;
     }
     const float mg = max16(fmaxf(fmaxf(xg[0], xg[1]), fmaxf(xg[2], xg[3])));
     const float ma = max16(fmaxf(fmaxf(xa[0], xa[1]), fmaxf(xa[2], xa[3])));
@@ -219,8 +233,12 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
     for (int j = 0; j < 4; ++j) {
       lpg[j] = xg[j] - lseg; lpa[j] = xa[j] - lsea;
       pg[j] = expf(lpg[j]); pa[j] = expf(lpa[j]);
-      if (pg[j] != 0.f) { ent -= pg[j] * lpg[j]; kl += pg[j] * (lpg[j] - lpa[j]); }
-      if (c4 + j == act) { g_logp = lpg[j]; a_logp = lpa[j]; }
+      const bool nz = pg[j] != 0.f;   // selects, not branches: an exec-masked block per element serialises the row
+      ent -= nz ? pg[j] * lpg[j] : 0.f;
+      kl += nz ? pg[j] * (lpg[j] - lpa[j]) : 0.f;
+      const bool hit = c4 + j == act;
+      g_logp = hit ? lpg[j] : g_logp;
+      a_logp = hit ? lpa[j] : a_logp;
     }
     ent = sum16(ent); kl = sum16(kl); g_logp = sum16(g_logp); a_logp = sum16(a_logp);
     const float old = a.old_logp[rr];
@@ -262,16 +280,21 @@ __global__ __launch_bounds__(256) void k_magpo_loss(LossArgs a) {
       for (int j = 0; j < 4; ++j) {
         const float onehot = (c4 + j == act) ? 1.f : 0.f;
         float gg = c_g * (onehot - pg[j]);
-        if (pg[j] != 0.f) gg += km * pg[j] * ((lpg[j] - lpa[j]) - kl) + a.ent_coef * pg[j] * (lpg[j] + ent);
+        gg += (pg[j] != 0.f) ? km * pg[j] * ((lpg[j] - lpa[j]) - kl) + a.ent_coef * pg[j] * (lpg[j] + ent) : 0.f;
         float ga = a.alpha * c_a * (onehot - pa[j]) + (pa[j] - pg[j]);
         if (!legal[j]) { gg = 0.f; ga = 0.f; }
         pog[j] = a.inv_R * gg;
         poa[j] = a.inv_R * ga;
       }
-      if (c4 + 3 < a.lddg) *reinterpret_cast<float4*>(a.dg_logits + r * a.lddg + c4) = og;
-      else for (int j = 0; j < 4; ++j) if (c4 + j < a.lddg) a.dg_logits[r * a.lddg + c4 + j] = pog[j];
-      if (c4 + 3 < a.lddda) *reinterpret_cast<float4*>(a.da_logits + r * a.lddda + c4) = oa;
-      else for (int j = 0; j < 4; ++j) if (c4 + j < a.lddda) a.da_logits[r * a.lddda + c4 + j] = poa[j];
+      if (a.lddg >= 64 && a.lddda >= 64) {   // uniform: whole padded rows
+        *reinterpret_cast<float4*>(a.dg_logits + r * a.lddg + c4) = og;
+        *reinterpret_cast<float4*>(a.da_logits + r * a.lddda + c4) = oa;
+      } else {
+        if (c4 + 3 < a.lddg) *reinterpret_cast<float4*>(a.dg_logits + r * a.lddg + c4) = og;
+        else for (int j = 0; j < 4; ++j) if (c4 + j < a.lddg) a.dg_logits[r * a.lddg + c4 + j] = pog[j];
+        if (c4 + 3 < a.lddda) *reinterpret_cast<float4*>(a.da_logits + r * a.lddda + c4) = oa;
+        else for (int j = 0; j < 4; ++j) if (c4 + j < a.lddda) a.da_logits[r * a.lddda + c4 + j] = poa[j];
+      }
       if (l16 == 0) {
         a.dvalue[r] = a.inv_R * a.vf_coef * dvl;
         acc[0] += pgl; acc[1] += km * kl; acc[2] += ent; acc[3] += vl; acc[4] += apl; acc[5] += kl;

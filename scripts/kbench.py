@@ -1,5 +1,5 @@
 """Per-kernel micro-benchmarks at the bench shapes (R = 8192 seqs x 128 steps x 4 agents rows), HIP-event timed.
-usage: python scripts/kbench.py [wgrad] [linear] [ret] [gru] [rows]"""
+usage: python scripts/kbench.py [wgrad] [linear] [ret] [gru] [rows] [loss]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -74,3 +74,13 @@ if "rows" in which:
     timeit("torch fill (write-only ref)", lambda: Y.fill_(1.0), 0, 4.0 * R * 128)
     Y2 = torch.empty_like(Y)
     timeit("torch copy (read+write ref)", lambda: Y2.copy_(Y), 0, 8.0 * R * 128)
+if "loss" in which:
+    K = 20
+    gl = torch.randn(R, 64, device=dev, generator=g); al = torch.randn(R, 64, device=dev, generator=g)
+    action = torch.randint(0, K, (R,), device=dev, generator=g, dtype=torch.int32)
+    old = torch.randn(R, device=dev, generator=g) * 0.1 - 3.0; vold = torch.randn(R, device=dev, generator=g); val = vold + 0.1 * torch.randn(R, device=dev, generator=g)
+    adv = torch.randn(R, device=dev, generator=g); tgt = torch.randn(R, device=dev, generator=g)
+    stats = torch.tensor([0.0, 1.0], device=dev); ws = torch.empty(8 * 1024, device=dev, dtype=torch.float64); lo = torch.empty(9, device=dev)
+    dg = torch.empty(R, 64, device=dev); da = torch.empty(R, 64, device=dev); dv = torch.empty(R, device=dev)
+    timeit("loss_fwd_bwd (K=20, 64-wide rows)", lambda: L.call("magpo_loss_fwd_bwd", gl, 64, al, 64, None, action, old, vold, val, adv, tgt, stats, dg, 64, da, 64, dv, ws, lo,
+           R, K, 0.2, 3.0, 0.01, 0.5, 1.0, st), 0, 4.0 * R * (4 * 64 + 8))
