@@ -86,9 +86,10 @@ def get_eval_fn(eval_env, act_fn: Callable, config, absolute_metric: bool, devic
             state = {"hidden_state": init_act_state["hidden_state"].clone()}
             got = torch.zeros(n_envs, dtype=torch.bool, device=device)
             ep_ret, ep_len = f32(n_envs), i32(n_envs)
+            step_key = key   # the scan's carried key is discarded by _episode (evaluator.py:140,150): loop 2 continues from ``key``
             for _t in range(TL + 1):
-                ks = host_split(key, 2)
-                key, act_key = ks[0], ks[1]
+                ks = host_split(step_key, 2)
+                step_key, act_key = ks[0], ks[1]
                 action, state = act_fn(params, obs, done, act_key, state)
                 env.step(action, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=False)
                 first = done.bool() & ~got

@@ -343,9 +343,11 @@ class MagpoLearner:
                     m["value"], m["logp"], m["adv"], m["targets"], m["h0idx"], T, N, A, F, K, mb, self._st())
         return m
 
-    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group: int = 0):
+    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group: int = 0, hs_idx: Optional[torch.Tensor] = None):
         """Forward + loss + backward of both networks for one minibatch of one group; gradients land in
-        guider.grads / actor.grads, loss scalars in self.loss_out (all inside self.grad_all, on device)."""
+        guider.grads / actor.grads, loss scalars in self.loss_out (all inside self.grad_all, on device).
+        ``hs_idx`` [mb]: env whose rollout-start Sable states sequence j trains on (quirk B19: in the reference
+        it differs from ``env_idx`` after the first PPO epoch); default = ``env_idx``."""
         s, T, A, K = self.sys, self.T, self.A, self.K
         g = self.groups[group]
         m = self._gather(g, env_idx, agent_perm)
@@ -356,7 +358,8 @@ class MagpoLearner:
             side.wait_stream(main)  # minibatch gather (and the previous optimiser step) are complete for the actor
             with torch.cuda.stream(side):
                 a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T)
-        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], g.prev_sable_hs, env_idx, mb, T)
+        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], g.prev_sable_hs,
+                                                env_idx if hs_idx is None else hs_idx, mb, T)
         if side is not None:
             main.wait_stream(side)
         else:
@@ -400,6 +403,11 @@ class MagpoLearner:
         mbs = N // M
         U = len(self.groups)
         losses = torch.zeros(s.ppo_epochs, M, 9, device=self.dev)
+        # Quirk B19 (rec_magpo.py:437,447,471): the reference shuffles prev_hstates by batch_perm and carries the SHUFFLED
+        # arrays into the next epoch, so epoch e reads state row hs_idx_e[i] = hs_idx_{e-1}[batch_perm_e[i]] for
+        # sequence i while the trajectory is gathered by batch_perm_e alone.  Only the index is composed; the 48 KiB
+        # states never move.
+        hs_idx = None
         for e in range(s.ppo_epochs):
             # every group holds the same key => one permutation serves all groups
             ks = host_split(self.groups[0].key, 4)
@@ -408,15 +416,17 @@ class MagpoLearner:
                 g.key = ks[0].copy()
             batch_perm = self._permutation(kb, N)
             agent_perm = self._permutation(ka, A)
+            hs_idx = batch_perm if hs_idx is None else hs_idx[batch_perm.long()].contiguous()
             for mi in range(M):
                 ke = host_split(ke, 2)[0]  # key, entropy_key = split(key): unused for discrete actions (:373)
                 idx = batch_perm[mi * mbs:(mi + 1) * mbs].contiguous()
+                hidx = hs_idx[mi * mbs:(mi + 1) * mbs].contiguous()
                 if U == 1:
-                    self.minibatch_grads(idx, agent_perm, 0)
+                    self.minibatch_grads(idx, agent_perm, 0, hidx)
                 else:  # pmean over the "batch" axis (:395-397): accumulate, the 1/U goes into grad_scale
                     self.grad_acc.zero_()
                     for gi in range(U):
-                        self.minibatch_grads(idx, agent_perm, gi)
+                        self.minibatch_grads(idx, agent_perm, gi, hidx)
                         self.grad_acc.add_(self.grad_all)
                     self.grad_all.copy_(self.grad_acc)
                 scale = (grad_sync(self) if grad_sync is not None else 1.0) / U

@@ -211,8 +211,14 @@ class OracleLearner:
         return out
 
     # -- training ---------------------------------------------------------------------------
-    def make_minibatches(self, batch_perm: np.ndarray, agent_perm: np.ndarray):
-        """rec_magpo.py:441-462: take env axis, take agent axis, concat time & agents, split."""
+    def make_minibatches(self, batch_perm: np.ndarray, agent_perm: np.ndarray, prev_hstates=None):
+        """rec_magpo.py:441-462: take env axis, take agent axis, concat time & agents, split.
+
+        ``prev_hstates`` is the epoch carry of rec_magpo.py:437: the reference rebinds
+        ``prev_hstates = take(prev_hstates, batch_perm)`` (:447) and puts the SHUFFLED arrays back into
+        ``update_state`` (:471), so the rollout-start Sable states are permuted cumulatively across the
+        PPO epochs while the trajectory is always shuffled from its original order (quirk B19).  The
+        shuffled states are left in ``self._epoch_prev_hs`` for the next epoch; None = first epoch."""
         M = self.sys.num_minibatches
         bp = torch.from_numpy(batch_perm.astype(np.int64))
         apm = torch.from_numpy(agent_perm.astype(np.int64))
@@ -226,7 +232,9 @@ class OracleLearner:
             return x.reshape(M, N // M, *x.shape[1:])
 
         fields = {k: prep(tr[k]) for k in ("done", "action", "value", "log_prob", "obs", "step_count", "mask", "adv", "targets")}
-        prev = tuple(h.index_select(0, bp).reshape(M, N // M, *h.shape[1:]) for h in self.prev_sable_hs)
+        carried = self.prev_sable_hs if prev_hstates is None else prev_hstates
+        self._epoch_prev_hs = tuple(h.index_select(0, bp) for h in carried)          # :447, carried by :471
+        prev = tuple(h.reshape(M, N // M, *h.shape[1:]) for h in self._epoch_prev_hs)
         h0 = self.policy_h0.index_select(0, bp).index_select(1, apm).reshape(M, N // M, *self.policy_h0.shape[1:])
         mbs = []
         for m in range(M):
@@ -256,12 +264,15 @@ class OracleLearner:
         """_update_epoch x ppo_epochs (rec_magpo.py:214-487)."""
         sys = self.sys
         infos = []
+        prev_hstates = None   # update_state[-1] = prev_sable_hstates (:474-482)
         for _ in range(sys.ppo_epochs):
             ks = prng.split(self.key, 4)
             self.key, kb, ka, ke = ks[0], ks[1], ks[2], ks[3]
             batch_perm = prng.permutation(kb, self.N)
             agent_perm = prng.permutation(ka, self.spec.num_agents)
-            for mb in self.make_minibatches(batch_perm, agent_perm):
+            mbs = self.make_minibatches(batch_perm, agent_perm, prev_hstates)
+            prev_hstates = self._epoch_prev_hs
+            for mb in mbs:
                 ke = prng.split(ke, 2)[0]  # key, entropy_key = split(key) (:373), unused for discrete
                 gg, ag, info, _ = self.minibatch_grads(mb)
                 if grad_hook is not None:

@@ -53,6 +53,10 @@ def env_fixture():
                         final_target=st["target"], final_record=st["record"], final_key=st["key"])
 
 
+N_STEPS = 3   # consecutive update steps: from step 2 on the rollout starts from non-zero retention states, so the
+              # cumulative prev_hstates permutation of rec_magpo.py:437-471 (quirk B19) changes the results
+
+
 def learner_fixture():
     A, K, TL, maxval, N, T = 2, 6, 5, 9, 4, 8
     gp = onets.init_guider_params(11, 64, A + 1, K)
@@ -61,18 +65,25 @@ def learner_fixture():
                               onets.SableCfg(A, K, A + 1), gp, ap)
     key = oprng.split(oprng.prng_key(3), 4)[0]
     ol.setup(key)
-    ol.rollout()
-    tr = {k: ol.traj[k].numpy() for k in ("action", "value", "log_prob", "reward", "adv", "targets")}
-    ol.update()
-    out = dict(cfg=np.array([A, K, TL, maxval, N, T]), key=key, key_after=ol.key, **{"traj_" + k: v for k, v in tr.items()})
+    out = dict(cfg=np.array([A, K, TL, maxval, N, T]), key=key, n_steps=np.array(N_STEPS))
+
     # initial parameters are regenerated from their seeds (11, 12); they are pinned here by checksums.
     # Post-update parameters are pinned by (sum, sum |.|, first 8 elements) per tensor to keep the fixture small.
     def stat(v):
         x = v.double().reshape(-1)
         return np.concatenate([[x.sum().item(), x.abs().sum().item()], x[:8].numpy(), np.zeros(max(0, 8 - x.numel()))])
-    for tag, d in (("gp0", gp), ("ap0", ap), ("gp1", ol.gp), ("ap1", ol.ap)):
+    for tag, d in (("gp0", gp), ("ap0", ap)):
         for n, v in d.items():
             out[tag + "/" + n] = stat(v)
+    for s in range(1, N_STEPS + 1):
+        ol.rollout()
+        for k in ("action", "value", "log_prob", "reward", "adv", "targets"):
+            out[f"s{s}_traj_{k}"] = ol.traj[k].numpy()
+        ol.update()
+        out[f"s{s}_key_after"] = ol.key
+        for tag, d in ((f"gp{s}", ol.gp), (f"ap{s}", ol.ap)):
+            for n, v in d.items():
+                out[tag + "/" + n] = stat(v)
     np.savez_compressed(os.path.join(OUT, "learner.npz"), **out)
 
 

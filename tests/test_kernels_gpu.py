@@ -315,39 +315,64 @@ def _ret_reference(q, k, v, s0, dones_t, A, kappa, masked):
     return ((q @ k.transpose(1, 2)) * D) @ v + (q @ s0) * xi
 
 
-@pytest.mark.parametrize("A,T,masked", [(4, 40, 1), (4, 128, 0), (2, 50, 1), (3, 45, 1), (8, 24, 0), (5, 30, 1)])
-def test_retention_chunk(L, stream, A, T, masked):
+@pytest.mark.parametrize("A,T,masked,hs", [(4, 40, 1, 64), (4, 128, 0, 64), (2, 50, 1, 64), (3, 45, 1, 64), (8, 24, 0, 64), (5, 30, 1, 64),
+                                           # BASELINE config 5 / the 5x20 scenario at the default rollout length: 16 and 10 chunks, i.e. more
+                                           # than the 8 whose decay bookkeeping is built once per workgroup (the per-chunk `!pre` branch)
+                                           (8, 128, 0, 64), (8, 128, 1, 64), (5, 128, 0, 64), (5, 128, 1, 64),
+                                           # narrow heads (n_head 2 / 4) over >= 3 chunks with a non-zero carried state: the padded-head
+                                           # inter-chunk state hand-off, forward and backward
+                                           (4, 48, 1, 32), (4, 48, 0, 16), (3, 70, 1, 16), (8, 128, 1, 32), (5, 128, 0, 16)])
+def test_retention_chunk(L, stream, A, T, masked, hs):
     g = torch.Generator().manual_seed(5)
     B, kappa = 5, 0.775
     C = T * A
-    q, k, v, dr = (torch.randn(B, C, 64, generator=g) * 0.5 for _ in range(4))
-    s0 = torch.randn(B, 64, 64, generator=g) * 0.3
-    dones = torch.rand(B, T, generator=g) < 0.08
+    q, k, v, dr = (torch.randn(B, C, hs, generator=g) * 0.5 for _ in range(4))
+    s0 = torch.randn(B, hs, hs, generator=g) * 0.3
+    dones = torch.rand(B, T, generator=g) < (0.08 if T < 100 else 0.02)
     dones[0, 0] = True
     dones[1, :] = False
+    dones[2, :] = False; dones[2, T // 2] = True     # exactly one episode start in the middle
     qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
     ref = _ret_reference(qd, kd, vd, s0.double(), dones, A, kappa, bool(masked))
     (ref * dr.double()).sum().backward()
     nch = L.call("magpo_retention_num_chunks", T, A)
-    # q, k, v live in one [R, 256] buffer like the fused projection output
-    buf = torch.zeros(B * C, 256, device=DEV)
-    buf[:, 0:64] = dev(q.reshape(-1, 64)); buf[:, 64:128] = dev(k.reshape(-1, 64)); buf[:, 128:192] = dev(v.reshape(-1, 64))
-    r = torch.zeros(B * C, 64, device=DEV)
+    assert nch >= 3 or hs == 64
+    # q, k, v live in one [R, 256] buffer like the fused projection output; with narrow heads the neighbouring columns hold the
+    # other heads' data (random here): the kernel must neither read them into the product nor write over them
+    buf = dev(torch.randn(B * C, 256, generator=g))
+    buf[:, 0:hs] = dev(q.reshape(-1, hs)); buf[:, 64:64 + hs] = dev(k.reshape(-1, hs)); buf[:, 128:128 + hs] = dev(v.reshape(-1, hs))
+    drb = dev(torch.randn(B * C, 64, generator=g))
+    drb[:, :hs] = dev(dr.reshape(-1, hs))
+    r = torch.full((B * C, 64), 7.0, device=DEV)
     states = torch.zeros(B, nch, 64, 64, device=DEV)
     sfin = torch.zeros(B, 64, 64, device=DEV)
     perm = torch.tensor([3, 1, 4, 0, 2], dtype=torch.int32)
-    s0_store = torch.zeros(B, 64, 64)
-    s0_store[perm.long()] = s0
+    s0_store = torch.zeros(B, 64, 64)     # device head states are zero-padded to 64 x 64
+    s0_store[perm.long(), :hs, :hs] = s0
     dn = dev(dones.to(torch.uint8))
     L.call("magpo_retention_chunk_fwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, r, 64, dev(s0_store), dev(perm),
-           dn, states, sfin, B, T, A, masked, kappa, 64, stream)
-    close(r.reshape(B, C, 64), ref, 1e-4, 1e-5, "ret fwd")
-    dbuf = torch.zeros(B * C, 256, device=DEV)
-    L.call("magpo_retention_chunk_bwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, dev(dr.reshape(-1, 64)), 64,
-           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, 64, stream)
-    close(dbuf[:, 0:64].reshape(B, C, 64), qd.grad, 1e-4, 1e-5, "dq")
-    close(dbuf[:, 64:128].reshape(B, C, 64), kd.grad, 1e-4, 1e-5, "dk")
-    close(dbuf[:, 128:192].reshape(B, C, 64), vd.grad, 1e-4, 1e-5, "dv")
+           dn, states, sfin, B, T, A, masked, kappa, hs, stream)
+    close(r[:, :hs].reshape(B, C, hs), ref, 1e-4, 1e-5, "ret fwd")
+    if hs < 64:
+        assert bool((r[:, hs:] == 7.0).all()), "columns of the neighbouring heads were written"
+    dbuf = torch.full((B * C, 256), 9.0, device=DEV)
+    L.call("magpo_retention_chunk_bwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, drb, 64,
+           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, stream)
+    close(dbuf[:, 0:hs].reshape(B, C, hs), qd.grad, 1e-4, 1e-5, "dq")
+    close(dbuf[:, 64:64 + hs].reshape(B, C, hs), kd.grad, 1e-4, 1e-5, "dk")
+    close(dbuf[:, 128:128 + hs].reshape(B, C, hs), vd.grad, 1e-4, 1e-5, "dv")
+    if hs < 64:
+        for o in (0, 64, 128):
+            assert bool((dbuf[:, o + hs:o + 64] == 9.0).all()), "gradient columns of the neighbouring heads were written"
+    # the state after the last token (next-chunk hand-off, retention.py:88-92) against the recurrent form
+    S = s0.double()
+    for t in range(T):
+        for b in range(B):
+            if dones[b, t]:
+                S[b] = 0
+        kt = k.double().reshape(B, T, A, hs)[:, t]; vt = v.double().reshape(B, T, A, hs)[:, t]
+        S = kappa * S + kt.transpose(1, 2) @ vt
+    close(sfin[:, :hs, :hs], S, 1e-4, 1e-5, "final state")
 
 
 def test_retention_recurrent(L, stream):

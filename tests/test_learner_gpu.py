@@ -99,10 +99,29 @@ def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh):
     for n, v in dl.actor.named.items():
         close(v, ol.ap[n].reshape(v.shape), 0, 3e-5, f"actor param {n}")
     close(losses[-1, -1, 1], torch.tensor(oinfos[-1]["value_loss"]), 5e-3, 1e-5, "final value loss")
-    # second update step keeps working on carried-over state
+    # ---- update steps 2 and 3 against the oracle: carried-over env / hidden state, non-zero rollout-start retention
+    # states (so the cumulative prev_hstates permutation of rec_magpo.py:437-471, quirk B19, changes the result),
+    # Adam counts > P*M, and from step 3 on the HIP-graph replay of the rollout
     dl._carry_over()
-    dl.update_step()
-    assert torch.isfinite(dl.guider.P.flat).all() and torch.isfinite(dl.actor.P.flat).all()
+    for s in (2, 3):
+        om = ol.rollout()
+        dl.rollout()
+        assert np.array_equal(dl.traj["action"].cpu().numpy(), ol.traj["action"].numpy()), f"update step {s}: sampled actions differ"
+        assert np.array_equal(dl.traj["reward"].cpu().numpy(), ol.traj["reward"].numpy())
+        # (the parameters entering this rollout agree to 3e-5 * (s - 1), so activations agree to ~1e-3 relative, not 1e-4)
+        close(dl.traj["value"], ol.traj["value"], 1e-3, 2e-5, f"value (step {s})")
+        close(dl.traj["adv"], ol.traj["adv"], 1e-3, 1e-4, f"adv (step {s})")
+        for k in ("episode_return", "episode_length"):
+            assert np.array_equal(dl.metrics[k].cpu().numpy(), om[k]), (s, k)
+        ol.update()
+        dl.update()
+        dl._carry_over()
+        assert np.array_equal(dl.key, ol.key)
+        for n, v in dl.guider.named.items():
+            close(v, ol.gp[n].reshape(v.shape), 0, 3e-5 * s, f"guider param {n} (step {s})")
+        for n, v in dl.actor.named.items():
+            close(v, ol.ap[n].reshape(v.shape), 0, 3e-5 * s, f"actor param {n} (step {s})")
+    assert dl.groups[0].graph is not None, "the third rollout should have been a HIP-graph capture/replay"
 
 
 def test_graph_replay_equals_eager_rollout():
