@@ -27,6 +27,7 @@ import torch
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 PEAK_F32_MFMA_TF = 157.3   # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_f32)
+PMC_FILE = "r02_pmc_hbm_traffic.json"   # offline PMC passes (scripts/pmc_kernels.py + scripts/pmc_collect.py)
 
 
 class KernelTimer:
@@ -89,13 +90,25 @@ class KernelTimer:
         if name == "magpo_seg_bwd":
             R = a[0]
             return "k_seg_bwd", 4.0 * R * 64 * 9, 2.0 * R * 64 * 64
+        if name == "magpo_sable_act":
+            import ctypes
+            d = (ctypes.c_int * 10).from_address(a[0])
+            N, A, nb, nh, hs, value_only = d[0], d[1], d[4], d[5], d[6], d[9]
+            if value_only or N < 1024:
+                return None
+            # the three retention states read + written once per env step = 2 * 3 * nb * nh * hs^2 * 4 B per env
+            # (98 304 B at E = 64, one block, one head).  Everything else the launch touches (obs, weights, outputs) is < 1 %.
+            state = 4.0 * nb * nh * hs * hs
+            return f"k_sable_act<{A}>", 6.0 * state * N, N * A * (46.0 * 64 * 64 + 12.0 * 64 * 64 / nh)
         if name == "magpo_loss_fwd_bwd":
             R, K = a[19], a[20]
             return "k_magpo_loss", 4.0 * R * (4 * K + 8), 60.0 * R * K
         return None
 
+    only = None   # restrict timing to these entry points (set-up pass for the acting kernel)
+
     def begin(self, name, args):
-        if not self.enabled or torch.cuda.is_current_stream_capturing():
+        if not self.enabled or torch.cuda.is_current_stream_capturing() or (self.only is not None and name not in self.only):
             return None
         m = self._model(name, args)
         if m is None:
@@ -120,10 +133,14 @@ class KernelTimer:
             r["flops"] += flops
         self.pending = []
 
-    def dominant(self):
+    def dominant(self, steps: int = 1, once_per_step=()):
+        """``once_per_step``: keys whose record covers exactly ONE update step (the acting kernel, timed on one eager rollout
+        in the untimed set-up because inside the timed region it runs inside the rollout's HIP graph); the others cover
+        ``steps`` update steps of the timed region.  The dominant kernel is the one with the most time per update step."""
         if not self.rec:
             return None, None
-        key = max(self.rec, key=lambda k: self.rec[k]["ms"])
+        per_step = lambda k: self.rec[k]["ms"] / (1 if k in once_per_step else max(1, steps))
+        key = max(self.rec, key=per_step)
         r = self.rec[key]
         avg_s = r["ms"] / r["calls"] / 1e3
         gbs = r["bytes"] / r["calls"] / avg_s / 1e9
@@ -133,27 +150,34 @@ class KernelTimer:
             roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
         else:
             roof = dict(bound="mfma", achieved=round(tfs, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(tfs / PEAK_F32_MFMA_TF, 4))
-        roof.update(kernel=key, avg_us=round(avg_s * 1e6, 1), calls=r["calls"], traffic=None,
-                    algorithmic_bytes_per_launch=round(r["bytes"] / r["calls"]))
+        roof.update(kernel=key, avg_us=round(avg_s * 1e6, 1), calls=r["calls"], ms_per_update_step=round(per_step(key), 2), traffic=None,
+                    traffic_source=None, algorithmic_bytes_per_launch=round(r["bytes"] / r["calls"]),
+                    timing=("HIP events around each launch of one eager rollout in the untimed set-up (inside the timed region this kernel "
+                            "runs inside the rollout's HIP graph, whose replays are timed as a whole: see rollout_graph_ms_per_step)"
+                            if key in once_per_step else "HIP events around every launch inside the timed region"))
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; same
         # workload, profiles/r01_pmc_hbm_traffic.json, made by scripts/pmc_kernels.py + scripts/pmc_collect.py).  Only attached when the kernel family matches.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 pmc = json.load(f)
-            name = key   # timer keys are the rocprof kernel names (template arguments without spaces)
-            if name in pmc and getattr(self, "attach_traffic", True):
-                roof["traffic"] = round(pmc[name]["total"])
+            name = key.split("<")[0] if key.startswith("k_sable_act") else key   # timer keys are the rocprof kernel names
+            cand = [k for k in pmc if k == name or (name == "k_sable_act" and k.startswith("k_sable_act"))]
+            if cand and getattr(self, "attach_traffic", True):
+                roof["traffic"] = round(max(pmc[k]["total"] for k in cand))
+                roof["traffic_source"] = (f"profiles/{PMC_FILE}: offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs) "
+                                          "of this workload; NOT measured in this run")
         except (OSError, ValueError):
             pass
-        table = {k: dict(calls=v["calls"], ms=round(v["ms"], 2), gbs=round(v["bytes"] / v["ms"] / 1e6, 1),
-                         tflops=round(v["flops"] / v["ms"] / 1e9, 2)) for k, v in sorted(self.rec.items(), key=lambda kv: -kv[1]["ms"])}
+        table = {k: dict(calls=v["calls"], ms=round(v["ms"], 2), ms_per_step=round(per_step(k), 2), gbs=round(v["bytes"] / v["ms"] / 1e6, 1),
+                         tflops=round(v["flops"] / v["ms"] / 1e9, 2)) for k, v in sorted(self.rec.items(), key=lambda kv: -per_step(kv[0]))}
         return roof, table
 
 
-def cpu_baseline(seconds_budget: float = 20.0):
+def cpu_baseline(seconds_budget: float = 12.0):
     """The CPU oracle (a torch-CPU port of the reference loop; the reference's own JAX path cannot run here:
     jax / flax / jumanji are not installed) timed on this box's host cores on a bounded sample of the same
-    workload: CoordSum-4ag, same network sizes, rollout_length=128, 4 epochs x 2 minibatches, 16 envs."""
+    workload: CoordSum-4ag, same network sizes, rollout_length=128, 4 epochs x 2 minibatches, 256 envs (SURVEY 8(d) asks for
+    N in {4, 64, 1024}; at 256 envs the torch-CPU kernels are no longer launch-bound and one update step takes ~10 s)."""
     from oracle import coordsum as ocs
     from oracle import learner as olearn
     from oracle import networks as onets
@@ -164,7 +188,7 @@ def cpu_baseline(seconds_budget: float = 20.0):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))  # the GPU box gives one GPU a 16-core share; more threads only oversubscribe
     torch.set_num_threads(cores)
-    A, K, N = 4, 20, 16
+    A, K, N = 4, 20, 256
     ol = olearn.OracleLearner(ocs.CoordSumSpec(A, K, 100, 60), N, olearn.SystemCfg(), onets.SableCfg(A, K, A + 1),
                               onets.init_guider_params(1, 64, A + 1, K), onets.init_actor_params(2, A + 1, 128, K))
     ol.setup(oprng.split(oprng.prng_key(42), 4)[0])
@@ -173,7 +197,7 @@ def cpu_baseline(seconds_budget: float = 20.0):
     while True:
         ol.update_step()
         steps += 1
-        if time.time() - t0 > seconds_budget or steps >= 8:
+        if time.time() - t0 > seconds_budget or steps >= 3:
             break
     dt = time.time() - t0
     return dict(value=round(steps * N * 128 / dt, 1), unit="env-steps/s", cores=cores, kind="port",
@@ -255,9 +279,30 @@ def main():
         log(f"warmup step {i} done")
     timer = KernelTimer(min_rows=1 << 16)
     timer.attach_traffic = args.workload == "coordsum-4ag" and N == 16384  # the PMC passes were taken on that workload
-    if not args.no_kernel_timing and rank == 0:
-        lib().timer = timer
-        timer.enabled = True
+    timing = not args.no_kernel_timing and rank == 0
+    act_keys = ()
+    if timing and learner.fused_act and env_cfg.num_agents <= 8:
+        # The acting kernel runs inside the rollout's HIP graph, where per-launch events cannot be recorded: time it on one
+        # EAGER rollout here (same kernel, same shapes, same data distribution), still outside the timed region.  Every rank
+        # runs this extra update step so that the replicas stay in lock-step.
+        lib().timer, timer.enabled, timer.only = timer, True, ("magpo_sable_act",)
+    learner.use_graph = False
+    learner.update_step(grad_sync)
+    learner.use_graph = True
+    if timing:
+        timer.collect()
+        act_keys = tuple(timer.rec)
+        timer.only = None
+    roll_events = []
+    if timing:
+        lib().timer, timer.enabled = timer, True
+        orig_rollout = learner.rollout
+
+        def timed_rollout():   # events around the graph replay(s) of the rollout (acting + env + actor carry + GAE)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); orig_rollout(); e1.record()
+            roll_events.append((e0, e1))
+        learner.rollout = timed_rollout
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -274,7 +319,8 @@ def main():
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     if rank == 0:
         timer.collect()
-        roof, table = timer.dominant()
+        roof, table = timer.dominant(args.steps, act_keys)
+        rollout_ms = round(sum(e0.elapsed_time(e1) for e0, e1 in roll_events) / max(1, len(roll_events)), 2) if roll_events else None
         env_steps = world * N * sysc.rollout_length * args.steps
         out = {
             "metric": f"env-steps/sec (all agents stepping jointly), CoordSum-{env_cfg.num_agents}ag, full MAGPO update loop",
@@ -295,6 +341,7 @@ def main():
                        "agent_steps_per_s": round(env_steps * env_cfg.num_agents / elapsed, 1),
                        "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},
             "roofline": roof,
+            "rollout_graph_ms_per_step": rollout_ms,
             "kernel_table": table,
         }
         if world == 1 and not args.no_cpu_baseline:

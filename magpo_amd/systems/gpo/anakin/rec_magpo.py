@@ -29,7 +29,7 @@ from magpo_amd.evaluator import get_eval_fn, get_num_eval_envs, make_rec_eval_ac
 from magpo_amd.learner import MagpoLearner, SystemConfig, host_split, prng_key
 from magpo_amd.types import ExperimentOutput, GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
 from magpo_amd.utils import make_env as environments
-from magpo_amd.utils.checkpointing import Checkpointer
+from magpo_amd.utils.checkpointing import Checkpointer, restore_learner_state
 from magpo_amd.utils.config import check_total_timesteps
 from magpo_amd.utils.logger import LogEvent, MavaLogger
 
@@ -46,30 +46,66 @@ def _system_config(config) -> SystemConfig:
                         alpha=float(s.alpha), actor_lr=float(s.actor_lr))
 
 
+_ENV_FIELDS = ("step_count", "target", "record", "key", "metrics_key", "run_ret", "run_len", "ep_ret", "ep_len")
+
+
 def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:
-    """LearnerState view of the learner.  Parameters and optimiser moments are CLONED so that the state a caller
-    holds stays readable after the next learn() call (the harness evaluates the pre-interval parameters,
-    rec_magpo.py:770); rollout state leaves are live views."""
-    g0 = learner.groups[0]
+    """LearnerState of the learner as an independent COPY (rec_magpo.py:488-497): the state a caller holds stays readable
+    and re-usable after later learn() calls (the harness evaluates the pre-interval parameters, rec_magpo.py:770, SURVEY
+    B12; a checkpoint of it can be resumed).  Leaves carry a leading group axis (the reference's update-batch axis)."""
+    gs = learner.groups
     params = Params({k: v.clone() for k, v in learner.guider.named.items()}, {k: v.clone() for k, v in learner.actor.named.items()})
     opt = OptStates(dict(count=learner.g_count, mu=learner.g_mu.clone(), nu=learner.g_nu.clone()),
                     dict(count=learner.a_count, mu=learner.a_mu.clone(), nu=learner.a_nu.clone()))
-    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i] for g in learner.groups]) for i in range(3)]),
-                      torch.stack([g.policy_h[g.cur] for g in learner.groups]))
-    env_state = [dict(step_count=g.env.step_count, target=g.env.target, record=g.env.record, key=g.env.key) for g in learner.groups]
-    timestep = [dict(agents_view=g.traj["obs"][0], step_count=g.traj["step_count"][0]) for g in learner.groups]
-    dones = torch.stack([g.traj["done"][0] for g in learner.groups])
-    return GPOLearnerState(params, opt, g0.key.copy(), env_state, timestep, dones, hs)
+    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i] for g in gs]) for i in range(3)]),
+                      torch.stack([g.policy_h[g.cur] for g in gs]))
+    env_state = {f: torch.stack([getattr(g.env, f) for g in gs]) for f in _ENV_FIELDS}
+    timestep = dict(agents_view=torch.stack([g.traj["obs"][0] for g in gs]), step_count=torch.stack([g.traj["step_count"][0] for g in gs]))
+    dones = torch.stack([g.traj["done"][0] for g in gs])
+    return GPOLearnerState(params, opt, gs[0].key.copy(), env_state, timestep, dones, hs)
+
+
+def load_learner_state(learner: MagpoLearner, state: GPOLearnerState) -> None:
+    """Inverse of ``_snapshot_state``: write every leaf of ``state`` into the learner's (static, graph-captured) buffers."""
+    as_dict = lambda x: x if isinstance(x, dict) else x._asdict()
+    params, opt, hst = as_dict(state.params), as_dict(state.opt_states), as_dict(state.hstates)
+    learner.guider.load_named(params["guider_params"])
+    learner.actor.load_named(params["actor_params"])
+    g, a = opt["guider_opt_state"], opt["actor_opt_state"]
+    learner.g_mu.copy_(g["mu"]); learner.g_nu.copy_(g["nu"]); learner.g_count = int(g["count"])
+    learner.a_mu.copy_(a["mu"]); learner.a_nu.copy_(a["nu"]); learner.a_count = int(a["count"])
+    sable = as_dict(hst["sable_hidden_state"])
+    sable = (sable["encoder"], sable["decoder_self_retn"], sable["decoder_cross_retn"])
+    if state.dones.shape[0] != len(learner.groups):
+        raise ValueError(f"learner state holds {state.dones.shape[0]} env groups, the learner {len(learner.groups)}")
+    for gi, grp in enumerate(learner.groups):
+        for f in _ENV_FIELDS:
+            getattr(grp.env, f).copy_(state.env_state[f][gi])
+        grp.traj["obs"][0].copy_(state.timestep["agents_view"][gi])
+        grp.traj["step_count"][0].copy_(state.timestep["step_count"][gi])
+        grp.traj["done"][0].copy_(state.dones[gi])
+        for i in range(3):
+            grp.sable_hs[i].copy_(sable[i][gi])
+        grp.policy_h[grp.cur].copy_(hst["policy_hidden_state"][gi])
+        grp.key = np.array(state.key, dtype=np.uint32).copy()
 
 
 def get_learner_fn(env, apply_fns, update_fn, config):
     """Returns ``learn(learner_state) -> ExperimentOutput``: ``config.system.num_updates_per_eval`` update steps
-    (rec_magpo.py:501-528).  ``apply_fns`` carries the MagpoLearner that owns kernels and buffers; ``update_fn``
-    is the optional gradient-sync hook (RCCL all-reduce)."""
+    (rec_magpo.py:501-528).  In the reference ``apply_fns`` / ``update_fn`` are the networks' apply functions and the optax
+    update functions; here both roles are played by objects that own HIP kernels and their device buffers: ``apply_fns`` is
+    the MagpoLearner (guider + actor kernels), ``update_fn`` the optional gradient-sync hook (RCCL all-reduce) that runs
+    in front of the fused clip + Adam kernel.
+
+    State in, state out: the learner's device buffers are a cache of the last state it produced.  When ``learner_state``
+    is that state (the normal host loop, rec_magpo.py:754,792) nothing is copied; any other state (an older one, a restored
+    checkpoint) is loaded into the buffers first, so ``learn`` is a function of its argument."""
     learner: MagpoLearner = apply_fns
     grad_sync = update_fn
 
     def learner_fn(learner_state: GPOLearnerState) -> ExperimentOutput:
+        if learner_state is not getattr(learner, "_live_state", None):
+            load_learner_state(learner, learner_state)
         n_up = int(config.system.num_updates_per_eval)
         ep: Dict[str, List[np.ndarray]] = {"episode_return": [], "episode_length": [], "is_terminal_step": []}
         train = []
@@ -83,7 +119,8 @@ def get_learner_fn(env, apply_fns, update_fn, config):
         train_metrics = {n: tl[..., i] for i, n in enumerate(names)}
         episode_metrics = {k: np.stack(v) for k, v in ep.items()}
         episode_metrics["is_terminal_step"] = episode_metrics["is_terminal_step"].astype(bool)
-        return ExperimentOutput(_snapshot_state(learner), episode_metrics, train_metrics)
+        learner._live_state = _snapshot_state(learner)
+        return ExperimentOutput(learner._live_state, episode_metrics, train_metrics)
 
     return learner_fn
 
@@ -114,7 +151,8 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
     grad_sync = mdist.make_grad_sync(world)
     learn = get_learner_fn(env, learner, grad_sync, config)
     learn.learner = learner
-    return learn, learner.actor, _snapshot_state(learner)
+    learner._live_state = _snapshot_state(learner)
+    return learn, learner.actor, learner._live_state
 
 
 def run_experiment(_config) -> float:
@@ -146,6 +184,17 @@ def run_experiment(_config) -> float:
     if save_checkpoint:
         checkpointer = Checkpointer(metadata=config.to_container(), model_name=config.logger.system_name,
                                     base_path=config.logger.base_exp_path, **config.logger.checkpointing.save_args.to_container())
+    if bool(config.logger.checkpointing.load_model):
+        # Resume from the latest checkpoint of load_args.checkpoint_uid (the reference saves the full learner state,
+        # checkpointing.py:108-145, but rec_magpo.py never reads it back: this closes the loop for long sweeps).
+        import glob
+        import os
+        la = config.logger.checkpointing.load_args
+        cdir = os.path.join(config.logger.base_exp_path, la.rel_dir, config.logger.system_name, str(la.checkpoint_uid))
+        cands = sorted(glob.glob(os.path.join(cdir, "*.pt")), key=lambda f: int(os.path.basename(f)[:-3]))
+        if not cands:
+            raise FileNotFoundError(f"load_model=True but no checkpoint under {cdir}")
+        learner_state, _ = restore_learner_state(cands[-1], device)
     eval_batch = get_num_eval_envs(config, absolute_metric=False, n_devices=n_devices)
     eval_hs = {"hidden_state": torch.zeros(eval_batch * env.num_agents, 128, device=device)}
 

@@ -63,14 +63,32 @@ class Checkpointer:
         return True
 
 
-def restore_learner_state(path: str, learner) -> int:
-    """Load parameters, optimiser moments and counters of a checkpoint into a MagpoLearner; returns its timestep.
-    Rollout state (envs, hidden states, PRNG key) restarts from the learner's current setup, as a fresh run would."""
+def restore_learner_state(path: str, device="cuda"):
+    """Load a checkpoint written by ``Checkpointer.save`` and rebuild the full GPOLearnerState on ``device``: parameters,
+    optimiser moments and counters, PRNG key, env state, last timestep / dones and both hidden states -- everything
+    ``learn(state)`` needs to continue bit-identically (mava/utils/checkpointing.py:108-145 saves exactly this pytree; the
+    reference's own ``restore_params`` :147-198 reads back only params / hidden states).  Returns (state, timestep)."""
+    from ..types import GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
     ck = torch.load(path, map_location="cpu", weights_only=False)
     st = ck["learner_state"]
-    learner.guider.load_named(st["params"]["guider_params"])
-    learner.actor.load_named(st["params"]["actor_params"])
-    g, a = st["opt_states"]["guider_opt_state"], st["opt_states"]["actor_opt_state"]
-    learner.g_mu.copy_(g["mu"]); learner.g_nu.copy_(g["nu"]); learner.g_count = int(g["count"])
-    learner.a_mu.copy_(a["mu"]); learner.a_nu.copy_(a["nu"]); learner.a_count = int(a["count"])
-    return int(ck["timestep"])
+
+    def dev(x):
+        if torch.is_tensor(x):
+            return x.to(device)
+        if isinstance(x, dict):
+            return {k: dev(v) for k, v in x.items()}
+        return x
+
+    hs = st["hstates"]
+    state = GPOLearnerState(Params(dev(st["params"]["guider_params"]), dev(st["params"]["actor_params"])),
+                            OptStates(dev(st["opt_states"]["guider_opt_state"]), dev(st["opt_states"]["actor_opt_state"])),
+                            st["key"], dev(st["env_state"]), dev(st["timestep"]), dev(st["dones"]),
+                            HiddenStates(SableHiddenStates(**dev(hs["sable_hidden_state"])), dev(hs["policy_hidden_state"])))
+    return state, int(ck["timestep"])
+
+
+def restore_params(path: str, restore_hstates: bool = False, device="cuda"):
+    """Checkpointer.restore_params (mava/utils/checkpointing.py:147-198): the parameters (and optionally the hidden states)
+    of a checkpoint."""
+    state, _ = restore_learner_state(path, device)
+    return state.params, (state.hstates if restore_hstates else None)

@@ -60,3 +60,60 @@ def test_two_groups_share_parameters_and_average_gradients():
     assert torch.allclose(two.guider.P.flat, singles[0].guider.P.flat, atol=1e-7)
     assert torch.allclose(two.actor.P.flat, singles[0].actor.P.flat, atol=1e-7)
     assert mean.abs().max() > 0
+
+
+def _small_cfg(tmp_path, seed, extra=()):
+    from magpo_amd.config import compose
+    return compose("rec_magpo", ["env=coordsum", "env/scenario=3x10-30", "arch.num_envs=6", "arch.num_evaluation=2", "arch.num_eval_episodes=6",
+                                 "system.total_timesteps=~", "system.num_updates=4", "system.rollout_length=12", "system.ppo_epochs=2",
+                                 "system.update_batch_size=2", "env.kwargs.time_limit=7", f"system.seed={seed}", f"logger.base_exp_path={tmp_path}/",
+                                 *extra])
+
+
+def _setup(cfg):
+    from magpo_amd.learner import host_split, prng_key
+    from magpo_amd.systems.gpo.anakin import rec_magpo
+    from magpo_amd.utils import make_env as environments
+    from magpo_amd.utils.config import check_total_timesteps
+    env, _ = environments.make(cfg)
+    ks = host_split(prng_key(int(cfg.system.seed)), 4)
+    learn, _, state = rec_magpo.learner_setup(env, (ks[0], ks[2], ks[3]), cfg, torch.device("cuda"))
+    cfg = check_total_timesteps(cfg, 1)
+    cfg.system.num_updates_per_eval = 1
+    return learn, state
+
+
+def _flat(state):
+    out = [state.params.guider_params[k] for k in sorted(state.params.guider_params)] + [state.params.actor_params[k] for k in sorted(state.params.actor_params)]
+    out += [state.opt_states.guider_opt_state["mu"], state.opt_states.actor_opt_state["nu"], state.hstates.policy_hidden_state,
+            *state.hstates.sable_hidden_state, state.dones, state.timestep["agents_view"], *[state.env_state[k] for k in sorted(state.env_state)]]
+    return [t.detach().cpu() for t in out]
+
+
+def test_learn_is_a_function_of_its_state_and_checkpoints_resume(tmp_path):
+    """LearnerFn contract (mava/types.py:207, rec_magpo.py:501-528): state in, state out.  (1) An OLD state can be passed again
+    and gives the same successor; (2) a checkpoint (mava/utils/checkpointing.py:108-145) restored into a learner that was set
+    up from a different seed continues bit-identically to the uninterrupted run: parameters, Adam moments, PRNG key, env state,
+    observation / dones and both hidden states all travel."""
+    from magpo_amd.utils.checkpointing import Checkpointer, restore_learner_state
+    learn, s0 = _setup(_small_cfg(tmp_path, 42))
+    s1 = learn(s0).learner_state
+    s2 = learn(s1).learner_state
+    ck = Checkpointer("rec_magpo", base_path=str(tmp_path), checkpoint_uid="resume")
+    ck.save(2, s2, episode_return=1.0)
+    s3 = learn(s2).learner_state
+    # (1) rewind: the learner's buffers hold s3 now, learn(s1) must reproduce s2 exactly
+    s2b = learn(s1).learner_state
+    assert np.array_equal(s2b.key, s2.key)
+    for a, b in zip(_flat(s2b), _flat(s2)):
+        assert torch.equal(a, b)
+    # (2) resume in a learner built from another seed (other parameters, env keys, step key)
+    learn2, t0 = _setup(_small_cfg(tmp_path, 7))
+    assert not torch.equal(_flat(t0)[0], _flat(s0)[0])
+    restored, ts = restore_learner_state(os.path.join(tmp_path, "checkpoints", "rec_magpo", "resume", "2.pt"), "cuda")
+    assert ts == 2
+    r3 = learn2(restored).learner_state
+    assert np.array_equal(r3.key, s3.key)
+    assert r3.opt_states.guider_opt_state["count"] == s3.opt_states.guider_opt_state["count"] == 12
+    for a, b in zip(_flat(r3), _flat(s3)):
+        assert torch.equal(a, b), "resumed run differs from the uninterrupted one"

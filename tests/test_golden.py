@@ -104,7 +104,7 @@ def test_hip_learner_matches_golden():
         dl.update()
         dl._carry_over()
         assert np.array_equal(dl.key, f[f"s{s}_key_after"])
-        tol = 3e-5 * s
+        tol = 3e-5 + 1e-4 * (s - 1)   # Adam turns tiny gradient differences into ~lr-sized steps (see test_learner_gpu.py)
         for n, v in dl.guider.named.items():
             st = _stat(v)
             assert np.allclose(st[2:], f[f"gp{s}/" + n][2:], atol=tol), (s, n)          # leading elements

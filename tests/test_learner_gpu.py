@@ -41,7 +41,10 @@ def close(a, b, rtol, atol, what):
 
 @pytest.mark.parametrize("A,K,TL,maxval,N,T,nb,nh", [(4, 20, 10, 60, 8, 16, 1, 1), (2, 10, 7, 15, 4, 12, 1, 1), (3, 10, 9, 30, 6, 11, 1, 1),
                                                        (4, 20, 10, 60, 8, 16, 2, 1), (8, 15, 9, 100, 4, 11, 3, 1),
-                                                       (5, 20, 9, 80, 4, 11, 2, 2), (3, 10, 9, 30, 6, 10, 1, 4)])
+                                                       (5, 20, 9, 80, 4, 11, 2, 2), (3, 10, 9, 30, 6, 10, 1, 4),
+                                                       # the default rollout length on BASELINE's shapes: 8 / 16 / 10 retention chunks per
+                                                       # sequence (more than 8 takes the per-chunk bookkeeping branch), narrow heads over 10 chunks
+                                                       (4, 20, 100, 60, 4, 128, 1, 1), (8, 15, 100, 100, 2, 128, 1, 1), (5, 20, 100, 80, 2, 128, 1, 2)])
 def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh):
     ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb, nh=nh)
     assert np.array_equal(dl.env.target.cpu().numpy(), ol.env_state["target"])
@@ -101,27 +104,44 @@ def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh):
     close(losses[-1, -1, 1], torch.tensor(oinfos[-1]["value_loss"]), 5e-3, 1e-5, "final value loss")
     # ---- update steps 2 and 3 against the oracle: carried-over env / hidden state, non-zero rollout-start retention
     # states (so the cumulative prev_hstates permutation of rec_magpo.py:437-471, quirk B19, changes the result),
-    # Adam counts > P*M, and from step 3 on the HIP-graph replay of the rollout
+    # Adam counts > P*M, and from step 2 on the HIP-graph capture / replay of the rollout.
+    # The update is a chaotic map of the parameters: for the 3-block net a 3e-6 parameter difference after step 1 changes
+    # the step-2 gradient of enc.block2.retn.w_k by 47 % -- reproduced inside the oracle alone by evaluating it at the
+    # device's parameters, where device and oracle agree to 8e-6 (scripts/debug/step2_sens.py).  So each further step is
+    # compared from a COMMON starting point: the oracle takes over the device's parameters and Adam moments (the drift
+    # up to there is bounded separately), while env state, PRNG keys, hidden states and trajectories keep running unsynced.
     dl._carry_over()
     for s in (2, 3):
+        drift = max((v.cpu() - ref[n].reshape(v.shape)).abs().max().item() for net, ref in ((dl.guider, ol.gp), (dl.actor, ol.ap))
+                    for n, v in net.named.items())
+        assert drift <= 3e-5, f"parameter drift entering update step {s}: {drift:.2e}"
+        for net, ref, opt, mu, nu in ((dl.guider, ol.gp, ol.g_opt, dl.g_mu, dl.g_nu), (dl.actor, ol.ap, ol.a_opt, dl.a_mu, dl.a_nu)):
+            mv, nv = net.P.views(mu), net.P.views(nu)
+            from magpo_amd.params import actor_named_views, guider_named_views
+            named = (lambda v: guider_named_views(v, 64, nh)) if net is dl.guider else actor_named_views
+            mn, nn = named(mv), named(nv)
+            for n in ref:
+                ref[n] = net.named[n].detach().cpu().reshape(ref[n].shape).clone()
+                opt["mu"][n] = mn[n].detach().cpu().reshape(ref[n].shape).clone()
+                opt["nu"][n] = nn[n].detach().cpu().reshape(ref[n].shape).clone()
         om = ol.rollout()
         dl.rollout()
         assert np.array_equal(dl.traj["action"].cpu().numpy(), ol.traj["action"].numpy()), f"update step {s}: sampled actions differ"
         assert np.array_equal(dl.traj["reward"].cpu().numpy(), ol.traj["reward"].numpy())
-        # (the parameters entering this rollout agree to 3e-5 * (s - 1), so activations agree to ~1e-3 relative, not 1e-4)
-        close(dl.traj["value"], ol.traj["value"], 1e-3, 2e-5, f"value (step {s})")
-        close(dl.traj["adv"], ol.traj["adv"], 1e-3, 1e-4, f"adv (step {s})")
+        close(dl.traj["value"], ol.traj["value"], 1e-4, 2e-6, f"value (step {s})")
+        close(dl.traj["adv"], ol.traj["adv"], 1e-4, 2e-5, f"adv (step {s})")
         for k in ("episode_return", "episode_length"):
             assert np.array_equal(dl.metrics[k].cpu().numpy(), om[k]), (s, k)
+        for d, o in zip(dl.groups[0].prev_sable_hs, ol.prev_sable_hs):
+            assert float(o.abs().max()) > 0, "rollout-start retention states must be non-zero from step 2 on"
         ol.update()
         dl.update()
         dl._carry_over()
         assert np.array_equal(dl.key, ol.key)
-        for n, v in dl.guider.named.items():
-            close(v, ol.gp[n].reshape(v.shape), 0, 3e-5 * s, f"guider param {n} (step {s})")
-        for n, v in dl.actor.named.items():
-            close(v, ol.ap[n].reshape(v.shape), 0, 3e-5 * s, f"actor param {n} (step {s})")
-    assert dl.groups[0].graph is not None, "the third rollout should have been a HIP-graph capture/replay"
+        for net, ref in ((dl.guider, ol.gp), (dl.actor, ol.ap)):
+            for n, v in net.named.items():
+                close(v, ref[n].reshape(v.shape), 0, 3e-5, f"param {n} (step {s})")
+    assert dl.groups[0].graph is not None, "the rollouts of steps 2 and 3 should have been a HIP-graph capture / replay"
 
 
 def test_graph_replay_equals_eager_rollout():

@@ -1,0 +1,68 @@
+"""N > 1 path on the GPU box: two processes (one env group each, torch.distributed) must end with the parameters of a
+single process that owns both groups (update_batch_size = 2) -- the gradient mean of rec_magpo.py:395-409 is the only
+coupling.  One GPU is available to the tests, so the two ranks share it and the all-reduce runs over gloo (staged
+through host memory, magpo_amd/distributed.py); on a multi-GPU node the same code path runs over RCCL."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(A=3, K=10, TL=6, maxval=30, N=6, T=8, P=2, M=2, steps=2, seed=31)
+
+
+def _mk(num_groups):
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
+    c = CFG
+    return MagpoLearner(CoordSumConfig(c["A"], c["K"], c["TL"], c["maxval"]), c["N"],
+                        SystemConfig(rollout_length=c["T"], ppo_epochs=c["P"], num_minibatches=c["M"]), "cuda", net_seed=5, wgrad_groups=4,
+                        num_groups=num_groups)
+
+
+def _key():
+    from magpo_amd.learner import host_split, prng_key
+    return host_split(prng_key(CFG["seed"]), 4)[0]
+
+
+def _rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from magpo_amd import distributed as mdist
+    mdist.init_from_env("gloo")
+    l = _mk(1)
+    l.setup(_key(), n_groups=world, group=rank)
+    sync = mdist.make_grad_sync(world)
+    losses = [l.update_step(sync).cpu() for _ in range(CFG["steps"])]
+    torch.cuda.synchronize()
+    q.put((rank, l.guider.P.flat.cpu().numpy(), l.actor.P.flat.cpu().numpy(), torch.stack(losses).numpy(), l.traj["action"].cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_with_two_groups():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = _mk(2)
+    one.setup(_key(), n_groups=2, group=0)
+    losses = torch.stack([one.update_step().cpu() for _ in range(CFG["steps"])]).numpy()
+    gp, ap = one.guider.P.flat.cpu().numpy(), one.actor.P.flat.cpu().numpy()
+    # replicas stay identical without a broadcast (identical optimiser step on identical averaged gradients)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    # ... and equal the single-process two-group learner (summation order of the two gradient halves may differ)
+    assert np.allclose(res[0][1], gp, rtol=0, atol=2e-6), float(np.abs(res[0][1] - gp).max())
+    assert np.allclose(res[0][2], ap, rtol=0, atol=2e-6), float(np.abs(res[0][2] - ap).max())
+    assert np.allclose(res[0][3], losses, rtol=1e-4, atol=1e-6)
+    for r in range(2):   # rank r rolled out group r's envs
+        assert np.array_equal(res[r][4], one.groups[r].traj["action"].cpu().numpy())
+    assert not np.array_equal(res[0][4], res[1][4])
