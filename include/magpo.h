@@ -42,6 +42,14 @@ int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key
                         float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
                         int auto_reset, magpo_stream_t stream);
 
+/* input classes of wrapped CoordSum tokens (first-layer tables, csrc/classtab.hip): cls_enc = ((agent * maxval + target) * npos + pos),
+ * cls_dec = prev * npos + pos per row; class_rows writes the distinct rows in class order: obs_tab [A*maxval*npos][A+1], pos_enc,
+ * and prev_dec / pos_dec [(K+1)*npos].  The actor's class (agent, target) is cls_enc / npos. */
+int magpo_coordsum_classes(const float* obs, int F, const int* prev, const int* pos, int A, int maxval, int npos,
+                           int* cls_enc, int* cls_dec, long R, magpo_stream_t stream);
+int magpo_coordsum_class_rows(int A, int maxval, int npos, int K, float* obs_tab, int* pos_enc, int* prev_dec, int* pos_dec,
+                              magpo_stream_t stream);
+
 /* ---- dense layers on fp32 MFMA (flax nn.Dense / retention projections) ----
  * act: 0 none, 1 relu, 2 gelu(tanh), 3 swish, 4 mask: Y = (M > 0) ? XW+b : 0 with the mask M passed in the Ypre argument (same stride as Y)
  * -- the ReLU backward fused into dX = dY W^T.  Ypre (act 0-3, nullable): receives the pre-activation. */
@@ -166,6 +174,16 @@ int magpo_gather_minibatch(const float* obs, const int* action, const int* stepc
                            int* o_action, int* o_prev, int* o_pos, unsigned char* o_done, unsigned char* o_mask,
                            float* o_value, float* o_logp, float* o_adv, float* o_targets, int* o_h0idx, int T,
                            int N, int A, int F, int K, int mb, magpo_stream_t stream);
+/* ---- input-class tables (csrc/classtab.hip): a first layer applied to R rows that take only C << R distinct values is the layer
+ * applied to the C distinct rows + a row gather; its parameter gradient is the layer's backward on per-class sums of dY.
+ * (mava/networks/base.py:166-170 pre-torso + GRU input projection; sable_network.py:93-101,257-267 obs / action embeddings)
+ * class_sum: order [R] = row ids sorted stably by class, offsets [C+1] = class boundaries in order (both int64, device);
+ * partial [magpo_class_sum_slots(C)][C][W] workspace; out [C][W].  Bit-stable (data-dependent order only). */
+int magpo_gather_rows(const float* table, long ldt, const int* cls, float* out, long ldo, long R, int W,
+                      magpo_stream_t stream);
+int magpo_class_sum_slots(int C);
+int magpo_class_sum(const float* X, long ldx, const long* order, const long* offsets, int C, int W, float* partial,
+                    float* out, magpo_stream_t stream);
 int magpo_adv_moments(const float* x, long n, double* workspace, float* out, magpo_stream_t stream);
 int magpo_loss_fwd_bwd(const float* g_logits, long ldg, const float* a_logits, long lda, const unsigned char* mask,
                        const int* action, const float* old_logp, const float* old_value, const float* value,

@@ -112,17 +112,34 @@ class GruActor:
         self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
         L.call("magpo_gru_carry", xi, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, st)
 
-    def seq_fwd(self, obs, dones, h0, h0_idx, nseq: int, T: int):
+    def input_table(self, obs_tab: torch.Tensor):
+        """xi of every distinct observation row: pre-torso + GRU input projection on obs_tab [C,F] -> [C,384] (the rows of a
+        minibatch then take their xi by class index; see csrc/classtab.hip)."""
+        L, st, F, v, b = self.L, self._st(), self.F, self.v, self.b
+        C = obs_tab.shape[0]
+        emb_tab = b.get("c_embtab", (C, H)); xi_tab = b.get("c_xitab", (C, 3 * H))
+        L.call("magpo_small_linear", obs_tab, F, F, v["pre.kernel"], v["pre.bias"], emb_tab, H, H, C, 1, st)
+        self.lin(emb_tab, H, self.wt["wi"], v["gru.bi"], xi_tab, 3 * H, C, H, 3 * H)
+        return emb_tab, xi_tab
+
+    def seq_fwd(self, obs, dones, h0, h0_idx, nseq: int, T: int, classes=None):
         """obs [R,F] rows (seq, t, agent); dones [nseq,T] u8 resets; h0 [*,128] gathered through h0_idx [nseq*A].
+        ``classes`` (optional) = (obs_tab [C,F], cls [R] i32, order [R] i64, offsets [C+1] i64): the rows' observations are
+        obs_tab[cls]; the input side of the GRU is then evaluated on the C distinct rows only.
         Returns raw logits [R,64] (K valid columns)."""
         L, st, A, F, v, b = self.L, self._st(), self.A, self.F, self.v, self.b
         R = nseq * T * A
-        emb = b.get("t_emb", (R, H)); xi = b.get("t_xi", (R, 3 * H)); hs = b.get("t_hs", (R, H))
+        xi = b.get("t_xi", (R, 3 * H)); hs = b.get("t_hs", (R, H))
         gates = b.get("t_gates", (R, 4 * H)); hprev = b.get("t_hprev", (R, H)); y = b.get("t_y", (R, H))
         logits = b.get("t_logits", (R, 64), zero=True)
-        self._saved = dict(obs=obs, dones=dones, nseq=nseq, T=T, R=R)
-        L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
-        self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
+        self._saved = dict(obs=obs, dones=dones, nseq=nseq, T=T, R=R, classes=classes)
+        if classes is not None:
+            _, xi_tab = self.input_table(classes[0])
+            L.call("magpo_gather_rows", xi_tab, 3 * H, classes[1], xi, 3 * H, R, 3 * H, st)
+        else:
+            emb = b.get("t_emb", (R, H))
+            L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
+            self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
         L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h0, h0_idx, dones, hs, gates, hprev, nseq, T, A, st)
         self.lin(hs, H, self.wt["post"], v["post.bias"], y, H, R, H, H, act=1)
         self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
@@ -146,13 +163,22 @@ class GruActor:
         slab = b.get("g_slab", (nblk, H))
         L.call("magpo_gru_scan_bwd", t("gates"), t("hprev"), dones, dhs, v["gru.wh"], dxi, dhh, slab, nseq, T, A, st)
         L.call("magpo_reduce_slabs", slab, gv["gru.hn.bias"], nblk, H, H, 1.0, 0, st)
-        self.wgrad(t("emb"), H, dxi, 3 * H, R, H, 3 * H, gv["gru.wi"], gv["gru.bi"])
         self.wgrad(t("hprev"), H, dhh, 3 * H, R, H, 3 * H, gv["gru.wh"])
+        if sv["classes"] is not None:
+            # input side on the class table: S[c] = sum of dxi over the rows of class c, then the layers' backward on C rows
+            obs, _, order, offsets = sv["classes"]
+            C = obs.shape[0]
+            part = b.get("g_cpart", (L.call("magpo_class_sum_slots", C), C, 3 * H)); dxi_c = b.get("g_dxic", (C, 3 * H))
+            L.call("magpo_class_sum", dxi, 3 * H, order, offsets, C, 3 * H, part, dxi_c, st)
+            emb, dxi, R = b.t["c_embtab"], dxi_c, C
+        else:
+            emb = t("emb")
+        self.wgrad(emb, H, dxi, 3 * H, R, H, 3 * H, gv["gru.wi"], gv["gru.bi"])
         demb = b.get("g_demb", (R, H))
         self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H)
         grid = L.call("magpo_row_grid", R)
         sw = b.get("g_slabw", (grid, 33 * H))
-        L.call("magpo_small_relu_wgrad", obs, F, F, t("emb"), demb, sw, R, st)
+        L.call("magpo_small_relu_wgrad", obs, F, F, emb, demb, sw, R, st)
         L.call("magpo_reduce_slabs", sw, gv["pre.kernel"], grid, F * H, 33 * H, 1.0, 0, st)
         L.call("magpo_reduce_slabs", sw[:, 32 * H:], gv["pre.bias"], grid, H, 33 * H, 1.0, 0, st)
         if self.overlap_wgrad and self.wgrad_stream is not None:

@@ -190,3 +190,51 @@ extern "C" int magpo_coordsum_step(int* step_count, int* target, int* record, ui
   hipLaunchKernelGGL(k_coordsum_step, dim3((N + 3) / 4), dim3(256), 0, st, s, c, actions, act_stride, o, auto_reset);
   return check_launch("magpo_coordsum_step");
 }
+
+// ---- input classes of the networks' first layers (csrc/classtab.hip) for wrapped CoordSum observations -----------------
+// A token's observation is [one-hot agent id | target] (observation.py:42-54, matrax.py:117-134) and its position the env step
+// count, so the first layers see only A*maxval (actor), A*maxval*npos (encoder) and (K+1)*npos (decoder) distinct inputs.
+namespace magpo {
+__global__ void k_coordsum_classes(const float* __restrict__ obs, int F, const int* __restrict__ prev, const int* __restrict__ pos,
+                                   int A, int maxval, int npos, int* __restrict__ cls_enc, int* __restrict__ cls_dec, long R) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* o = obs + r * F;
+  int ag = 0;
+  for (int a = 1; a < A; ++a) ag = o[a] != 0.f ? a : ag;
+  int g = (int)o[A];
+  g = g < 0 ? 0 : (g >= maxval ? maxval - 1 : g);
+  int p = pos[r];
+  p = p < 0 ? 0 : (p >= npos ? npos - 1 : p);
+  cls_enc[r] = (ag * maxval + g) * npos + p;
+  cls_dec[r] = prev[r] * npos + p;
+}
+// the distinct rows themselves, in class order: obs_tab [A*maxval*npos][F], pos_tab, and for the decoder prev_tab / pos_tab
+__global__ void k_coordsum_class_rows(int A, int maxval, int npos, int K, float* __restrict__ obs_tab, int* __restrict__ pos_enc,
+                                      int* __restrict__ prev_dec, int* __restrict__ pos_dec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int F = A + 1, Ce = A * maxval * npos, Cd = (K + 1) * npos;
+  if (i < Ce) {
+    const int p = i % npos, ag_g = i / npos, g = ag_g % maxval, ag = ag_g / maxval;
+    for (int a = 0; a < A; ++a) obs_tab[(long)i * F + a] = a == ag ? 1.f : 0.f;
+    obs_tab[(long)i * F + A] = (float)g;
+    pos_enc[i] = p;
+  }
+  if (i < Cd) { prev_dec[i] = i / npos; pos_dec[i] = i % npos; }
+}
+}  // namespace magpo
+
+extern "C" int magpo_coordsum_classes(const float* obs, int F, const int* prev, const int* pos, int A, int maxval, int npos,
+                                      int* cls_enc, int* cls_dec, long R, hipStream_t st) {
+  if (F != A + 1) { magpo::set_error("coordsum_classes: observations must be [one-hot agent id | target] (F = A + 1)"); return MAGPO_EINVAL; }
+  hipLaunchKernelGGL(magpo::k_coordsum_classes, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, obs, F, prev, pos, A, maxval, npos,
+                     cls_enc, cls_dec, R);
+  return magpo::check_launch("magpo_coordsum_classes");
+}
+
+extern "C" int magpo_coordsum_class_rows(int A, int maxval, int npos, int K, float* obs_tab, int* pos_enc, int* prev_dec, int* pos_dec,
+                                         hipStream_t st) {
+  const int Ce = A * maxval * npos, Cd = (K + 1) * npos, n = Ce > Cd ? Ce : Cd;
+  hipLaunchKernelGGL(magpo::k_coordsum_class_rows, dim3((n + 255) / 256), dim3(256), 0, st, A, maxval, npos, K, obs_tab, pos_enc, prev_dec, pos_dec);
+  return magpo::check_launch("magpo_coordsum_class_rows");
+}

@@ -158,6 +158,11 @@ class MagpoLearner:
         self.gnorm = f32(2)
         self.adv_stats = f32(2)
         self._mb: Dict[str, torch.Tensor] = {}
+        # First-layer class tables (csrc/classtab.hip): a wrapped CoordSum token is one of A*maxval*npos distinct inputs, so the
+        # layers in front of the GRU / of the first retention run on the distinct rows only.  MAGPO_CLASS_TABLES=0 = dense path.
+        import os
+        self.class_tables = os.environ.get("MAGPO_CLASS_TABLES", "1") != "0"
+        self._cls = None
         # the actor's forward / backward run on a second HIP stream next to the guider's (independent until the loss)
         self.overlap_actor = False  # opt-in (bench.py --overlap): ~3 %, but per-kernel timings then include contention
         self._actor_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
@@ -343,6 +348,39 @@ class MagpoLearner:
                     m["value"], m["logp"], m["adv"], m["targets"], m["h0idx"], T, N, A, F, K, mb, self._st())
         return m
 
+    def _class_rows(self):
+        """Distinct first-layer inputs of wrapped CoordSum tokens, in class order (built once)."""
+        if self._cls is None:
+            A, K, mv, npos = self.A, self.K, self.env_cfg.maxval, self.env_cfg.time_limit + 1
+            Ce, Cd = A * mv * npos, (K + 1) * npos
+            c = dict(Ce=Ce, Cd=Cd, Ca=A * mv, npos=npos, obs_enc=torch.empty(Ce, self.F, device=self.dev),
+                     pos_enc=torch.empty(Ce, dtype=torch.int32, device=self.dev), prev_dec=torch.empty(Cd, dtype=torch.int32, device=self.dev),
+                     pos_dec=torch.empty(Cd, dtype=torch.int32, device=self.dev))
+            self.L.call("magpo_coordsum_class_rows", A, mv, npos, K, c["obs_enc"], c["pos_enc"], c["prev_dec"], c["pos_dec"], self._st())
+            c["obs_act"] = c["obs_enc"][::npos].contiguous()     # actor class (agent, target) = encoder class // npos
+            c["zero"] = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self._cls = c
+        return self._cls
+
+    def _classes(self, m):
+        """Class index of every minibatch row and the stable row order per class (one sort per network side; the actor's
+        classes are a coarsening of the encoder's, so it shares that order)."""
+        c = self._class_rows()
+        R = m["R"]
+        if m.get("cls_R") != R:
+            m.update(cls_R=R, cls_enc=torch.empty(R, dtype=torch.int32, device=self.dev), cls_dec=torch.empty(R, dtype=torch.int32, device=self.dev))
+        self.L.call("magpo_coordsum_classes", m["obs"], self.F, m["prev"], m["pos"], self.A, self.env_cfg.maxval, c["npos"],
+                    m["cls_enc"], m["cls_dec"], R, self._st())
+        out = {}
+        for side, C in (("enc", c["Ce"]), ("dec", c["Cd"])):
+            cls = m["cls_" + side]
+            order = torch.sort(cls, stable=True).indices
+            offsets = torch.cat([c["zero"], torch.cumsum(torch.bincount(cls, minlength=C), 0)])
+            out[side] = (cls, order, offsets)
+        cls_act = torch.div(m["cls_enc"], c["npos"], rounding_mode="floor").to(torch.int32)
+        out["act"] = (c["obs_act"], cls_act, out["enc"][1], out["enc"][2][::c["npos"]].contiguous())
+        return out
+
     def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group: int = 0, hs_idx: Optional[torch.Tensor] = None):
         """Forward + loss + backward of both networks for one minibatch of one group; gradients land in
         guider.grads / actor.grads, loss scalars in self.loss_out (all inside self.grad_all, on device).
@@ -352,18 +390,20 @@ class MagpoLearner:
         g = self.groups[group]
         m = self._gather(g, env_idx, agent_perm)
         mb, R = env_idx.numel(), m["R"]
+        cl = self._classes(m) if self.class_tables else None
+        acl = None if cl is None else cl["act"]
         side = self._actor_stream if self.overlap_actor else None
         main = torch.cuda.current_stream()
         if side is not None:
             side.wait_stream(main)  # minibatch gather (and the previous optimiser step) are complete for the actor
             with torch.cuda.stream(side):
-                a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T)
+                a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T, classes=acl)
         g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], g.prev_sable_hs,
                                                 env_idx if hs_idx is None else hs_idx, mb, T)
         if side is not None:
             main.wait_stream(side)
         else:
-            a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T)
+            a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T, classes=acl)
         st = self._st()
         self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
         self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, None, m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],

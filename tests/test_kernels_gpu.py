@@ -654,3 +654,28 @@ def test_gather_minibatch(L, stream):
     assert torch.equal(o_pos.cpu().reshape(mb, T, A)[:, :, 0], sc.index_select(1, env_idx.long()).T)
     assert torch.equal(o_done.cpu(), done.index_select(1, env_idx.long()).T)
     assert torch.equal(o_h0.cpu().reshape(mb, A), env_idx[:, None] * A + ap[None, :])
+
+
+@pytest.mark.parametrize("R,C,W", [(5000, 7, 384), (3000, 240, 256), (4097, 2121, 64), (100, 300, 64)])
+def test_gather_rows_and_class_sum(L, stream, R, C, W):
+    """csrc/classtab.hip: out[r] = table[cls[r]]; per-class row sums through a stable order (bit-stable, empty classes = 0)."""
+    g = torch.Generator().manual_seed(R + C)
+    cls = torch.randint(0, C, (R,), generator=g).int()
+    if C > 3:
+        cls[cls == 2] = 3     # an empty class
+    table = torch.randn(C, W, generator=g)
+    out = torch.zeros(R, W + 4, device=DEV)
+    L.call("magpo_gather_rows", dev(table), W, dev(cls), out, W + 4, R, W, stream)
+    assert torch.equal(out[:, :W].cpu(), table[cls.long()])
+    X = torch.randn(R, W, generator=g)
+    cd = dev(cls)
+    order = torch.sort(cd, stable=True).indices
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), torch.cumsum(torch.bincount(cd, minlength=C), 0)])
+    S = L.call("magpo_class_sum_slots", C)
+    part = torch.empty(S, C, W, device=DEV)
+    res = [torch.empty(C, W, device=DEV) for _ in range(2)]
+    for o in res:
+        L.call("magpo_class_sum", dev(X), W, order, offsets, C, W, part, o, stream)
+    ref = torch.zeros(C, W, dtype=torch.float64).index_add_(0, cls.long(), X.double())
+    close(res[0], ref, 1e-5, 1e-5, "class sums")
+    assert torch.equal(res[0], res[1]), "class sums must be bit-stable"

@@ -215,3 +215,32 @@ def test_fused_segments_equal_kernel_composition(A, K, N, T, nb):
     scale = float(ga.abs().max())
     assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-7, "guider gradients differ between the fused and the composed path"
     close(b.actor.grads, a.actor.grads, 1e-5, 1e-7, "actor gradients")
+
+
+@pytest.mark.parametrize("A,K,N,T,nb", [(4, 20, 12, 16, 1), (3, 10, 7, 9, 2), (8, 15, 5, 12, 1)])
+def test_class_tables_equal_dense_path(A, K, N, T, nb):
+    """First-layer class tables (csrc/classtab.hip: layers in front of the GRU / the first retention evaluated on the distinct
+    (agent, target[, step]) / (previous action, step) rows only, parameter gradients from per-class sums) against the dense
+    path on every row: same losses and gradients to fp32 summation order."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    sysc = SystemConfig(rollout_length=T, ppo_epochs=1, num_minibatches=1)
+    key = host_split(prng_key(33), 4)[0]
+    ls = []
+    for tables in (False, True):
+        l = MagpoLearner(CoordSumConfig(A, K, 7, 3 * K), N, sysc, "cuda", net_seed=3, wgrad_groups=4, n_block=nb)
+        l.class_tables = tables
+        l.use_graph = False
+        l.setup(key)
+        l.rollout()
+        g = torch.Generator().manual_seed(1)
+        l.minibatch_grads(torch.randperm(N, generator=g).int().cuda(), torch.randperm(A, generator=g).int().cuda())
+        torch.cuda.synchronize()
+        ls.append(l)
+    a, b = ls
+    assert torch.equal(a.traj["action"], b.traj["action"])
+    close(b.loss_out, a.loss_out, 1e-5, 1e-6, "losses")
+    for net in ("guider", "actor"):
+        for n, ga in getattr(a, net).named_grads.items():
+            gb = getattr(b, net).named_grads[n]
+            scale = float(ga.abs().max())
+            assert float((ga - gb).abs().max()) <= 3e-5 * scale + 1e-9, f"{net} gradient {n} differs between class tables and the dense path"
