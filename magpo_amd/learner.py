@@ -392,6 +392,8 @@ class MagpoLearner:
         mb, R = env_idx.numel(), m["R"]
         cl = self._classes(m) if self.class_tables else None
         acl = None if cl is None else cl["act"]
+        gcl = None if cl is None else dict(rows=(self._cls["obs_enc"], self._cls["pos_enc"], self._cls["prev_dec"], self._cls["pos_dec"]),
+                                           enc=cl["enc"], dec=cl["dec"])
         side = self._actor_stream if self.overlap_actor else None
         main = torch.cuda.current_stream()
         if side is not None:
@@ -399,7 +401,7 @@ class MagpoLearner:
             with torch.cuda.stream(side):
                 a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T, classes=acl)
         g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], g.prev_sable_hs,
-                                                env_idx if hs_idx is None else hs_idx, mb, T)
+                                                env_idx if hs_idx is None else hs_idx, mb, T, classes=gcl)
         if side is not None:
             main.wait_stream(side)
         else:

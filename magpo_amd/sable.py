@@ -362,25 +362,39 @@ class SableGuider:
         self.reduce(sl[2], gv[pfx + "gn.scale"]); self.reduce(sl[3], gv[pfx + "gn.bias"])
 
     # ------------------------------------------------------------------ training forward (chunkwise form)
-    def train_fwd(self, obs, prev_idx, pos, dones, s0, seq_env, nseq: int, T: int):
+    def train_fwd(self, obs, prev_idx, pos, dones, s0, seq_env, nseq: int, T: int, classes=None):
         """obs [R,F], prev_idx [R] (0 = start token, a+1 otherwise), pos [R] step counts, dones [nseq,T] u8,
         s0 = three [n_block, N, 64, 64] rollout-start states indexed through seq_env [nseq].
+        ``classes`` (optional, csrc/classtab.hip) = dict(rows=(obs_enc [Ce,F], pos_enc [Ce], prev_dec [Cd], pos_dec [Cd]),
+        enc=(cls, order, offsets), dec=(cls, order, offsets)): the embeddings and the first q|k|v|g projections of encoder
+        and decoder are then evaluated on the distinct input rows only and gathered by class.
         Returns (logits [R,64] raw with K valid columns, value [R])."""
         L, st, A, K, F, v, b, nb = self.L, self._st(), self.A, self.K, self.F, self.v, self.b, self.nb
         R = nseq * T * A
         nch = L.call("magpo_retention_num_chunks", T, A)
         g = lambda n, w=E: b.get("t_" + n, (R, w))
         stt = lambda n: b.get("t_" + n, (nseq, nch, E, E))
-        self._saved = dict(obs=obs, prev_idx=prev_idx, pos=pos, dones=dones, nseq=nseq, T=T, R=R)
+        self._saved = dict(obs=obs, prev_idx=prev_idx, pos=pos, dones=dones, nseq=nseq, T=T, R=R, classes=classes)
         rep, reppe, hv, value = g("rep"), g("reppe"), g("hv"), b.get("t_value", (R,))
         logits = b.get("t_logits", (R, E), zero=True)
         # ---- encoder
-        L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
-               self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, st)   # z is recomputed by the backward
+        if classes is not None:   # embedding + first projection on the Ce distinct (agent, target, step) rows, gathered by class
+            obs_c, pos_c = classes["rows"][0], classes["rows"][1]
+            Ce = obs_c.shape[0]
+            xn_c, kin_c, qkvg_c = b.get("c_xn0", (Ce, E)), b.get("c_kin0", (Ce, E)), b.get("c_qkvg0", (Ce, 4 * E))
+            L.call("magpo_embed_fwd", 0, obs_c, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
+                   self.pe, pos_c, 1, self.npos, None, 0, xn_c, E, kin_c, E, Ce, st)
+            self.lin(kin_c, E, self.wt["qkvg0"], None, qkvg_c, 4 * E, Ce, E, 4 * E)
+            L.call("magpo_gather_rows", xn_c, E, classes["enc"][0], g("xn0"), E, R, E, st)
+            L.call("magpo_gather_rows", qkvg_c, 4 * E, classes["enc"][0], g("qkvg0", 4 * E), 4 * E, R, 4 * E, st)
+        else:
+            L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
+                   self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, st)   # z is recomputed by the backward
         for k in range(nb):
             e = f"enc.block{k}."
-            xn, kin, qkvg, r, u, y = g(f"xn{k}"), g(f"kin{k}"), g(f"qkvg{k}", 4 * E), g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
-            self.lin(kin, E, self.wt[f"qkvg{k}"], None, qkvg, 4 * E, R, E, 4 * E)
+            xn, qkvg, r, u, y = g(f"xn{k}"), g(f"qkvg{k}", 4 * E), g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
+            if k > 0 or classes is None:
+                self.lin(g(f"kin{k}"), E, self.wt[f"qkvg{k}"], None, qkvg, 4 * E, R, E, 4 * E)
             self._ret_fwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, s0[0][k], seq_env, dones, f"st_e{k}", nseq, T, 0)
             if self.fused_segments and k == nb - 1:
                 # GroupNorm + gate, W_o, residual + norms, value head and the cross-retention queries of every decoder block: one launch
@@ -411,14 +425,25 @@ class SableGuider:
             L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
                    value, 1, R, st)
         # ---- decoder
-        L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_idx, 1, v["dec.ln.scale"], self.pe, pos, 1, self.npos,
-               None, 0, g("x0"), E, g("xpe0"), E, R, st)   # za = W_act[prev] is gathered again by the backward
+        if classes is not None:   # action embedding + first projection on the Cd distinct (previous action, step) rows
+            prev_c, posd_c = classes["rows"][2], classes["rows"][3]
+            Cd = prev_c.shape[0]
+            x_c, xpe_c, qkvg1_c = b.get("c_x0", (Cd, E)), b.get("c_xpe0", (Cd, E)), b.get("c_qkvg10", (Cd, 4 * E))
+            L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_c, 1, v["dec.ln.scale"], self.pe, posd_c, 1, self.npos,
+                   None, 0, x_c, E, xpe_c, E, Cd, st)
+            self.lin(xpe_c, E, self.wt["qkvg10"], None, qkvg1_c, 4 * E, Cd, E, 4 * E)
+            L.call("magpo_gather_rows", x_c, E, classes["dec"][0], g("x0"), E, R, E, st)
+            L.call("magpo_gather_rows", qkvg1_c, 4 * E, classes["dec"][0], g("qkvg10", 4 * E), 4 * E, R, 4 * E, st)
+        else:
+            L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_idx, 1, v["dec.ln.scale"], self.pe, pos, 1, self.npos,
+                   None, 0, g("x0"), E, g("xpe0"), E, R, st)   # za = W_act[prev] is gathered again by the backward
         for k in range(nb):
             d = f"dec.block{k}."
-            x, xpe = g(f"x{k}"), g(f"xpe{k}")
+            x = g(f"x{k}")
             qkvg1, r1, u1, y1 = g(f"qkvg1{k}", 4 * E), g(f"r1{k}"), g(f"u1{k}"), g(f"y1{k}")
             cpe, q2, kvg2, r2, u2, y2 = g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
-            self.lin(xpe, E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
+            if k > 0 or classes is None:
+                self.lin(g(f"xpe{k}"), E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
             self._ret_fwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, s0[1][k], seq_env, dones, f"st_1{k}", nseq, T, 1)
             if self.fused_segments:
                 # after the self-retention: gate, W_o, residual + norm (+ pe) and the k | v | g projection of the cross-retention
@@ -463,6 +488,7 @@ class SableGuider:
         sv = self._saved
         R, nseq, T = sv["R"], sv["nseq"], sv["T"]
         obs, prev_idx, pos, dones = sv["obs"], sv["prev_idx"], sv["pos"], sv["dones"]
+        cl, Rd = sv["classes"], R
         t = lambda n: b.t["t_" + n]
         g = lambda n, w=E: b.get("g_" + n, (R, w))
         grid = L.call("magpo_row_grid", R)
@@ -526,14 +552,28 @@ class SableGuider:
                 self._retpost_bwd(t(f"r1{k}"), qkvg1[:, 3 * E:], 4 * E, d + "retn1.", du1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
             self._ret_bwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, dr1, dqkvg1, 4 * E, dqkvg1[:, E:], 4 * E,
                           dqkvg1[:, 2 * E:], 4 * E, dones, f"st_1{k}", nseq, T, 1)
+            if k == 0 and cl is not None:   # block 0 on the class table: per-class sums of both gradient paths, then Cd rows
+                _, order, offsets = cl["dec"]
+                Cd = cl["rows"][2].shape[0]
+                dq_c, ds_c = b.get("gc_dqkvg1", (Cd, 4 * E)), b.get("gc_dsum1", (Cd, E))
+                part = b.get("gc_part_d", (L.call("magpo_class_sum_slots", Cd), Cd, 4 * E))
+                L.call("magpo_class_sum", dqkvg1, 4 * E, order, offsets, Cd, 4 * E, part, dq_c, st)
+                L.call("magpo_class_sum", dsum1, E, order, offsets, Cd, E, part, ds_c, st)
+                self.wgrad(b.t["c_xpe0"], E, dq_c, 4 * E, Cd, E, 4 * E, gv[d + "retn1.w_qkvg"])
+                dkin1 = b.get("gc_dkin1", (Cd, E))
+                self.lin(dq_c, 4 * E, v[d + "retn1.w_qkvg"], None, dkin1, E, Cd, 4 * E, E)
+                din0, din1, prev_idx, Rd = ds_c, dkin1, cl["rows"][2], Cd
+                break
             self.wgrad(t(f"xpe{k}"), E, dqkvg1, 4 * E, R, E, 4 * E, gv[d + "retn1.w_qkvg"])
             dkin1 = g(f"dkin1_{k}")
             self.lin(dqkvg1, 4 * E, v[d + "retn1.w_qkvg"], None, dkin1, E, R, 4 * E, E)
             din0, din1 = dsum1, dkin1      # gradient of x_k (block input): residual path + key/query/value path
-        L.call("magpo_embed_bwd", 1, None, 0, din0, E, din1, E, None, 0, v["dec.ln.scale"], None, 0, slab("a"), slab("w", 32 * E),
-               K + 1, None, 0, 0, None, v["dec.act.kernel"], None, prev_idx, 1, R, st)
-        self.reduce(slab("a"), gv["dec.ln.scale"])
-        self.reduce(slab("w", 32 * E), gv["dec.act.kernel"], P=(K + 1) * E, stride=32 * E)
+        gridd = L.call("magpo_row_grid", Rd)
+        sa_d, sw_d = b.get("s_a_d", (gridd, 64)), b.get("s_w_d", (gridd, 32 * E))
+        L.call("magpo_embed_bwd", 1, None, 0, din0, E, din1, E, None, 0, v["dec.ln.scale"], None, 0, sa_d, sw_d,
+               K + 1, None, 0, 0, None, v["dec.act.kernel"], None, prev_idx, 1, Rd, st)
+        self.reduce(sa_d, gv["dec.ln.scale"])
+        self.reduce(sw_d, gv["dec.act.kernel"], P=(K + 1) * E, stride=32 * E)
         # ---- value head
         dhv = g("dhv")
         L.call("magpo_headmid_bwd", t("hv"), E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], dvalue, 1, dhv, E,
@@ -565,6 +605,25 @@ class SableGuider:
                 self._retpost_bwd(t(f"r{k}"), qkvg[:, 3 * E:], 4 * E, e + "retn.", du, dr, dqkvg[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
             self._ret_bwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, dr, dqkvg, 4 * E, dqkvg[:, E:], 4 * E, dqkvg[:, 2 * E:], 4 * E,
                           dones, f"st_e{k}", nseq, T, 0)
+            if k == 0 and cl is not None:
+                _, order, offsets = cl["enc"]
+                obs_c = cl["rows"][0]
+                Ce = obs_c.shape[0]
+                dq_c, ds_c = b.get("gc_dqkvg0", (Ce, 4 * E)), b.get("gc_dsum0", (Ce, E))
+                part = b.get("gc_part_e", (L.call("magpo_class_sum_slots", Ce), Ce, 4 * E))
+                L.call("magpo_class_sum", dqkvg, 4 * E, order, offsets, Ce, 4 * E, part, dq_c, st)
+                L.call("magpo_class_sum", dsum0, E, order, offsets, Ce, E, part, ds_c, st)
+                self.wgrad(b.t["c_kin0"], E, dq_c, 4 * E, Ce, E, 4 * E, gv[e + "retn.w_qkvg"])
+                dkin = b.get("gc_dkin0", (Ce, E))
+                self.lin(dq_c, 4 * E, v[e + "retn.w_qkvg"], None, dkin, E, Ce, 4 * E, E)
+                gride = L.call("magpo_row_grid", Ce)
+                sa, sw, sd = b.get("s_a_e", (gride, 64)), b.get("s_w_e", (gride, 32 * E)), b.get("s_d_e", (gride, 32))
+                L.call("magpo_embed_bwd", 0, None, 0, ds_c, E, dkin, E, None, 0, v["enc.ln.scale"], None, 0, sa, sw, F,
+                       obs_c, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], sd, None, 0, Ce, st)
+                self.reduce(sa, gv["enc.ln.scale"], accumulate=not first_ln)
+                self.reduce(sd, gv["enc.obs.norm.scale"], P=F, stride=32)
+                self.reduce(sw, gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)
+                break
             self.wgrad(t(f"kin{k}"), E, dqkvg, 4 * E, R, E, 4 * E, gv[e + "retn.w_qkvg"])
             dkin = g(f"dkin_{k}")
             self.lin(dqkvg, 4 * E, v[e + "retn.w_qkvg"], None, dkin, E, R, 4 * E, E)
