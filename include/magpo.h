@@ -44,7 +44,8 @@ int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key
 
 /* input classes of wrapped CoordSum tokens (first-layer tables, csrc/classtab.hip): cls_enc = ((agent * maxval + target) * npos + pos),
  * cls_dec = prev * npos + pos per row; class_rows writes the distinct rows in class order: obs_tab [A*maxval*npos][A+1], pos_enc,
- * and prev_dec / pos_dec [(K+1)*npos].  The actor's class (agent, target) is cls_enc / npos. */
+ * and prev_dec / pos_dec [(K+1)*npos].  The actor's class (agent, target) is cls_enc / npos (or cls_enc itself with pos = NULL, npos = 1;
+ * prev / cls_dec may then be NULL as well). */
 int magpo_coordsum_classes(const float* obs, int F, const int* prev, const int* pos, int A, int maxval, int npos,
                            int* cls_enc, int* cls_dec, long R, magpo_stream_t stream);
 int magpo_coordsum_class_rows(int A, int maxval, int npos, int K, float* obs_tab, int* pos_enc, int* prev_dec, int* pos_dec,
@@ -152,10 +153,11 @@ int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int
  * ((r, z, n, h W_hn + b_hn) interleaved per hidden column). */
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                        const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
-                       magpo_stream_t stream);
-/* hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
+                       const int* xi_cls, magpo_stream_t stream);
+/* xi_cls (nullable): xi is a table over the distinct input rows and token row r takes xi[xi_cls[r]] (csrc/classtab.hip).
+ * hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
 int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,
-                    float* h_last, int nenv, int T, int A, magpo_stream_t stream);
+                    float* h_last, int nenv, int T, int A, const int* xi_cls, magpo_stream_t stream);
 int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned char* reset, const float* dhs,
                        const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
                        magpo_stream_t stream);

@@ -92,7 +92,7 @@ class GruActor:
         emb = b.get("s_emb", (R, H)); xi = b.get("s_xi", (R, 3 * H))
         L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
         self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
-        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h_in, None, reset_env, h_out, None, None, N, 1, A, st)
+        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h_in, None, reset_env, h_out, None, None, N, 1, A, None, st)
         if not want_logits:
             return None
         y = b.get("s_y", (R, H)); logits = b.get("s_logits", (R, 64), zero=True)
@@ -100,24 +100,29 @@ class GruActor:
         self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
         return logits
 
-    def carry(self, obs_tm, h_in, reset_tm, h_out):
+    def carry(self, obs_tm, h_in, reset_tm, h_out, classes=None):
         """Hidden-state carry over a whole rollout at once: obs_tm [T,N,A,F] (time-major trajectory), reset_tm [T,N] u8
         reset-before-step flags, h_in / h_out [N*A,128].  Same result as T calls of :meth:`step` (ScannedRNN, base.py:121-149):
-        the carry depends on (obs, done) only, never on the sampled actions."""
+        the carry depends on (obs, done) only, never on the sampled actions.  ``classes`` = (obs_tab [C,F], cls [T*N*A] i32):
+        the input side on the distinct rows only (csrc/classtab.hip)."""
         L, st, A, F, v, b = self.L, self._st(), self.A, self.F, self.v, self.b
         T, N = obs_tm.shape[0], obs_tm.shape[1]
         R = T * N * A
+        if classes is not None:
+            _, xi_tab = self.input_table(classes[0], "r")
+            L.call("magpo_gru_carry", xi_tab, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, classes[1], st)
+            return
         emb = b.get("c_emb", (R, H)); xi = b.get("c_xi", (R, 3 * H))
         L.call("magpo_small_linear", obs_tm, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
         self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
-        L.call("magpo_gru_carry", xi, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, st)
+        L.call("magpo_gru_carry", xi, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, None, st)
 
-    def input_table(self, obs_tab: torch.Tensor):
+    def input_table(self, obs_tab: torch.Tensor, tag: str = ""):
         """xi of every distinct observation row: pre-torso + GRU input projection on obs_tab [C,F] -> [C,384] (the rows of a
         minibatch then take their xi by class index; see csrc/classtab.hip)."""
         L, st, F, v, b = self.L, self._st(), self.F, self.v, self.b
         C = obs_tab.shape[0]
-        emb_tab = b.get("c_embtab", (C, H)); xi_tab = b.get("c_xitab", (C, 3 * H))
+        emb_tab = b.get("c_embtab" + tag, (C, H)); xi_tab = b.get("c_xitab" + tag, (C, 3 * H))
         L.call("magpo_small_linear", obs_tab, F, F, v["pre.kernel"], v["pre.bias"], emb_tab, H, H, C, 1, st)
         self.lin(emb_tab, H, self.wt["wi"], v["gru.bi"], xi_tab, 3 * H, C, H, 3 * H)
         return emb_tab, xi_tab
@@ -129,18 +134,19 @@ class GruActor:
         Returns raw logits [R,64] (K valid columns)."""
         L, st, A, F, v, b = self.L, self._st(), self.A, self.F, self.v, self.b
         R = nseq * T * A
-        xi = b.get("t_xi", (R, 3 * H)); hs = b.get("t_hs", (R, H))
+        hs = b.get("t_hs", (R, H))
         gates = b.get("t_gates", (R, 4 * H)); hprev = b.get("t_hprev", (R, H)); y = b.get("t_y", (R, H))
         logits = b.get("t_logits", (R, 64), zero=True)
         self._saved = dict(obs=obs, dones=dones, nseq=nseq, T=T, R=R, classes=classes)
-        if classes is not None:
-            _, xi_tab = self.input_table(classes[0])
-            L.call("magpo_gather_rows", xi_tab, 3 * H, classes[1], xi, 3 * H, R, 3 * H, st)
+        if classes is not None:   # the scan reads xi rows straight from the (L2-resident) class table
+            _, xi = self.input_table(classes[0])
+            xi_cls = classes[1]
         else:
-            emb = b.get("t_emb", (R, H))
+            emb = b.get("t_emb", (R, H)); xi = b.get("t_xi", (R, 3 * H))
+            xi_cls = None
             L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
             self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
-        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h0, h0_idx, dones, hs, gates, hprev, nseq, T, A, st)
+        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h0, h0_idx, dones, hs, gates, hprev, nseq, T, A, xi_cls, st)
         self.lin(hs, H, self.wt["post"], v["post.bias"], y, H, R, H, H, act=1)
         self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
         return logits

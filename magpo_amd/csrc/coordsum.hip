@@ -204,10 +204,10 @@ __global__ void k_coordsum_classes(const float* __restrict__ obs, int F, const i
   for (int a = 1; a < A; ++a) ag = o[a] != 0.f ? a : ag;
   int g = (int)o[A];
   g = g < 0 ? 0 : (g >= maxval ? maxval - 1 : g);
-  int p = pos[r];
+  int p = pos ? pos[r] : 0;
   p = p < 0 ? 0 : (p >= npos ? npos - 1 : p);
   cls_enc[r] = (ag * maxval + g) * npos + p;
-  cls_dec[r] = prev[r] * npos + p;
+  if (cls_dec) cls_dec[r] = prev[r] * npos + p;
 }
 // the distinct rows themselves, in class order: obs_tab [A*maxval*npos][F], pos_tab, and for the decoder prev_tab / pos_tab
 __global__ void k_coordsum_class_rows(int A, int maxval, int npos, int K, float* __restrict__ obs_tab, int* __restrict__ pos_enc,

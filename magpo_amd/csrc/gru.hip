@@ -30,6 +30,7 @@ struct GruArgs {
   int T, A, NR;           // NR = nseq * A recurrent rows
   int time_major;         // 0: rows (seq, t, agent), reset [nseq][T];  1: rows (t, seq, agent), reset [T][nseq] (rollout trajectory)
   float* h_last;          // [NR][H] state after the last step (nullable)
+  const int* xi_cls;      // [R] nullable: row r takes xi[xi_cls[r]] (xi = table over the distinct input rows, csrc/classtab.hip)
 };
 
 #ifdef MAGPO_GRU_PROF
@@ -60,7 +61,7 @@ template <bool FULL, int MODE>
 __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) {
   constexpr bool TM = MODE == 1;
   __shared__ __align__(16) float hbuf[2][64 * HP];
-  extern __shared__ unsigned char rflag[];   // [64][T] reset-before-step flags of the block's rows
+  extern __shared__ unsigned char rflag[];   // [64][T] reset-before-step flags of the block's rows, then (xi_cls) [64][T] int xi rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int rho0 = (block0 + blockIdx.x) * 64;
   const int col = 32 * wave + lr;
@@ -75,6 +76,17 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
     const int rl = i / T, t = i - rl * T;
     const int rho = min(rho0 + rl, a.NR - 1);
     rflag[i] = TM ? a.reset[(long)t * (a.NR / a.A) + rho / a.A] : a.reset[(long)(rho / a.A) * T + t];
+  }
+  // xi rows through the class table: the block's 64 x T class indices are staged once, like the flags (a dependent global
+  // load per step would sit in front of every xi load)
+  int* ctab = reinterpret_cast<int*>(rflag + 64 * T);
+  const bool by_cls = a.xi_cls != nullptr;
+  if (by_cls) {
+    for (int i = tid; i < 64 * T; i += 256) {
+      const int rl = i / T, t = i - rl * T;
+      const int rho = min(rho0 + rl, a.NR - 1);
+      ctab[i] = a.xi_cls[TM ? (long)t * a.NR + rho : tok_row(rho, t, T, a.A)];
+    }
   }
   // initial carry (with the reset of step 0 applied)
   for (int i = tid; i < 64 * (H / 4); i += 256) {
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
         const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
         const long row = rbase[rl] + (long)t * t_stride;
         rowi[i] = row;
-        const float* x = a.xi + row * G3;
+        const float* x = a.xi + (by_cls ? (long)ctab[rl * T + t] : row) * G3;
         xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
       }
       // carry values and next-step reset flags of the job's rows: LDS round trips hidden under the MFMAs as well
@@ -393,11 +405,11 @@ using namespace magpo;
 
 extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                                   const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
-                                  hipStream_t st) {
-  GruArgs a{xi, Wht, b_hn, h0, h0_idx, reset, hs, gates, hprev, T, A, nseq * A, 0, nullptr};
+                                  const int* xi_cls, hipStream_t st) {
+  GruArgs a{xi, Wht, b_hn, h0, h0_idx, reset, hs, gates, hprev, T, A, nseq * A, 0, nullptr, xi_cls};
   if (a.NR <= 0) return MAGPO_OK;
-  const size_t lds = (size_t)64 * T;   // reset flags of the block's rows
-  if (lds > 24 * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }
+  const size_t lds = (size_t)64 * T * (xi_cls ? 5 : 1);   // reset flags (+ xi class rows) of the block's rows
+  if (lds > (xi_cls ? 80 : 24) * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS tables"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
   if (hs && gates && hprev) {
     if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 0>), dim3(nfull), dim3(256), lds, st, a, 0);
@@ -413,11 +425,11 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
 // only the state after the last step is written.  The carry is a pure function of (obs, done), so the rollout computes it
 // once for all T steps instead of once per env step (ScannedRNN semantics, base.py:121-149).
 extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,
-                               float* h_last, int nenv, int T, int A, hipStream_t st) {
-  GruArgs a{xi, Wht, b_hn, h0, nullptr, reset_tm, nullptr, nullptr, nullptr, T, A, nenv * A, 1, h_last};
+                               float* h_last, int nenv, int T, int A, const int* xi_cls, hipStream_t st) {
+  GruArgs a{xi, Wht, b_hn, h0, nullptr, reset_tm, nullptr, nullptr, nullptr, T, A, nenv * A, 1, h_last, xi_cls};
   if (a.NR <= 0 || T <= 0) return MAGPO_OK;
-  const size_t lds = (size_t)64 * T;
-  if (lds > 24 * 1024) { set_error("magpo_gru_carry: T too large for the LDS flag table"); return MAGPO_EINVAL; }
+  const size_t lds = (size_t)64 * T * (xi_cls ? 5 : 1);
+  if (lds > (xi_cls ? 80 : 24) * 1024) { set_error("magpo_gru_carry: T too large for the LDS tables"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
   if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 1>), dim3(nfull), dim3(256), lds, st, a, 0);
   if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 1>), dim3(1), dim3(256), lds, st, a, nfull);

@@ -301,7 +301,13 @@ class MagpoLearner:
         if side is not None:
             main.wait_stream(side)
         if self.batched_actor_carry:   # one scan over the finished trajectory instead of T single steps (same result)
-            self.actor.carry(tr["obs"][:T], g.policy_h[g.cur], tr["done"][:T], g.policy_h[1 - g.cur])
+            ccl = None
+            if self.class_tables:   # input side of the GRU on the A*maxval distinct (agent, target) rows
+                if getattr(g, "traj_cls", None) is None:
+                    g.traj_cls = torch.empty(T * N * A, dtype=torch.int32, device=self.dev)
+                L.call("magpo_coordsum_classes", tr["obs"], self.F, None, None, A, self.env_cfg.maxval, 1, g.traj_cls, None, T * N * A, st)
+                ccl = (self._class_rows()["obs_act"], g.traj_cls)
+            self.actor.carry(tr["obs"][:T], g.policy_h[g.cur], tr["done"][:T], g.policy_h[1 - g.cur], classes=ccl)
             g.cur = 1 - g.cur
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])

@@ -14,7 +14,7 @@ bhn = torch.zeros(H, device=dev); h0 = torch.zeros(nseq * A, H, device=dev)
 reset = (torch.rand(nseq, T, device=dev, generator=g) < 0.01).to(torch.uint8)
 hs = torch.empty(R, H, device=dev); gates = torch.empty(R, 4 * H, device=dev); hprev = torch.empty(R, H, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-call = lambda: L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hprev, nseq, T, A, st)
+call = lambda: L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hprev, nseq, T, A, None, st)
 fn = L.raw("magpo_debug_gru_prof"); out = np.zeros(8, dtype=np.uint64)
 call(); call(); torch.cuda.synchronize(); fn(ctypes.c_void_p(out.ctypes.data), 1)
 t0 = time.time()

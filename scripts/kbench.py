@@ -51,7 +51,7 @@ if "gru" in which:
     bhn = torch.zeros(H, device=dev); h0 = torch.zeros(nseq * A, H, device=dev)
     reset = (torch.rand(nseq, T, device=dev, generator=g) < 0.01).to(torch.uint8)
     hs = torch.empty(R, H, device=dev); gates = torch.empty(R, 4 * H, device=dev); hprev = torch.empty(R, H, device=dev)
-    timeit("gru_scan_fwd", lambda: L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hprev, nseq, T, A, st), 2.0 * R * H * 3 * H, 0)
+    timeit("gru_scan_fwd", lambda: L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hprev, nseq, T, A, None, st), 2.0 * R * H * 3 * H, 0)
     dhs = torch.randn(R, H, device=dev, generator=g) * 0.1
     dxi = torch.empty(R, 3 * H, device=dev); dhh = torch.empty(R, 3 * H, device=dev); slab = torch.empty((nseq * A + 63) // 64, H, device=dev)
     timeit("gru_scan_bwd", lambda: L.call("magpo_gru_scan_bwd", gates, hprev, reset, dhs, Wh, dxi, dhh, slab, nseq, T, A, st), 2.0 * R * H * 3 * H, 0)

@@ -129,22 +129,37 @@ def test_wgrad_whole_matrix(L, stream, KIN, NOUT, R, G):
 
 
 def test_gru_carry_equals_stepwise_scan(L, stream):
-    """magpo_gru_carry (time-major rollout trajectory, last state only) == the sequence-major scan on the same data."""
+    """magpo_gru_carry (time-major rollout trajectory, last state only) == the sequence-major scan on the same data; and xi rows
+    taken through a class table (xi_cls, csrc/classtab.hip) == the materialised rows, in both row layouts, bit for bit."""
     N, T, A, H = 37, 9, 3, 128
     g = torch.Generator().manual_seed(13)
-    xi_tm = torch.randn(T, N, A, 3 * H, generator=g) * 0.5            # rows (t, env, agent)
+    C = 11
+    tab = torch.randn(C, 3 * H, generator=g) * 0.5
+    cls_tm = torch.randint(0, C, (T, N, A), generator=g).int()         # rows (t, env, agent)
+    xi_tm = tab[cls_tm.long()]
     Wht = torch.randn(3 * H, H, generator=g) * 0.08
     bhn = torch.randn(H, generator=g) * 0.1
     h0 = torch.randn(N * A, H, generator=g) * 0.3
     reset_tm = (torch.rand(T, N, generator=g) < 0.2).to(torch.uint8)
     h_last = torch.zeros(N * A, H, device=DEV)
-    L.call("magpo_gru_carry", dev(xi_tm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last, N, T, A, stream)
+    L.call("magpo_gru_carry", dev(xi_tm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last, N, T, A, None, stream)
     xi_sm = xi_tm.permute(1, 0, 2, 3).contiguous()                     # rows (env, t, agent)
     hs = torch.zeros(N * T * A, H, device=DEV)
     L.call("magpo_gru_scan_fwd", dev(xi_sm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), None, dev(reset_tm.t().contiguous()), hs, None, None,
-           N, T, A, stream)
+           N, T, A, None, stream)
     ref = hs.view(N, T, A, H)[:, T - 1].reshape(N * A, H)
     assert torch.equal(h_last, ref)
+    h_last2 = torch.zeros(N * A, H, device=DEV)
+    L.call("magpo_gru_carry", dev(tab), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last2, N, T, A, dev(cls_tm.reshape(-1)), stream)
+    assert torch.equal(h_last2, h_last)
+    hs2 = torch.zeros(N * T * A, H, device=DEV); gates = [torch.zeros(N * T * A, 4 * H, device=DEV) for _ in range(2)]
+    hp = [torch.zeros(N * T * A, H, device=DEV) for _ in range(2)]
+    cls_sm = cls_tm.permute(1, 0, 2).contiguous().reshape(-1)
+    L.call("magpo_gru_scan_fwd", dev(xi_sm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), None, dev(reset_tm.t().contiguous()), hs, gates[0], hp[0],
+           N, T, A, None, stream)
+    L.call("magpo_gru_scan_fwd", dev(tab), dev(Wht), dev(bhn), dev(h0), None, dev(reset_tm.t().contiguous()), hs2, gates[1], hp[1],
+           N, T, A, dev(cls_sm), stream)
+    assert torch.equal(hs2, hs) and torch.equal(gates[0], gates[1]) and torch.equal(hp[0], hp[1])
 
 
 @pytest.mark.parametrize("F,R,relu", [(5, 100, 1), (5, 5003, 1), (8, 4096, 0), (3, 4096 * 32 * 2 + 4133, 1)])
@@ -432,7 +447,7 @@ def test_gru_scan(L, stream):
     rs = dev(done.to(torch.uint8))
     Wht = transpose_pad(L, stream, dev(Wh))
     L.call("magpo_gru_scan_fwd", xi, Wht, dev(p["gru.hn.bias"].detach().float()), dev(h0_store), dev(perm), rs, hsd, gates, hprev,
-           nseq, T, A, stream)
+           nseq, T, A, None, stream)
     close(hsd, to_rows(hs), 1e-4, 1e-5, "hs")
     dxi = torch.empty(R, 3 * H, device=DEV); dhh = torch.empty(R, 3 * H, device=DEV)
     nblk = (nseq * A + 63) // 64
