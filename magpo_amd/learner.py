@@ -126,7 +126,7 @@ class EnvGroup:
 class MagpoLearner:
     def __init__(self, env_cfg: CoordSumConfig, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
                  decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 512, num_groups: int = 1,
-                 n_block: int = 1, n_head: int = 1):
+                 n_block: int = 1, n_head: int = 1, embed_dim: int = 64):
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
         F = A + 1  # AgentIDWrapper (observation.py:42-54), add_agent_id: True
@@ -137,12 +137,12 @@ class MagpoLearner:
         # one contiguous buffer [guider grads | actor grads | loss scalars] = one all-reduce message (rec_magpo.py:395-409)
         from .params import FlatParams, actor_layout, guider_layout
         self.nb, self.nh = int(n_block), int(n_head)
-        gn = FlatParams(guider_layout(64, F, K, self.nb, self.nh), "cpu").numel
+        gn = FlatParams(guider_layout(int(embed_dim), F, K, self.nb, self.nh), "cpu").numel
         an = FlatParams(actor_layout(F, 128, K), "cpu").numel
         self.grad_all = torch.zeros(gn + an + 16, dtype=torch.float32, device=device)
         self.grad_acc = torch.zeros_like(self.grad_all) if num_groups > 1 else None
         self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
-                                  max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh,
+                                  max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh, embed_dim=int(embed_dim),
                                   seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn])
         self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
                               grads=self.grad_all[gn:gn + an])

@@ -43,7 +43,7 @@ class FlatParams:
 
 
 def guider_layout(E: int, F: int, K: int, nb: int = 1, nh: int = 1) -> "OrderedDict[str, Tuple[int, ...]]":
-    assert E == 64, "the gfx950 kernels are specialised for embed_dim = 64"
+    assert E in (16, 32, 64) and E % nh == 0, "embed_dim must be 16, 32 or 64 (narrower nets run embedded in the 64-wide kernels)"
     hs = E // nh  # GroupNorm scale / bias are per head channel (retention.py:247)
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     s["enc.ln.scale"] = (E,)
@@ -112,6 +112,96 @@ def guider_named_views(views: Dict[str, torch.Tensor], E: int = 64, nh: int = 1)
         else:
             out[n] = v
     return out
+
+
+class WidthEmbedding:
+    """Exact embedding of an embed_dim = E < 64 Sable network in the 64-wide kernels (E = 32: every feature twice, E = 16: four
+    times).  Activations are carried DUPLICATED, feature i at device positions m*i .. m*i + m - 1 (m = 64 / E): then every
+    mean over the 64 device channels (RMSNorm, GroupNorm over m * gs channels) equals the mean over the E logical ones, heads
+    stay contiguous, and element-wise ops are unchanged.  Parameters expand accordingly (`d` = duplicate along an axis, `z` =
+    value at position m*i, zeros behind it):
+        norm / GroupNorm scales, biases, positional-encoding rows            d
+        Dense F->E, (K+1)->E (embeddings)                                    columns d
+        Dense E->E read from duplicated activations (w_o, w_g, w_v, heads)   rows z, columns d
+        w_q, w_k                                                             rows z, columns z   (q.k over the logical features only)
+        Dense E->1 / E->K (value / logit heads)                              rows z
+    so that the 64-wide network computes the E-wide one exactly (up to fp32 summation order).  The device parameters are TIED
+    copies: the optimiser works on the logical buffer, ``expand`` rebuilds the device buffer after every step and ``fold`` sums
+    the device gradients of the copies (at most m addends; pure gathers, so bit-stable)."""
+
+    def __init__(self, E: int, F: int, K: int, nb: int, nh: int, device):
+        self.E, self.m = E, 64 // E
+        self.L = FlatParams(guider_layout(E, F, K, nb, nh), "cpu")
+        self.D = FlatParams(guider_layout(64, F, K, nb, nh), "cpu")
+        m = self.m
+        iota = torch.arange(1, self.L.numel + 1, dtype=torch.float64)
+        lv = self.L.views(iota)
+        dflat = torch.zeros(self.D.numel, dtype=torch.float64)
+        dv = self.D.views(dflat)
+
+        def d(x, ax):
+            return x.repeat_interleave(m, dim=ax)
+
+        def z(x, ax):
+            shp = list(x.shape)
+            shp[ax] *= m
+            out = torch.zeros(shp, dtype=x.dtype)
+            idx = [slice(None)] * x.dim()
+            idx[ax] = slice(0, None, m)
+            out[tuple(idx)] = x
+            return out
+
+        def blocks(x, kinds):   # fused projection [E, n*E]: column blocks of E with their own column rule, rows z
+            cols = [(d if kd == "d" else z)(x[:, i * E:(i + 1) * E], 1) for i, kd in enumerate(kinds)]
+            return z(torch.cat(cols, 1), 0)
+
+        for n, x in lv.items():
+            if n == "enc.obs.norm.scale" or n.endswith("dense1.bias"):
+                y = x
+            elif x.dim() == 1:
+                y = d(x, 0)
+            elif n in ("enc.obs.dense.kernel", "dec.act.kernel"):
+                y = d(x, 1)
+            elif n.endswith("dense1.kernel"):
+                y = z(x, 0)
+            elif n.endswith("w_qkvg"):
+                y = blocks(x, "zzdd")
+            elif n.endswith("w_kvg"):
+                y = blocks(x, "zdd")
+            elif n.endswith("retn2.w_q"):
+                y = z(z(x, 1), 0)
+            else:   # Dense E -> E on duplicated activations
+                y = z(d(x, 1), 0)
+            dv[n].copy_(y)
+        src = dflat.long() - 1                      # device element <- logical element (-1: structural zero)
+        self.gather = src.clamp(min=0).to(device)
+        self.mask = (src >= 0).to(torch.float32).to(device)
+        # fold: logical element <- its (up to m) device copies
+        pos = torch.nonzero(src >= 0).squeeze(1)
+        order = torch.argsort(src[pos], stable=True)
+        pos, owner = pos[order], src[pos][order]
+        counts = torch.bincount(owner, minlength=self.L.numel)
+        start = torch.cumsum(counts, 0) - counts
+        self.copies = []
+        for j in range(int(counts.max())):
+            has = counts > j
+            idx = torch.zeros(self.L.numel, dtype=torch.long)
+            idx[has] = pos[(start + j)[has]]
+            self.copies.append((idx.to(device), has.to(torch.float32).to(device)))
+
+    def expand(self, logical: torch.Tensor, out: torch.Tensor) -> None:
+        torch.mul(logical[self.gather], self.mask, out=out)
+
+    def fold(self, dev_grads: torch.Tensor, out: torch.Tensor) -> None:
+        idx, has = self.copies[0]
+        acc = dev_grads[idx] * has
+        for idx, has in self.copies[1:]:
+            acc = acc + dev_grads[idx] * has
+        out.copy_(acc)
+
+    def expand_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """[*, E] rows (positional encodings) -> [*, 64] duplicated."""
+        return x.repeat_interleave(self.m, dim=-1).contiguous()
 
 
 def actor_layout(F: int, H: int, K: int) -> "OrderedDict[str, Tuple[int, ...]]":

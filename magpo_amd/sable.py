@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from ._lib import lib
-from .params import FlatParams, guider_layout, guider_named_views, init_guider
+from .params import FlatParams, WidthEmbedding, guider_layout, guider_named_views, init_guider
 
 E = 64
 
@@ -45,10 +45,12 @@ class SableGuider:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, embed_dim: int = 64, n_head: int = 1,
                  n_block: int = 1, decay_scaling_factor: float = 0.8, use_pe: bool = True, max_pos: int = 101,
                  wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
-        if embed_dim != 64 or n_head not in (1, 2, 4) or n_block < 1:
-            raise NotImplementedError("gfx950 Sable kernels: embed_dim=64 and n_head in {1, 2, 4} (SURVEY 8f rank 3)")
+        if embed_dim not in (16, 32, 64) or n_head not in (1, 2, 4) or n_block < 1 or embed_dim % n_head or 64 // n_head // n_head < 4:
+            raise NotImplementedError("gfx950 Sable kernels: embed_dim in {16, 32, 64} (narrower nets run embedded in the 64-wide "
+                                      "kernels, params.WidthEmbedding) and n_head in {1, 2, 4} (SURVEY 8f rank 3)")
         self.nb, self.nh = int(n_block), int(n_head)
-        self.hs = E // self.nh          # head width
+        self.EL = int(embed_dim)        # logical embed_dim (what the optimiser, checkpoints and the reference see)
+        self.hs = E // self.nh          # head width of the 64-wide device network
         self.gs = self.hs // self.nh    # flax GroupNorm(num_groups=n_head) on (token*head, hs) rows: hs / n_head channels per group
         if obs_dim > 32 or action_dim > 31:
             raise NotImplementedError("obs_dim <= 32 and action_dim <= 31 required")
@@ -58,19 +60,32 @@ class SableGuider:
         self.kappas = decay_kappas(self.nh, decay_scaling_factor)
         self.kappa = self.kappas[0]
         self.G = wgrad_groups
-        self.P = FlatParams(guider_layout(E, obs_dim, action_dim, self.nb, self.nh), device)
+        # P / grads: the LOGICAL parameters (optimiser, all-reduce, checkpoints); PD / grads_D: what the kernels read and write.
+        # For embed_dim = 64 they are the same buffers.
+        self.P = FlatParams(guider_layout(self.EL, obs_dim, action_dim, self.nb, self.nh), device)
         self.grads = torch.zeros_like(self.P.flat) if grads is None else grads
         assert self.grads.numel() == self.P.numel
-        self.v = self.P.views()
-        self.gv = self.P.views(self.grads)
-        self.named = guider_named_views(self.v, E, self.nh)
-        self.named_grads = guider_named_views(self.gv, E, self.nh)
+        if self.EL == E:
+            self.emb, self.PD, self.grads_D = None, self.P, self.grads
+        else:
+            self.emb = WidthEmbedding(self.EL, obs_dim, action_dim, self.nb, self.nh, device)
+            self.PD = FlatParams(guider_layout(E, obs_dim, action_dim, self.nb, self.nh), device)
+            self.grads_D = torch.zeros_like(self.PD.flat)
+        self.v = self.PD.views()
+        self.gv = self.PD.views(self.grads_D)
+        self.named = guider_named_views(self.P.views(), self.EL, self.nh)
+        self.named_grads = guider_named_views(self.P.views(self.grads), self.EL, self.nh)
         if seed is not None:
-            init_guider(self.named, seed)
+            init_guider(self.named, seed, self.EL)
         self.npos = max_pos
         self.pe = torch.zeros(max_pos, E, device=device)
         if use_pe:
-            self.L.call("magpo_pe_table", self.pe, max_pos, E, self._st())
+            if self.emb is None:
+                self.L.call("magpo_pe_table", self.pe, max_pos, E, self._st())
+            else:   # positional_encoding.py:24-60 at the logical width, every feature duplicated like the activations
+                pe_l = torch.zeros(max_pos, self.EL, device=device)
+                self.L.call("magpo_pe_table", pe_l, max_pos, self.EL, self._st())
+                self.pe.copy_(self.emb.expand_rows(pe_l))
         self.wt: Dict[str, torch.Tensor] = {}
         self.b = _Bufs(device)
         self._act_tabs: Dict[tuple, tuple] = {}
@@ -109,7 +124,9 @@ class SableGuider:
         return t
 
     def refresh(self):
-        """Rebuild the transposed (forward-GEMM) weight copies after a parameter update."""
+        """Rebuild the device parameters (embed_dim < 64) and the transposed (forward-GEMM) weight copies after a parameter update."""
+        if self.emb is not None:
+            self.emb.expand(self.P.flat, self.PD.flat)
         v = self.v
         self._tp("vh0", v["enc.head.dense0.kernel"])
         self._tp("h0", v["dec.head.dense0.kernel"])
@@ -642,3 +659,5 @@ class SableGuider:
                 self.reduce(slab("w", 32 * E), gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)
         if self.overlap_wgrad and self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+        if self.emb is not None:   # gradient of a logical parameter = sum over its tied device copies
+            self.emb.fold(self.grads_D, self.grads)

@@ -140,13 +140,14 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
         mc.chunk_size = config.system.rollout_length * env.num_agents
     if mc.type != "rec_sable":
         raise NotImplementedError("memory_config.type must be rec_sable")
-    if int(nc.embed_dim) != 64 or int(nc.n_head) not in (1, 2, 4) or int(config.network.hidden_state_dim) != 128:
-        raise NotImplementedError("HIP kernels support embed_dim=64, n_head in {1,2,4}, hidden_state_dim=128 (any n_block)")
+    if int(nc.embed_dim) not in (16, 32, 64) or int(nc.n_head) not in (1, 2, 4) or int(config.network.hidden_state_dim) != 128:
+        raise NotImplementedError("HIP kernels support embed_dim in {16,32,64}, n_head in {1,2,4}, hidden_state_dim=128 (any n_block)")
     device = device or torch.device("cuda", torch.cuda.current_device())
     U = int(config.system.update_batch_size)
     learner = MagpoLearner(env.cfg, int(config.arch.num_envs), _system_config(config), device,
                            net_seed=int(net_key[1]) & 0x7FFFFFFF, decay_scaling_factor=float(mc.decay_scaling_factor),
-                           use_pe=bool(mc.timestep_positional_encoding), num_groups=U, n_block=int(nc.n_block), n_head=int(nc.n_head))
+                           use_pe=bool(mc.timestep_positional_encoding), num_groups=U, n_block=int(nc.n_block), n_head=int(nc.n_head),
+                           embed_dim=int(nc.embed_dim))
     learner.setup(key, n_groups=world * U, group=rank * U)
     grad_sync = mdist.make_grad_sync(world)
     learn = get_learner_fn(env, learner, grad_sync, config)

@@ -13,18 +13,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _mk(A, K, TL, maxval, N, T, P=2, M=2, seed=42, nb=1, nh=1):
+def _mk(A, K, TL, maxval, N, T, P=2, M=2, seed=42, nb=1, nh=1, E=64):
     from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
     spec = ocs.CoordSumSpec(A, K, TL, maxval)
-    scfg = onets.SableCfg(A, K, A + 1, n_block=nb, n_head=nh)
+    scfg = onets.SableCfg(A, K, A + 1, embed_dim=E, n_block=nb, n_head=nh)
     osys = olearn.SystemCfg(rollout_length=T, ppo_epochs=P, num_minibatches=M)
-    gp = onets.init_guider_params(1, 64, A + 1, K, nb=nb, nh=nh)
+    gp = onets.init_guider_params(1, E, A + 1, K, nb=nb, nh=nh)
     ap = onets.init_actor_params(2, A + 1, 128, K)
     ol = olearn.OracleLearner(spec, N, osys, scfg, gp, ap)
     key = oprng.split(oprng.prng_key(seed), 4)[0]
     ol.setup(key)
     dl = MagpoLearner(CoordSumConfig(A, K, TL, maxval), N, SystemConfig(rollout_length=T, ppo_epochs=P, num_minibatches=M), DEV,
-                      net_seed=None, wgrad_groups=8, n_block=nb, n_head=nh)
+                      net_seed=None, wgrad_groups=8, n_block=nb, n_head=nh, embed_dim=E)
     dl.guider.load_named(gp)
     dl.actor.load_named(ap)
     dl.setup(key)
@@ -39,14 +39,17 @@ def close(a, b, rtol, atol, what):
     assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} (ref scale {ref:.3e})"
 
 
-@pytest.mark.parametrize("A,K,TL,maxval,N,T,nb,nh", [(4, 20, 10, 60, 8, 16, 1, 1), (2, 10, 7, 15, 4, 12, 1, 1), (3, 10, 9, 30, 6, 11, 1, 1),
-                                                       (4, 20, 10, 60, 8, 16, 2, 1), (8, 15, 9, 100, 4, 11, 3, 1),
-                                                       (5, 20, 9, 80, 4, 11, 2, 2), (3, 10, 9, 30, 6, 10, 1, 4),
+@pytest.mark.parametrize("A,K,TL,maxval,N,T,nb,nh,E", [(4, 20, 10, 60, 8, 16, 1, 1, 64), (2, 10, 7, 15, 4, 12, 1, 1, 64), (3, 10, 9, 30, 6, 11, 1, 1, 64),
+                                                       (4, 20, 10, 60, 8, 16, 2, 1, 64), (8, 15, 9, 100, 4, 11, 3, 1, 64),
+                                                       (5, 20, 9, 80, 4, 11, 2, 2, 64), (3, 10, 9, 30, 6, 10, 1, 4, 64),
+                                                       # embed_dim 32 / 16 (tuned CoordSum 3x10 and both LBF rows of experiment_data/params.csv:
+                                                       # n_embd 32 with 1 / 4 heads): the narrow net runs embedded in the 64-wide kernels
+                                                       (3, 10, 9, 30, 6, 11, 2, 1, 32), (4, 20, 10, 60, 4, 12, 1, 2, 32), (2, 10, 7, 15, 4, 12, 1, 2, 16),
                                                        # the default rollout length on BASELINE's shapes: 8 / 16 / 10 retention chunks per
                                                        # sequence (more than 8 takes the per-chunk bookkeeping branch), narrow heads over 10 chunks
-                                                       (4, 20, 100, 60, 4, 128, 1, 1), (8, 15, 100, 100, 2, 128, 1, 1), (5, 20, 100, 80, 2, 128, 1, 2)])
-def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh):
-    ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb, nh=nh)
+                                                       (4, 20, 100, 60, 2, 128, 1, 1, 64), (8, 15, 100, 100, 2, 128, 1, 1, 64), (5, 20, 100, 80, 2, 128, 1, 2, 64)])
+def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh, E):
+    ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb, nh=nh, E=E)
     assert np.array_equal(dl.env.target.cpu().numpy(), ol.env_state["target"])
     assert np.array_equal(dl.key, ol.key)
     om = ol.rollout(record_logits=True)
@@ -66,9 +69,13 @@ def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh):
         assert np.array_equal(dl.metrics[k].cpu().numpy(), om[k]), k
     assert om["is_terminal_step"].any(), "the test must cross an episode boundary"
     for d, o in zip(dl.sable_hs, ol.sable_hs):
-        hs = 64 // nh   # device head states are zero-padded to 64 x 64; oracle layout (N, nh, nb, hs, hs)
-        close(d[:, :, :, :hs, :hs], o.permute(2, 1, 0, 3, 4), 1e-4, 1e-6, "sable state")
+        # device head states are zero-padded to 64 x 64; oracle layout (N, nh, nb, hs, hs).  With embed_dim < 64 every feature is
+        # carried m = 64 / E times (params.WidthEmbedding): S'[m i, m j + c] = S[i, j], the rows between are zero
+        hs, m = 64 // nh, 64 // E
+        close(d[:, :, :, :hs:m, :hs:m], o.permute(2, 1, 0, 3, 4), 1e-4, 1e-6, "sable state")
         assert float(d[:, :, :, hs:, :].abs().max() if hs < 64 else 0.0) == 0.0
+        if m > 1:
+            assert float(d[:, :, :, 1:hs:m, :].abs().max()) == 0.0 and torch.equal(d[:, :, :, :hs:m, 1:hs:m], d[:, :, :, :hs:m, :hs:m])
     close(dl.policy_h[dl._cur], ol.policy_h.reshape(N * A, 128), 1e-4, 1e-6, "policy hidden")
     assert np.array_equal(dl.key, ol.key)
 
@@ -118,7 +125,7 @@ def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh):
         for net, ref, opt, mu, nu in ((dl.guider, ol.gp, ol.g_opt, dl.g_mu, dl.g_nu), (dl.actor, ol.ap, ol.a_opt, dl.a_mu, dl.a_nu)):
             mv, nv = net.P.views(mu), net.P.views(nu)
             from magpo_amd.params import actor_named_views, guider_named_views
-            named = (lambda v: guider_named_views(v, 64, nh)) if net is dl.guider else actor_named_views
+            named = (lambda v: guider_named_views(v, E, nh)) if net is dl.guider else actor_named_views
             mn, nn = named(mv), named(nv)
             for n in ref:
                 ref[n] = net.named[n].detach().cpu().reshape(ref[n].shape).clone()
@@ -244,3 +251,25 @@ def test_class_tables_equal_dense_path(A, K, N, T, nb):
             gb = getattr(b, net).named_grads[n]
             scale = float(ga.abs().max())
             assert float((ga - gb).abs().max()) <= 3e-5 * scale + 1e-9, f"{net} gradient {n} differs between class tables and the dense path"
+
+
+def test_embed32_four_heads_lbf_setting():
+    """n_embd = 32 with 4 heads (both LBF rows of experiment_data/params.csv): head width 8, GroupNorm groups of TWO channels.
+    The normalised output is then +-gamma (a - b) / (2 sqrt(var + eps)) with a ~ b at init, which is ill-conditioned in fp32
+    for every implementation: the fp32 oracle at embed_dim 32 and the fp32 oracle run on the expanded 64-wide parameters differ
+    by ~1 % in the w_v gradients although they agree to 1e-12 in fp64 (scripts/debug/emb_grads.py).  So: rollout bit-exact /
+    1e-4 as everywhere, gradients against the oracle at a 5 % bound here; the 2e-3 bound is kept by the 1- and 2-head cases."""
+    A, K, TL, maxval, N, T, nb, nh, E = 4, 20, 10, 60, 4, 12, 1, 4, 32
+    ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb, nh=nh, E=E)
+    ol.rollout(); dl.rollout()
+    assert np.array_equal(dl.traj["action"].cpu().numpy(), ol.traj["action"].numpy())
+    close(dl.traj["value"], ol.traj["value"], 1e-4, 1e-6, "value")
+    close(dl.traj["log_prob"], ol.traj["log_prob"], 1e-5, 1e-6, "log_prob")
+    ks = oprng.split(ol.key, 4)
+    bp, apm = oprng.permutation(ks[1], N), oprng.permutation(ks[2], A)
+    gg, ag, info, inter = ol.minibatch_grads(ol.make_minibatches(bp, apm)[0])
+    dl.minibatch_grads(dl._permutation(ks[1], N)[:N // 2].contiguous(), dl._permutation(ks[2], A))
+    close(dl.guider.b.t["t_value"], inter["value"], 1e-4, 1e-6, "train value")
+    for n, g in dl.guider.named_grads.items():
+        scale = max(gg[n].abs().max().item(), 1e-6)
+        close(g / scale, gg[n].reshape(g.shape) / scale, 0, 5e-2, f"guider grad {n}")
