@@ -73,15 +73,19 @@ class GruActor:
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self._st())
 
+    def _groups(self, R):
+        """Row slabs of a split weight gradient: no more than one per 256 rows (small minibatches: fewer partials to reduce)."""
+        return max(1, min(self.G, R // 256))
+
     def wgrad(self, X, ldx, dY, ldy, R, KIN, NOUT, dW, db=None, krows=None):
         """dW = X^T dY, queued on the side stream (off the critical path of the backward chain)."""
         side = self.wgrad_stream if self.overlap_wgrad else None
         if side is None:
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
 
     # one step for N envs: returns new hidden [N*A,128]; logits [N*A,64] if want_logits
     def step(self, obs, h_in, reset_env, h_out, want_logits: bool = False):

@@ -148,6 +148,14 @@ class MagpoLearner:
                               grads=self.grad_all[gn:gn + an])
         self.loss_out = self.grad_all[gn + an:gn + an + 9]
         self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb, self.nh) for _ in range(num_groups)]
+        # rollout-start states of all groups in ONE tensor each (group g = envs g*N .. g*N + N - 1), so that the minibatches of all
+        # local groups train as one batch of sequences (update(): the groups differ only in their advantage statistics)
+        U_, N_ = num_groups, num_envs
+        self._prev_hs = tuple(torch.zeros(self.nb, self.nh, U_ * N_, 64, 64, device=device) for _ in range(3))
+        self._policy_h0 = torch.zeros(U_ * N_ * A, 128, device=device)
+        for gi, g in enumerate(self.groups):
+            g.prev_sable_hs = tuple(t[:, :, gi * N_:(gi + 1) * N_] for t in self._prev_hs)
+            g.policy_h0 = self._policy_h0[gi * N_ * A:(gi + 1) * N_ * A]
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         # optimiser state (optax adam: count, mu, nu)
         self.g_mu, self.g_nu = torch.zeros_like(self.guider.P.flat), torch.zeros_like(self.guider.P.flat)
@@ -211,6 +219,7 @@ class MagpoLearner:
     batched_actor_carry = True  # actor hidden-state carry as ONE scan over the finished trajectory (not T single steps)
     fused_act = True  # one launch per env step for the whole Sable acting step (csrc/act_fused.hip)
     use_graph = True  # replay the whole rollout as one HIP graph (removes ~11K host launches per rollout)
+    batch_groups = True  # update_batch_size > 1: the minibatches of all local groups train as one batch of sequences
 
     def rollout(self):
         for g in self.groups:
@@ -337,21 +346,29 @@ class MagpoLearner:
         return x.contiguous()
 
     # ------------------------------------------------------------------ one minibatch (rec_magpo.py:217-435)
-    def _gather(self, g: EnvGroup, env_idx: torch.Tensor, agent_perm: torch.Tensor):
+    def _gather(self, groups: List[int], env_idx: torch.Tensor, agent_perm: torch.Tensor):
+        """Minibatch rows (j, t, a') of the listed groups, group after group, in sequence-major order."""
         T, N, A, F, K = self.T, self.N, self.A, self.F, self.K
-        mb = env_idx.numel()
-        R = mb * T * A
+        mb, U = env_idx.numel(), len(groups)
+        R1 = mb * T * A
+        R = U * R1
         m = self._mb
         if m.get("R") != R:
             f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
             i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=self.dev)
-            m.update(R=R, obs=f32(R, F), action=i32(R), prev=i32(R), pos=i32(R), done=torch.empty(mb, T, dtype=torch.uint8, device=self.dev),
-                     value=f32(R), logp=f32(R), adv=f32(R), targets=f32(R), h0idx=i32(mb * A),
+            m.update(R=R, obs=f32(R, F), action=i32(R), prev=i32(R), pos=i32(R), done=torch.empty(U * mb, T, dtype=torch.uint8, device=self.dev),
+                     value=f32(R), logp=f32(R), adv=f32(R), targets=f32(R), h0idx=i32(U * mb * A),
                      dg=f32(R, 64), da=f32(R, 64), dv=f32(R))
-        tr = g.traj
-        self.L.call("magpo_gather_minibatch", tr["obs"], tr["action"], tr["step_count"], tr["done"], None, tr["value"], tr["log_prob"],
-                    tr["adv"], tr["targets"], env_idx, agent_perm, m["obs"], m["action"], m["prev"], m["pos"], m["done"], None,
-                    m["value"], m["logp"], m["adv"], m["targets"], m["h0idx"], T, N, A, F, K, mb, self._st())
+        for u, gi in enumerate(groups):
+            tr = self.groups[gi].traj
+            r = slice(u * R1, (u + 1) * R1)
+            h0 = m["h0idx"][u * mb * A:(u + 1) * mb * A]
+            self.L.call("magpo_gather_minibatch", tr["obs"], tr["action"], tr["step_count"], tr["done"], None, tr["value"], tr["log_prob"],
+                        tr["adv"], tr["targets"], env_idx, agent_perm, m["obs"][r], m["action"][r], m["prev"][r], m["pos"][r],
+                        m["done"][u * mb:(u + 1) * mb], None, m["value"][r], m["logp"][r], m["adv"][r], m["targets"][r], h0, T, N, A, F, K, mb,
+                        self._st())
+            if gi:
+                h0.add_(gi * N * A)      # rows of the stacked start states
         return m
 
     def _class_rows(self):
@@ -387,15 +404,23 @@ class MagpoLearner:
         out["act"] = (c["obs_act"], cls_act, out["enc"][1], out["enc"][2][::c["npos"]].contiguous())
         return out
 
-    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group: int = 0, hs_idx: Optional[torch.Tensor] = None):
-        """Forward + loss + backward of both networks for one minibatch of one group; gradients land in
-        guider.grads / actor.grads, loss scalars in self.loss_out (all inside self.grad_all, on device).
+    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group=0, hs_idx: Optional[torch.Tensor] = None):
+        """Forward + loss + backward of both networks for one minibatch; gradients land in guider.grads / actor.grads, loss
+        scalars in self.loss_out (all inside self.grad_all, on device).  ``group``: one group index, or a list of groups that
+        train as ONE batch of sequences -- every group uses the same env / agent permutation and the loss is a mean
+        over rows, so the batch gradient is the unweighted mean of the groups' gradients (the pmean over the "batch" axis,
+        rec_magpo.py:395-397); only the advantage normalisation stays per group (rec_magpo.py:283,356).
         ``hs_idx`` [mb]: env whose rollout-start Sable states sequence j trains on (quirk B19: in the reference
         it differs from ``env_idx`` after the first PPO epoch); default = ``env_idx``."""
-        s, T, A, K = self.sys, self.T, self.A, self.K
-        g = self.groups[group]
-        m = self._gather(g, env_idx, agent_perm)
+        s, T, A, K, N = self.sys, self.T, self.A, self.K, self.N
+        groups = [group] if isinstance(group, int) else list(group)
+        U = len(groups)
+        m = self._gather(groups, env_idx, agent_perm)
         mb, R = env_idx.numel(), m["R"]
+        nseq, R1 = U * mb, R // U
+        hidx = env_idx if hs_idx is None else hs_idx
+        if U > 1 or groups[0]:
+            hidx = torch.cat([hidx + gi * N for gi in groups])
         cl = self._classes(m) if self.class_tables else None
         acl = None if cl is None else cl["act"]
         gcl = None if cl is None else dict(rows=(self._cls["obs_enc"], self._cls["pos_enc"], self._cls["prev_dec"], self._cls["pos_dec"]),
@@ -405,17 +430,27 @@ class MagpoLearner:
         if side is not None:
             side.wait_stream(main)  # minibatch gather (and the previous optimiser step) are complete for the actor
             with torch.cuda.stream(side):
-                a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T, classes=acl)
-        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], g.prev_sable_hs,
-                                                env_idx if hs_idx is None else hs_idx, mb, T, classes=gcl)
+                a_logits = self.actor.seq_fwd(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
+        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], self._prev_hs, hidx, nseq, T, classes=gcl)
         if side is not None:
             main.wait_stream(side)
         else:
-            a_logits = self.actor.seq_fwd(m["obs"], m["done"], g.policy_h0, m["h0idx"], mb, T, classes=acl)
+            a_logits = self.actor.seq_fwd(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
         st = self._st()
-        self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
+        if U == 1:
+            self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
+            stats = self.adv_stats
+        else:   # per-group statistics, applied in place with the loss kernel's own expression (adv - mean) * rstd; identity stats after
+            if getattr(self, "_adv_stats_u", None) is None or self._adv_stats_u.shape[0] != U:
+                self._adv_stats_u = torch.zeros(U, 2, device=self.dev)
+                self._adv_ident = torch.tensor([0.0, 1.0], device=self.dev)
+            for u in range(U):
+                self.L.call("magpo_adv_moments", m["adv"][u * R1:(u + 1) * R1], R1, self.ws64, self._adv_stats_u[u], st)
+            a2 = m["adv"].view(U, R1)
+            a2.sub_(self._adv_stats_u[:, 0:1]).mul_(self._adv_stats_u[:, 1:2])
+            stats = self._adv_ident
         self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, None, m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],
-                    self.adv_stats, m["dg"], 64, m["da"], 64, m["dv"], self.ws64, self.loss_out, R, K, s.clip_eps, s.clip_gpo,
+                    stats, m["dg"], 64, m["da"], 64, m["dv"], self.ws64, self.loss_out, R, K, s.clip_eps, s.clip_gpo,
                     s.ent_coef, s.vf_coef, s.alpha, st)
         if side is not None:
             side.wait_stream(main)  # loss gradients are ready
@@ -471,13 +506,18 @@ class MagpoLearner:
                 hidx = hs_idx[mi * mbs:(mi + 1) * mbs].contiguous()
                 if U == 1:
                     self.minibatch_grads(idx, agent_perm, 0, hidx)
-                else:  # pmean over the "batch" axis (:395-397): accumulate, the 1/U goes into grad_scale
+                    scale = 1.0
+                elif self.batch_groups:   # all local groups as one batch of sequences: the row mean IS the pmean over "batch"
+                    self.minibatch_grads(idx, agent_perm, list(range(U)), hidx)
+                    scale = 1.0
+                else:  # group by group: accumulate, the 1/U goes into grad_scale
                     self.grad_acc.zero_()
                     for gi in range(U):
                         self.minibatch_grads(idx, agent_perm, gi, hidx)
                         self.grad_acc.add_(self.grad_all)
                     self.grad_all.copy_(self.grad_acc)
-                scale = (grad_sync(self) if grad_sync is not None else 1.0) / U
+                    scale = 1.0 / U
+                scale *= grad_sync(self) if grad_sync is not None else 1.0
                 self.apply_grads(scale)
                 losses[e, mi].copy_(self.loss_out)
                 losses[e, mi].mul_(scale)

@@ -142,17 +142,21 @@ class SableGuider:
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self._st())
 
+    def _groups(self, R):
+        """Row slabs of a split weight gradient: no more than one per 256 rows (small minibatches: fewer partials to reduce)."""
+        return max(1, min(self.G, R // 256))
+
     def wgrad(self, X, ldx, dY, ldy, R, KIN, NOUT, dW, db=None, krows=None):
         """dW = X^T dY.  With overlap_wgrad the GEMM is queued on the side stream behind everything the calling stream
         has queued so far (so X and dY are complete); the caller must not overwrite dY before train_bwd joins."""
         # (with n_block > 1 the d(obs_rep) sums are accumulated in place, so the side stream is not used)
         side = self.wgrad_stream if (self.overlap_wgrad and self.nb == 1) else None
         if side is None:
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self.G, 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
 
     def reduce(self, slab, out, P=64, stride=None, accumulate=False):
         self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P, stride or slab.shape[1], 1.0, 1 if accumulate else 0, self._st())
