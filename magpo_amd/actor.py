@@ -104,7 +104,7 @@ class GruActor:
         self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
         return logits
 
-    def carry(self, obs_tm, h_in, reset_tm, h_out, classes=None):
+    def carry(self, obs_tm, h_in, reset_tm, h_out, classes=None, tag=""):
         """Hidden-state carry over a whole rollout at once: obs_tm [T,N,A,F] (time-major trajectory), reset_tm [T,N] u8
         reset-before-step flags, h_in / h_out [N*A,128].  Same result as T calls of :meth:`step` (ScannedRNN, base.py:121-149):
         the carry depends on (obs, done) only, never on the sampled actions.  ``classes`` = (obs_tab [C,F], cls [T*N*A] i32):
@@ -113,7 +113,7 @@ class GruActor:
         T, N = obs_tm.shape[0], obs_tm.shape[1]
         R = T * N * A
         if classes is not None:
-            _, xi_tab = self.input_table(classes[0], "r")
+            _, xi_tab = self.input_table(classes[0], "r" + tag)
             L.call("magpo_gru_carry", xi_tab, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, classes[1], st)
             return
         emb = b.get("c_emb", (R, H)); xi = b.get("c_xi", (R, 3 * H))

@@ -222,6 +222,22 @@ class MagpoLearner:
     batch_groups = True  # update_batch_size > 1: the minibatches of all local groups train as one batch of sequences
 
     def rollout(self):
+        if len(self.groups) > 1 and self.use_graph and self.fused_act and self.A <= 8 and self.class_tables and self.batched_actor_carry \
+                and all(g.graph is not None for g in self.groups):
+            # the groups' rollouts are independent: replay their graphs side by side (at small num_envs a rollout is a latency
+            # chain that leaves most of the chip idle)
+            main = torch.cuda.current_stream()
+            for g in self.groups:
+                self._rollout_keys(g)
+                self._upload_keys(g)
+            for gi, g in enumerate(self.groups):
+                st = self._group_stream(gi)
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    g.graph.replay()
+            for gi in range(len(self.groups)):
+                main.wait_stream(self._group_stream(gi))
+            return
         for g in self.groups:
             self._rollout_keys(g)
             if not self.use_graph or g.graph_failed:
@@ -235,6 +251,13 @@ class MagpoLearner:
             else:
                 self._upload_keys(g)
                 self._capture(g)
+
+    def _group_stream(self, gi: int):
+        if not hasattr(self, "_gstreams"):
+            self._gstreams = {}
+        if gi not in self._gstreams:
+            self._gstreams[gi] = torch.cuda.Stream(device=self.dev)
+        return self._gstreams[gi]
 
     def _upload_keys(self, g: EnvGroup):
         # pageable source: the runtime stages the 8 KB immediately, so the host table can be reused right away
@@ -280,7 +303,8 @@ class MagpoLearner:
         main = torch.cuda.current_stream()
         side = self._actor_stream if self.overlap_actor_step else None
         fused = self.fused_act
-        act = self.guider.act_fused if fused else self.guider.act
+        gtag = str(self.groups.index(g))
+        act = (lambda *a, **k: self.guider.act_fused(*a, tag=gtag, **k)) if fused else self.guider.act
 
         def zero_done(done):
             for k in range(self.nb):
@@ -316,7 +340,7 @@ class MagpoLearner:
                     g.traj_cls = torch.empty(T * N * A, dtype=torch.int32, device=self.dev)
                 L.call("magpo_coordsum_classes", tr["obs"], self.F, None, None, A, self.env_cfg.maxval, 1, g.traj_cls, None, T * N * A, st)
                 ccl = (self._class_rows()["obs_act"], g.traj_cls)
-            self.actor.carry(tr["obs"][:T], g.policy_h[g.cur], tr["done"][:T], g.policy_h[1 - g.cur], classes=ccl)
+            self.actor.carry(tr["obs"][:T], g.policy_h[g.cur], tr["done"][:T], g.policy_h[1 - g.cur], classes=ccl, tag=gtag)
             g.cur = 1 - g.cur
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])

@@ -292,7 +292,7 @@ class SableGuider:
             L.call("magpo_sample_categorical", logits, E, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
                    k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
 
-    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None):
+    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag=""):
         """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a wave carries 8 envs
         through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64].  ``done`` [N] u8
         (optional): envs whose episode ended on the previous step -- their carried states are read as zero
@@ -315,7 +315,7 @@ class SableGuider:
                      value_out.data_ptr(), None if done is None else done.data_ptr())
         tabs = self._act_tabs.get(cache_key)
         if tabs is None:
-            g = lambda n, w=E, rows=R: b.get("f_" + n, (rows, w))
+            g = lambda n, w=E, rows=R: b.get(f"f{tag}_" + n, (rows, w))   # scratch per caller tag (env groups may act concurrently)
             ptr = lambda t: 0 if t is None else t.data_ptr()
             glob = [obs, pos, mask, kdev,
                     v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], v["enc.ln.scale"], v["dec.act.kernel"], v["dec.ln.scale"],
@@ -325,7 +325,7 @@ class SableGuider:
                     g("xn"), done, g("qkvg", 4 * E), g("u"), g("y"), g("rep"), g("reppe"), g("hv"),
                     g("xa", E, N), g("kin1", E, N), g("y1", E, N), g("c", E, N), g("cpe", E, N), g("y2", E, N), g("xo", E, N),
                     g("xope", E, N), g("hp", E, N), g("hn", E, N), g("logits", E, N), g("u1"), g("u2"),
-                    b.get("f_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out]
+                    b.get(f"f{tag}_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out]
             blk = []
             for k in range(nb):
                 e, d = f"enc.block{k}.", f"dec.block{k}."
