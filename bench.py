@@ -100,6 +100,12 @@ class KernelTimer:
             # (98 304 B at E = 64, one block, one head).  Everything else the launch touches (obs, weights, outputs) is < 1 %.
             state = 4.0 * nb * nh * hs * hs
             return f"k_sable_act<{A}>", 6.0 * state * N, N * A * (46.0 * 64 * 64 + 12.0 * 64 * 64 / nh)
+        if name == "magpo_coordsum_step":   # ~0.5 KB per env-step (record row + targets + obs / reward / metrics out)
+            N, A, TL = a[9], a[10], a[12]
+            return "k_coordsum_step", float(N) * (4.0 * TL + 4.0 * A * (A + 2) + 64.0), 0.0
+        if name == "magpo_lbf_step":        # state in + out, observation + action mask + reward / metrics out
+            N, A, NF = a[12], a[13], a[14]
+            return "k_lbf_step", float(N) * (2.0 * (12.0 * A + 13.0 * NF + 40.0) + 4.0 * A * (A + 3 * (NF + A)) + 6.0 * A + 4.0 * A + 12.0), 0.0
         if name == "magpo_loss_fwd_bwd":
             R, K = a[19], a[20]
             return "k_magpo_loss", 4.0 * R * (4 * K + 8), 60.0 * R * K
@@ -211,8 +217,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (weak scaling)")
-    ap.add_argument("--workload", default="coordsum-4ag", choices=["coordsum-4ag", "coordsum-8x15"],
-                    help="coordsum-4ag = BASELINE.json configs[1] (headline); coordsum-8x15 = configs[4] per GPU (registered 8x15-100, n_block=2, 8 minibatches)")
+    ap.add_argument("--workload", default="coordsum-4ag", choices=["coordsum-4ag", "coordsum-8x15", "lbf-8x8-2p-2f"],
+                    help="coordsum-4ag = BASELINE.json configs[1] (headline); coordsum-8x15 = configs[4] per GPU (registered 8x15-100, n_block=2, 8 minibatches); "
+                         "lbf-8x8-2p-2f = configs[2] (Level-Based Foraging 8x8-2p-2f-coop, UNPINNED dynamics: csrc/lbf.hip restates Jumanji's published algorithm)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
@@ -222,7 +229,7 @@ def main():
 
     from magpo_amd import distributed as mdist
     from magpo_amd._lib import lib
-    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    from magpo_amd.learner import CoordSumConfig, LbfConfig, MagpoLearner, SystemConfig, host_split, prng_key
     import torch.distributed as dist
 
     rank, world, local = mdist.init_from_env(args.backend)
@@ -238,6 +245,10 @@ def main():
         sysc = SystemConfig(num_minibatches=8)  # 8 agents: 8 minibatches (as the tuned run) keep R = mb*T*A at 2.1 M rows
         env_cfg = CoordSumConfig(num_agents=8, num_actions=15, time_limit=100, maxval=100)
         n_block = 2
+    elif args.workload == "lbf-8x8-2p-2f":
+        sysc = SystemConfig()
+        env_cfg = LbfConfig(grid_size=8, fov=8, num_agents=2, num_food=2, max_agent_level=2, force_coop=True, time_limit=100)
+        n_block = 1
     else:
         sysc = SystemConfig()  # reference defaults (configs/system/gpo/rec_magpo.yaml)
         env_cfg = CoordSumConfig(num_agents=4, num_actions=20, time_limit=100, maxval=60)
@@ -285,7 +296,7 @@ def main():
         # The acting kernel runs inside the rollout's HIP graph, where per-launch events cannot be recorded: time it on one
         # EAGER rollout here (same kernel, same shapes, same data distribution), still outside the timed region.  Every rank
         # runs this extra update step so that the replicas stay in lock-step.
-        lib().timer, timer.enabled, timer.only = timer, True, ("magpo_sable_act",)
+        lib().timer, timer.enabled, timer.only = timer, True, ("magpo_sable_act", "magpo_coordsum_step", "magpo_lbf_step")
     learner.use_graph = False
     learner.update_step(grad_sync)
     learner.use_graph = True
@@ -315,15 +326,22 @@ def main():
     if args.check_replicas and world > 1:
         cs = float(learner.guider.P.flat.double().sum().item() + learner.actor.P.flat.double().abs().sum().item())
         assert reduce_max(cs) == -reduce_max(-cs), "parameters diverged across ranks"
-        log(f"replica check ok (checksum {cs:.9f}); env targets differ per rank: {int(learner.env.target.sum().item())}")
+        log(f"replica check ok (checksum {cs:.9f}); env observations differ per rank: {float(learner.traj['obs'].double().sum().item()):.1f}")
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     if rank == 0:
         timer.collect()
         roof, table = timer.dominant(args.steps, act_keys)
         rollout_ms = round(sum(e0.elapsed_time(e1) for e0, e1 in roll_events) / max(1, len(roll_events)), 2) if roll_events else None
         env_steps = world * N * sysc.rollout_length * args.steps
+        if isinstance(env_cfg, LbfConfig):
+            env_name = "LevelBasedForaging"
+            env_desc = (f"Level-Based Foraging {env_cfg.grid_size}x{env_cfg.grid_size}-{env_cfg.num_agents}p-{env_cfg.num_food}f-coop (fov {env_cfg.fov}, "
+                        "time_limit=100; UNPINNED dynamics restated from Jumanji's published algorithm)")
+        else:
+            env_name = "CoordSum"
+            env_desc = f"CoordSum {env_cfg.num_agents}-agent (num_actions={env_cfg.num_actions}, maxval={env_cfg.maxval}, time_limit=100)"
         out = {
-            "metric": f"env-steps/sec (all agents stepping jointly), CoordSum-{env_cfg.num_agents}ag, full MAGPO update loop",
+            "metric": f"env-steps/sec (all agents stepping jointly), {env_name}-{env_cfg.num_agents}ag, full MAGPO update loop",
             "value": round(env_steps / elapsed, 1),
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -334,9 +352,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (fixed-seed CoordSum episodes, random-init networks)",
-            "config": {"workload": f"CoordSum {env_cfg.num_agents}-agent (num_actions={env_cfg.num_actions}, maxval={env_cfg.maxval}, "
-                                   f"time_limit=100), {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
+            "data": f"synthetic (fixed-seed {env_name} episodes, random-init networks)",
+            "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
                                    f"num_minibatches={sysc.num_minibatches}, Sable embed 64 / 1 head / {n_block} block, GRU 128",
                        "agent_steps_per_s": round(env_steps * env_cfg.num_agents / elapsed, 1),
                        "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},

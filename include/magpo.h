@@ -42,6 +42,23 @@ int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key
                         float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
                         int auto_reset, magpo_stream_t stream);
 
+/* ---- Level-Based Foraging env + wrappers (mava/wrappers/jumanji.py:171-220 LbfWrapper with the always-on team reward, AgentID, AutoReset,
+ * RecordEpisodeMetrics; the env itself is jumanji LevelBasedForaging-v0 with RandomGenerator(grid_size, fov, num_agents, num_food,
+ * max_agent_level, force_coop), configs/env/scenario/*-coop.yaml).  UNPINNED DYNAMICS: Jumanji's source is not part of the reference tree;
+ * csrc/lbf.hip and oracle/lbf.py restate its published algorithm and agree bit for bit with each other.
+ * State per env: agent_pos [A][2], agent_level [A], food_pos [NF][2], food_level [NF], food_eaten [NF] u8, step_count, key [2], metrics_key [2],
+ * episode-metric counters.  obs [N][A][A + 3 (NF + A)] f32 = [one-hot id | (x, y, level) of foods, self, others], mask [N][A][6] u8. */
+int magpo_lbf_reset(int* agent_pos, int* agent_level, int* food_pos, int* food_level, unsigned char* food_eaten,
+                    int* step_count, uint32_t* key, uint32_t* metrics_key, float* run_ret, int* run_len, float* ep_ret,
+                    int* ep_len, int N, int A, int NF, int G, int fov, int max_level, int force_coop, int time_limit,
+                    const uint32_t* env_keys, float* obs, int* obs_step, unsigned char* mask, magpo_stream_t stream);
+int magpo_lbf_step(int* agent_pos, int* agent_level, int* food_pos, int* food_level, unsigned char* food_eaten,
+                   int* step_count, uint32_t* key, uint32_t* metrics_key, float* run_ret, int* run_len, float* ep_ret,
+                   int* ep_len, int N, int A, int NF, int G, int fov, int max_level, int force_coop, int time_limit,
+                   const int* actions, int act_stride, float* reward, unsigned char* done, float* obs, int* obs_step,
+                   unsigned char* mask, float* m_ep_ret, int* m_ep_len, unsigned char* m_term, int auto_reset,
+                   magpo_stream_t stream);
+
 /* input classes of wrapped CoordSum tokens (first-layer tables, csrc/classtab.hip): cls_enc = ((agent * maxval + target) * npos + pos),
  * cls_dec = prev * npos + pos per row; class_rows writes the distinct rows in class order: obs_tab [A*maxval*npos][A+1], pos_enc,
  * and prev_dec / pos_dec [(K+1)*npos].  The actor's class (agent, target) is cls_enc / npos (or cls_enc itself with pos = NULL, npos = 1;

@@ -16,7 +16,7 @@ import torch
 
 from ._lib import lib
 from .actor import GruActor
-from .learner import CoordSumEnvBatch, host_split
+from .learner import host_split, make_env_batch
 
 
 def get_num_eval_envs(config, absolute_metric: bool, n_devices: int = 1) -> int:
@@ -33,7 +33,7 @@ def make_rec_eval_act_fn(actor: GruActor, config) -> Callable:
     L = lib()
     loaded = {"params": None}
 
-    def eval_act_fn(params: Dict[str, torch.Tensor], obs: torch.Tensor, last_done: torch.Tensor, key: np.ndarray, actor_state):
+    def eval_act_fn(params: Dict[str, torch.Tensor], obs: torch.Tensor, last_done: torch.Tensor, key: np.ndarray, actor_state, mask=None):
         if params is not None and params is not actor.named and params is not loaded["params"]:
             actor.load_named(params)
             loaded["params"] = params
@@ -44,12 +44,15 @@ def make_rec_eval_act_fn(actor: GruActor, config) -> Callable:
         logits = actor.step(obs, h_in, last_done, h_out, want_logits=True)
         N, A = obs.shape[0], obs.shape[1]
         action = torch.empty(N, A, dtype=torch.int32, device=obs.device)
-        if greedy:
-            action.copy_(logits[:, :actor.K].argmax(-1).view(N, A))
+        if greedy:   # pi.mode() of the masked categorical (heads.py:56-63: illegal logits -> finfo.min)
+            lg = logits[:, :actor.K]
+            if mask is not None:
+                lg = torch.where(mask.view(N * A, actor.K) != 0, lg, torch.full_like(lg, torch.finfo(torch.float32).min))
+            action.copy_(lg.argmax(-1).view(N, A))
         else:
             logp = torch.empty(N * A, device=obs.device)
-            L.call("magpo_sample_categorical", logits, 64, None, 0, int(key[0]), int(key[1]), None, action, 1, logp, 1, None, 0, None, 0,
-                   N * A, actor.K, torch.cuda.current_stream().cuda_stream)
+            L.call("magpo_sample_categorical", logits, 64, mask, 0 if mask is None else actor.K, int(key[0]), int(key[1]), None, action, 1,
+                   logp, 1, None, 0, None, 0, N * A, actor.K, torch.cuda.current_stream().cuda_stream)
         return action, {"hidden_state": h_out, "_spare": h_in}
 
     return eval_act_fn
@@ -65,10 +68,11 @@ def get_eval_fn(eval_env, act_fn: Callable, config, absolute_metric: bool, devic
                       f"({n_parallel}); running {loops * n_parallel} episodes.", stacklevel=2)
     cfg = eval_env.cfg
     A, TL = cfg.num_agents, cfg.time_limit
-    env = CoordSumEnvBatch(cfg, n_envs, device)
+    env = make_env_batch(cfg, n_envs, device)
     f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
     i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
-    obs, obs_step = f32(n_envs, A, A + 1), i32(n_envs)
+    obs, obs_step = f32(n_envs, A, cfg.obs_dim), i32(n_envs)
+    mask = torch.zeros(n_envs, A, cfg.num_actions, dtype=torch.uint8, device=device) if cfg.has_mask else None
     reward, done = f32(n_envs, A), torch.zeros(n_envs, dtype=torch.uint8, device=device)
     m_ret, m_len, m_term = f32(n_envs), i32(n_envs), torch.zeros(n_envs, dtype=torch.uint8, device=device)
     L = lib()
@@ -81,7 +85,7 @@ def get_eval_fn(eval_env, act_fn: Callable, config, absolute_metric: bool, devic
             kd = torch.from_numpy(reset_key.view(np.int32).copy()).to(device)
             rk = torch.empty(n_envs, 2, dtype=torch.int32, device=device)
             L.call("magpo_threefry_split", kd, rk, n_envs, torch.cuda.current_stream().cuda_stream)
-            env.reset(rk, obs, obs_step)
+            env.reset(rk, obs, obs_step, mask)
             done.zero_()
             state = {"hidden_state": init_act_state["hidden_state"].clone()}
             got = torch.zeros(n_envs, dtype=torch.bool, device=device)
@@ -90,8 +94,8 @@ def get_eval_fn(eval_env, act_fn: Callable, config, absolute_metric: bool, devic
             for _t in range(TL + 1):
                 ks = host_split(step_key, 2)
                 step_key, act_key = ks[0], ks[1]
-                action, state = act_fn(params, obs, done, act_key, state)
-                env.step(action, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=False)
+                action, state = act_fn(params, obs, done, act_key, state) if mask is None else act_fn(params, obs, done, act_key, state, mask)
+                env.step(action, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=False, mask=mask)
                 first = done.bool() & ~got
                 ep_ret = torch.where(first, m_ret, ep_ret)
                 ep_len = torch.where(first, m_len, ep_len)

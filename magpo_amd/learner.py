@@ -48,10 +48,35 @@ class CoordSumConfig:
     num_actions: int
     time_limit: int = 100
     maxval: Optional[int] = None
+    has_mask = False          # action_mask is all-True (matrax.py:117-134): never stored
+    class_tables = True       # observations take few distinct values: first-layer class tables apply (csrc/classtab.hip)
 
     def __post_init__(self):
         if not self.maxval:
             self.maxval = self.num_actions  # coordsum/env.py:49-53
+
+    @property
+    def obs_dim(self) -> int:   # AgentIDWrapper (observation.py:42-54): [one-hot id | target]
+        return self.num_agents + 1
+
+
+@dataclass
+class LbfConfig:
+    """jumanji LevelBasedForaging-v0 + RandomGenerator(**task_config) (configs/env/scenario/*-coop.yaml) under LbfWrapper."""
+    grid_size: int = 8
+    fov: int = 8
+    num_agents: int = 2
+    num_food: int = 2
+    max_agent_level: int = 2
+    force_coop: bool = True
+    time_limit: int = 100
+    has_mask = True
+    class_tables = False
+    num_actions = 6
+
+    @property
+    def obs_dim(self) -> int:   # vector observation 3 (num_food + num_agents) + one-hot agent id
+        return 3 * (self.num_food + self.num_agents) + self.num_agents
 
 
 def host_split(key: np.ndarray, num: int = 2) -> np.ndarray:
@@ -87,12 +112,48 @@ class CoordSumEnvBatch:
         c = self.cfg
         return (self.N, c.num_agents, c.num_actions, c.time_limit, c.maxval)
 
-    def reset(self, env_keys: torch.Tensor, obs, obs_step):
+    state_fields = ("step_count", "target", "record", "key", "metrics_key", "run_ret", "run_len", "ep_ret", "ep_len")
+
+    def reset(self, env_keys: torch.Tensor, obs, obs_step, mask=None):
         self.L.call("magpo_coordsum_reset", *self._state(), *self._cfg(), env_keys, obs, obs_step, torch.cuda.current_stream().cuda_stream)
 
-    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True):
+    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None):
         self.L.call("magpo_coordsum_step", *self._state(), *self._cfg(), actions, self.cfg.num_agents, reward, done, obs, obs_step,
                     m_ret, m_len, m_term, 1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
+
+
+class LbfEnvBatch:
+    """Device-resident batch of wrapped Level-Based Foraging envs (csrc/lbf.hip; UNPINNED dynamics, see oracle/lbf.py)."""
+    state_fields = ("agent_pos", "agent_level", "food_pos", "food_level", "food_eaten", "step_count", "key", "metrics_key",
+                    "run_ret", "run_len", "ep_ret", "ep_len")
+
+    def __init__(self, cfg: LbfConfig, N: int, device):
+        self.cfg, self.N, self.dev = cfg, N, device
+        A, NF = cfg.num_agents, cfg.num_food
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        self.agent_pos, self.agent_level, self.food_pos, self.food_level = i32(N, A, 2), i32(N, A), i32(N, NF, 2), i32(N, NF)
+        self.food_eaten = torch.zeros(N, NF, dtype=torch.uint8, device=device)
+        self.step_count, self.key, self.metrics_key = i32(N), i32(N, 2), i32(N, 2)
+        self.run_ret, self.run_len = torch.zeros(N, device=device), i32(N)
+        self.ep_ret, self.ep_len = torch.zeros(N, device=device), i32(N)
+        self.L = lib()
+
+    def _args(self):
+        c = self.cfg
+        return (self.agent_pos, self.agent_level, self.food_pos, self.food_level, self.food_eaten, self.step_count, self.key, self.metrics_key,
+                self.run_ret, self.run_len, self.ep_ret, self.ep_len, self.N, c.num_agents, c.num_food, c.grid_size, c.fov, c.max_agent_level,
+                1 if c.force_coop else 0, c.time_limit)
+
+    def reset(self, env_keys: torch.Tensor, obs, obs_step, mask=None):
+        self.L.call("magpo_lbf_reset", *self._args(), env_keys, obs, obs_step, mask, torch.cuda.current_stream().cuda_stream)
+
+    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None):
+        self.L.call("magpo_lbf_step", *self._args(), actions, self.cfg.num_agents, reward, done, obs, obs_step, mask, m_ret, m_len, m_term,
+                    1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
+
+
+def make_env_batch(cfg, N: int, device):
+    return LbfEnvBatch(cfg, N, device) if isinstance(cfg, LbfConfig) else CoordSumEnvBatch(cfg, N, device)
 
 
 class EnvGroup:
@@ -100,14 +161,16 @@ class EnvGroup:
     reference's (device, update-batch) replica (rec_magpo.py:519, :648-653); all groups of a process share
     the parameters and the training workspaces."""
 
-    def __init__(self, env_cfg: CoordSumConfig, N: int, T: int, device, n_block: int = 1, n_head: int = 1):
-        A, F = env_cfg.num_agents, env_cfg.num_agents + 1
+    def __init__(self, env_cfg, N: int, T: int, device, n_block: int = 1, n_head: int = 1):
+        A, F = env_cfg.num_agents, env_cfg.obs_dim
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
         u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=device)
-        self.env = CoordSumEnvBatch(env_cfg, N, device)
+        self.env = make_env_batch(env_cfg, N, device)
         self.traj = dict(obs=f32(T + 1, N, A, F), step_count=i32(T + 1, N), done=u8(T + 1, N), action=i32(T, N, A), value=f32(T, N, A),
                          reward=f32(T, N, A), log_prob=f32(T, N, A), adv=f32(T, N, A), targets=f32(T, N, A))
+        # action masks (Observation.action_mask) only for envs that have illegal actions; None = every action legal
+        self.traj["mask"] = u8(T + 1, N, A, env_cfg.num_actions) if env_cfg.has_mask else None
         self.metrics = dict(episode_return=f32(T, N), episode_length=i32(T, N), is_terminal_step=u8(T, N))
         # (encoder, decoder self, decoder cross) retention states; head states are padded to 64 x 64 on the device
         self.sable_hs = tuple(f32(n_block, n_head, N, 64, 64) for _ in range(3))
@@ -124,12 +187,12 @@ class EnvGroup:
 
 
 class MagpoLearner:
-    def __init__(self, env_cfg: CoordSumConfig, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
+    def __init__(self, env_cfg, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
                  decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 512, num_groups: int = 1,
                  n_block: int = 1, n_head: int = 1, embed_dim: int = 64):
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
-        F = A + 1  # AgentIDWrapper (observation.py:42-54), add_agent_id: True
+        F = env_cfg.obs_dim  # with the AgentIDWrapper's one-hot id (observation.py:42-54), add_agent_id: True
         self.A, self.K, self.F, self.T = A, K, F, sys.rollout_length
         if num_envs % sys.num_minibatches:
             raise ValueError("num_envs must be divisible by num_minibatches")
@@ -169,7 +232,7 @@ class MagpoLearner:
         # First-layer class tables (csrc/classtab.hip): a wrapped CoordSum token is one of A*maxval*npos distinct inputs, so the
         # layers in front of the GRU / of the first retention run on the distinct rows only.  MAGPO_CLASS_TABLES=0 = dense path.
         import os
-        self.class_tables = os.environ.get("MAGPO_CLASS_TABLES", "1") != "0"
+        self.class_tables = env_cfg.class_tables and os.environ.get("MAGPO_CLASS_TABLES", "1") != "0"
         self._cls = None
         # the actor's forward / backward run on a second HIP stream next to the guider's (independent until the loss)
         self.overlap_actor = False  # opt-in (bench.py --overlap): ~3 %, but per-kernel timings then include contention
@@ -206,7 +269,7 @@ class MagpoLearner:
         self.setup_key = ks[0]
         for gi, g in enumerate(self.groups):
             env_keys = allk[1 + (group + gi) * N: 1 + (group + gi + 1) * N].contiguous()
-            g.env.reset(env_keys, g.traj["obs"][0], g.traj["step_count"][0])
+            g.env.reset(env_keys, g.traj["obs"][0], g.traj["step_count"][0], None if g.traj["mask"] is None else g.traj["mask"][0])
             g.traj["done"][0].zero_()
             g.key = ks[1].copy()
             for h in g.sable_hs:
@@ -323,12 +386,14 @@ class MagpoLearner:
                 else:
                     self.actor.step(obs, h_in, done_prev, h_out)
                 g.cur = 1 - g.cur
+            mk = None if tr["mask"] is None else tr["mask"][t]
             if fused:   # states of envs whose episode just ended read as zero inside the kernel (rec_magpo.py:164-169)
-                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], done=done_prev)
+                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], done=done_prev, mask=mk)
             else:
-                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t])
+                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], mask=mk)
             g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
-                       g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t])
+                       g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t],
+                       mask=None if tr["mask"] is None else tr["mask"][t + 1])
             if not fused or t == T - 1:
                 zero_done(tr["done"][t + 1])
         if side is not None:
@@ -354,6 +419,8 @@ class MagpoLearner:
         for g in self.groups:
             tr = g.traj
             tr["obs"][0].copy_(tr["obs"][self.T]); tr["step_count"][0].copy_(tr["step_count"][self.T]); tr["done"][0].copy_(tr["done"][self.T])
+            if tr["mask"] is not None:
+                tr["mask"][0].copy_(tr["mask"][self.T])
 
     # ------------------------------------------------------------------ shuffles (jax.random.permutation)
     def _permutation(self, key: np.ndarray, n: int) -> torch.Tensor:
@@ -382,14 +449,15 @@ class MagpoLearner:
             i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=self.dev)
             m.update(R=R, obs=f32(R, F), action=i32(R), prev=i32(R), pos=i32(R), done=torch.empty(U * mb, T, dtype=torch.uint8, device=self.dev),
                      value=f32(R), logp=f32(R), adv=f32(R), targets=f32(R), h0idx=i32(U * mb * A),
-                     dg=f32(R, 64), da=f32(R, 64), dv=f32(R))
+                     dg=f32(R, 64), da=f32(R, 64), dv=f32(R),
+                     mask=torch.empty(R, K, dtype=torch.uint8, device=self.dev) if self.env_cfg.has_mask else None)
         for u, gi in enumerate(groups):
             tr = self.groups[gi].traj
             r = slice(u * R1, (u + 1) * R1)
             h0 = m["h0idx"][u * mb * A:(u + 1) * mb * A]
-            self.L.call("magpo_gather_minibatch", tr["obs"], tr["action"], tr["step_count"], tr["done"], None, tr["value"], tr["log_prob"],
+            self.L.call("magpo_gather_minibatch", tr["obs"], tr["action"], tr["step_count"], tr["done"], tr["mask"], tr["value"], tr["log_prob"],
                         tr["adv"], tr["targets"], env_idx, agent_perm, m["obs"][r], m["action"][r], m["prev"][r], m["pos"][r],
-                        m["done"][u * mb:(u + 1) * mb], None, m["value"][r], m["logp"][r], m["adv"][r], m["targets"][r], h0, T, N, A, F, K, mb,
+                        m["done"][u * mb:(u + 1) * mb], None if m["mask"] is None else m["mask"][r], m["value"][r], m["logp"][r], m["adv"][r], m["targets"][r], h0, T, N, A, F, K, mb,
                         self._st())
             if gi:
                 h0.add_(gi * N * A)      # rows of the stacked start states
@@ -473,7 +541,7 @@ class MagpoLearner:
             a2 = m["adv"].view(U, R1)
             a2.sub_(self._adv_stats_u[:, 0:1]).mul_(self._adv_stats_u[:, 1:2])
             stats = self._adv_ident
-        self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, None, m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],
+        self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, m["mask"], m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],
                     stats, m["dg"], 64, m["da"], 64, m["dv"], self.ws64, self.loss_out, R, K, s.clip_eps, s.clip_gpo,
                     s.ent_coef, s.vf_coef, s.alpha, st)
         if side is not None:

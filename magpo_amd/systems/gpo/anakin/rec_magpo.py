@@ -46,9 +46,6 @@ def _system_config(config) -> SystemConfig:
                         alpha=float(s.alpha), actor_lr=float(s.actor_lr))
 
 
-_ENV_FIELDS = ("step_count", "target", "record", "key", "metrics_key", "run_ret", "run_len", "ep_ret", "ep_len")
-
-
 def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:
     """LearnerState of the learner as an independent COPY (rec_magpo.py:488-497): the state a caller holds stays readable
     and re-usable after later learn() calls (the harness evaluates the pre-interval parameters, rec_magpo.py:770, SURVEY
@@ -59,8 +56,10 @@ def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:
                     dict(count=learner.a_count, mu=learner.a_mu.clone(), nu=learner.a_nu.clone()))
     hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i] for g in gs]) for i in range(3)]),
                       torch.stack([g.policy_h[g.cur] for g in gs]))
-    env_state = {f: torch.stack([getattr(g.env, f) for g in gs]) for f in _ENV_FIELDS}
+    env_state = {f: torch.stack([getattr(g.env, f) for g in gs]) for f in gs[0].env.state_fields}
     timestep = dict(agents_view=torch.stack([g.traj["obs"][0] for g in gs]), step_count=torch.stack([g.traj["step_count"][0] for g in gs]))
+    if gs[0].traj["mask"] is not None:
+        timestep["action_mask"] = torch.stack([g.traj["mask"][0] for g in gs])
     dones = torch.stack([g.traj["done"][0] for g in gs])
     return GPOLearnerState(params, opt, gs[0].key.copy(), env_state, timestep, dones, hs)
 
@@ -79,9 +78,11 @@ def load_learner_state(learner: MagpoLearner, state: GPOLearnerState) -> None:
     if state.dones.shape[0] != len(learner.groups):
         raise ValueError(f"learner state holds {state.dones.shape[0]} env groups, the learner {len(learner.groups)}")
     for gi, grp in enumerate(learner.groups):
-        for f in _ENV_FIELDS:
+        for f in grp.env.state_fields:
             getattr(grp.env, f).copy_(state.env_state[f][gi])
         grp.traj["obs"][0].copy_(state.timestep["agents_view"][gi])
+        if grp.traj["mask"] is not None:
+            grp.traj["mask"][0].copy_(state.timestep["action_mask"][gi])
         grp.traj["step_count"][0].copy_(state.timestep["step_count"][gi])
         grp.traj["done"][0].copy_(state.dones[gi])
         for i in range(3):

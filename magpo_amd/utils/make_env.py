@@ -1,14 +1,14 @@
 """Environment factory (mava/utils/make_env.py:202-218, 288-315): config -> (train_env, eval_env) descriptors.
 
-Only the CoordSum branch is implemented (the env dynamics live in the HIP kernel, csrc/coordsum.hip).
-LBF / RWARE dynamics live in third-party Jumanji, which is absent from the reference tree and from this
-image: they cannot be restated faithfully offline and raise NotImplementedError.
+CoordSum (csrc/coordsum.hip) and Level-Based Foraging (csrc/lbf.hip) are implemented.  LBF / RWARE dynamics live in
+third-party Jumanji, which is absent from the reference tree and from this image: LBF is restated from Jumanji's published
+algorithm with UNPINNED dynamics (oracle/lbf.py lists every rule); RWARE is not built and raises NotImplementedError.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
 
-from ..learner import CoordSumConfig
+from ..learner import CoordSumConfig, LbfConfig
 
 COORDSUM_REGISTRY = {  # mava/coordsum/__init__.py:6-45
     "5x20-80-v0": dict(num_agents=5, num_actions=20, time_limit=100, maxval=80),
@@ -21,7 +21,7 @@ COORDSUM_REGISTRY = {  # mava/coordsum/__init__.py:6-45
 @dataclass
 class MarlEnvSpec:
     """What the system file reads from a MarlEnv (mava/types.py:45-123)."""
-    cfg: CoordSumConfig
+    cfg: object   # CoordSumConfig | LbfConfig
     auto_reset: bool
     add_agent_id: bool = True
 
@@ -39,7 +39,7 @@ class MarlEnvSpec:
 
     @property
     def obs_dim(self) -> int:
-        return self.cfg.num_agents + 1 if self.add_agent_id else 1
+        return self.cfg.obs_dim
 
 
 def make_coordsum_env(config):
@@ -56,11 +56,32 @@ def make_coordsum_env(config):
     return MarlEnvSpec(cfg, auto_reset=True), MarlEnvSpec(cfg, auto_reset=False)
 
 
+def make_lbf_env(config):
+    """make_jumanji_env (make_env.py:107-135) for LevelBasedForaging: generator = RandomGenerator(**scenario.task_config), env
+    kwargs = {**env.kwargs, **scenario.env_kwargs}; LbfWrapper's aggregate_rewards keeps its default True whatever
+    env.aggregate_rewards says (the factory never passes it)."""
+    tc = config.env.scenario.task_config.to_container()
+    kw = {**config.env.kwargs.to_container(), **config.env.scenario.env_kwargs.to_container()}
+    unknown = set(kw) - {"time_limit"}
+    if unknown:
+        raise NotImplementedError(f"LevelBasedForaging kwargs {sorted(unknown)} are not supported (grid observations, penalties, unnormalised rewards)")
+    add_id = bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id)
+    config.system.add_agent_id = add_id
+    if not add_id:
+        raise NotImplementedError("system.add_agent_id=False is not supported by the HIP env kernels")
+    cfg = LbfConfig(grid_size=int(tc["grid_size"]), fov=int(tc["fov"]), num_agents=int(tc["num_agents"]), num_food=int(tc["num_food"]),
+                    max_agent_level=int(tc.get("max_agent_level", 2)), force_coop=bool(tc.get("force_coop", False)),
+                    time_limit=int(kw.get("time_limit", 100)))
+    return MarlEnvSpec(cfg, auto_reset=True), MarlEnvSpec(cfg, auto_reset=False)
+
+
 def make(config):
     env_name = config.env.env_name
     if env_name == "CoordSum":
         return make_coordsum_env(config)
-    if env_name in ("RobotWarehouse", "LevelBasedForaging"):
+    if env_name == "LevelBasedForaging":
+        return make_lbf_env(config)
+    if env_name in ("RobotWarehouse",):
         raise NotImplementedError(
             f"{env_name}: dynamics live in Jumanji (git pin 9ced6b8), which is not part of the reference tree; "
             "no verified HIP kernel exists yet (SURVEY 8f rank 2). Use env=coordsum.")

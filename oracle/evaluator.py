@@ -54,8 +54,8 @@ def rec_eval_act(ap, timestep, key, hidden, greedy: bool = False):
 
 
 @torch.no_grad()
-def evaluate(spec: cs.CoordSumSpec, ap, key: np.ndarray, num_envs: int, eval_episodes: int, hidden: int = 128,
-             greedy: bool = False, dtype=torch.float32) -> Dict[str, np.ndarray]:
+def evaluate(spec, ap, key: np.ndarray, num_envs: int, eval_episodes: int, hidden: int = 128,
+             greedy: bool = False, dtype=torch.float32, env=cs) -> Dict[str, np.ndarray]:
     """eval_fn (evaluator.py:113-157) on one device: returns flattened per-episode metric arrays."""
     n = get_num_eval_envs(num_envs, eval_episodes)
     loops = math.ceil(eval_episodes / n)
@@ -65,7 +65,7 @@ def evaluate(spec: cs.CoordSumSpec, ap, key: np.ndarray, num_envs: int, eval_epi
     for _ in range(loops):
         ks = prng.split(key, 2)                                   # :136
         key, reset_key = ks[0], ks[1]
-        state, ts = cs.reset(spec, prng.split(reset_key, n))      # :137-138
+        state, ts = env.reset(spec, prng.split(reset_key, n))      # :137-138
         h = torch.zeros(n, spec.num_agents, hidden, dtype=dtype)  # init_act_state (rec_magpo.py:745-748)
         step_key = key                                            # :140 (the carried copy is thrown away by :150)
         last_t, m_ret, m_len = [], [], []
@@ -73,7 +73,7 @@ def evaluate(spec: cs.CoordSumSpec, ap, key: np.ndarray, num_envs: int, eval_epi
             ks = prng.split(step_key, 2)                          # :128
             step_key, act_key = ks[0], ks[1]
             action, h = rec_eval_act(ap, ts, act_key, h, greedy)
-            state, ts = cs.step(spec, state, action, auto_reset=False)
+            state, ts = env.step(spec, state, action, auto_reset=False)
             last_t.append(ts["step_type"] == cs.STEP_LAST)
             m_ret.append(ts["episode_metrics"]["episode_return"].copy())
             m_len.append(ts["episode_metrics"]["episode_length"].copy())

@@ -131,9 +131,10 @@ def minibatch_forward(sys, scfg, gp, ap, mb):
 class OracleLearner:
     """Single-group learner; state lives in numpy/torch on the CPU."""
 
-    def __init__(self, spec: cs.CoordSumSpec, num_envs: int, sys: SystemCfg, scfg: nets.SableCfg,
-                 guider_params, actor_params, dtype=torch.float32):
-        self.spec, self.N, self.sys, self.scfg, self.dtype = spec, num_envs, sys, scfg, dtype
+    def __init__(self, spec, num_envs: int, sys: SystemCfg, scfg: nets.SableCfg,
+                 guider_params, actor_params, dtype=torch.float32, env=cs):
+        """``env``: the wrapped-env module (oracle.coordsum or oracle.lbf: reset(spec, keys) / step(spec, state, actions))."""
+        self.spec, self.N, self.sys, self.scfg, self.dtype, self.env = spec, num_envs, sys, scfg, dtype, env
         self.gp = {k: v.clone().to(dtype) for k, v in guider_params.items()}
         self.ap = {k: v.clone().to(dtype) for k, v in actor_params.items()}
         self.g_opt = adam_init(self.gp)
@@ -146,7 +147,7 @@ class OracleLearner:
         ks = prng.split(key, n_groups * N + 1)
         key = ks[0]
         env_keys = ks[1 + group * N: 1 + (group + 1) * N]
-        self.env_state, self.timestep = cs.reset(self.spec, env_keys)
+        self.env_state, self.timestep = self.env.reset(self.spec, env_keys)
         ks = prng.split(key, 2)
         self.setup_key, self.key = ks[0], ks[1]
         self.dones = np.zeros((N, self.spec.num_agents), bool)
@@ -176,7 +177,7 @@ class OracleLearner:
             last_done = torch.from_numpy(self.dones)
             self.policy_h, _, _ = nets.actor_apply(self.ap, self.policy_h, obs[None], last_done[None], mask[None])
             prev_done = self.dones.copy()
-            self.env_state, self.timestep = cs.step(spec, self.env_state, action.numpy(), auto_reset=True)
+            self.env_state, self.timestep = self.env.step(spec, self.env_state, action.numpy(), auto_reset=True)
             done = self.timestep["step_type"] == cs.STEP_LAST
             dmask = torch.from_numpy(done)[:, None, None, None, None]
             self.sable_hs = tuple(torch.where(dmask, torch.zeros_like(h), h) for h in new_hs)

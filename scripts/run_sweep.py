@@ -45,10 +45,13 @@ def main():
     ap.add_argument("--seeds", nargs="+", type=int, default=[0, 1, 2, 3, 4])
     ap.add_argument("--num-updates", type=int, default=1220)
     ap.add_argument("--num-evaluation", type=int, default=122)
+    ap.add_argument("--jobs", nargs="+", default=None, help="explicit job list scenario:seed (overrides --scenarios / --seeds)")
     ap.add_argument("--parallel", type=int, default=5, help="runs at once on the GPU (the box allows 6 GPU processes)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     jobs = [(s, seed) for s in args.scenarios for seed in args.seeds]
+    if args.jobs:
+        jobs = [(j.rsplit(":", 1)[0], int(j.rsplit(":", 1)[1])) for j in args.jobs]
     running = []
     t0 = time.time()
     while jobs or running:
