@@ -19,8 +19,8 @@ for f in sorted(glob.glob(os.path.join(out, "json", "*", "metrics.json"))):
     curve = [(v["step_count"], v["mean_episode_return"][0]) for _, v in steps if "mean_episode_return" in v]
     rows.setdefault(scen, []).append((int(seed), curve, run.get("absolute_metrics", {}).get("mean_episode_return", [float("nan")])[0],
                                       np.mean([v["steps_per_second"][0] for _, v in steps if "steps_per_second" in v])))
-print("| scenario | seeds | return @ ~10 M steps (mean +- std over seeds) | return @ end | absolute metric (best params, 320 episodes) | first evaluation |")
-print("|---|---|---|---|---|---|")
+print("| scenario | seeds | eval return at half the run (mean +- std over seeds) | eval return at the end of the run | absolute metric (best params, 320 episodes) | first evaluation | evaluator env-steps/s |")
+print("|---|---|---|---|---|---|---|")
 for scen, runs in rows.items():
     def at(frac):
         vals = []
@@ -30,5 +30,6 @@ for scen, runs in rows.items():
         return np.array(vals)
     mid, end, first = at(0.5), at(1.0), np.array([c[1][0][1] for c in runs])
     ab = np.array([r[2] for r in runs])
-    print(f"| {scen} | {len(runs)} | {mid.mean():.2f} +- {mid.std():.2f} | {end.mean():.2f} +- {end.std():.2f} (at {runs[0][1][-1][0] / 1e6:.1f} M steps) | "
-          f"{np.nanmean(ab):.2f} +- {np.nanstd(ab):.2f} | {first.mean():.2f} |")
+    T_end = runs[0][1][-1][0] / 1e6
+    print(f"| {scen} | {len(runs)} | {mid.mean():.2f} +- {mid.std():.2f} (at {T_end / 2:.1f} M steps) | {end.mean():.2f} +- {end.std():.2f} (at {T_end:.1f} M steps) | "
+          f"{np.nanmean(ab):.2f} +- {np.nanstd(ab):.2f} | {first.mean():.2f} | {np.mean([r[3] for r in runs]):.0f} |")
