@@ -356,6 +356,7 @@ def main():
             "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
                                    f"num_minibatches={sysc.num_minibatches}, Sable embed 64 / 1 head / {n_block} block, GRU 128",
                        "agent_steps_per_s": round(env_steps * env_cfg.num_agents / elapsed, 1),
+                       "first_layer_class_tables": bool(learner.class_tables),   # exact (no caching across updates); MAGPO_CLASS_TABLES=0 = dense path
                        "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},
             "roofline": roof,
             "rollout_graph_ms_per_step": rollout_ms,

@@ -489,8 +489,11 @@ class MagpoLearner:
         out = {}
         for side, C in (("enc", c["Ce"]), ("dec", c["Cd"])):
             cls = m["cls_" + side]
-            order = torch.sort(cls, stable=True).indices
-            offsets = torch.cat([c["zero"], torch.cumsum(torch.bincount(cls, minlength=C), 0)])
+            vals, order = torch.sort(cls, stable=True)
+            # class boundaries in the sorted order without a host synchronisation (torch.bincount sizes its output on the host)
+            if ("bounds_" + side) not in c:
+                c["bounds_" + side] = torch.arange(C + 1, dtype=torch.int32, device=self.dev)
+            offsets = torch.searchsorted(vals, c["bounds_" + side])
             out[side] = (cls, order, offsets)
         cls_act = torch.div(m["cls_enc"], c["npos"], rounding_mode="floor").to(torch.int32)
         out["act"] = (c["obs_act"], cls_act, out["enc"][1], out["enc"][2][::c["npos"]].contiguous())

@@ -54,7 +54,9 @@ def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:
     params = Params({k: v.clone() for k, v in learner.guider.named.items()}, {k: v.clone() for k, v in learner.actor.named.items()})
     opt = OptStates(dict(count=learner.g_count, mu=learner.g_mu.clone(), nu=learner.g_nu.clone()),
                     dict(count=learner.a_count, mu=learner.a_mu.clone(), nu=learner.a_nu.clone()))
-    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i] for g in gs]) for i in range(3)]),
+    # head states are zero-padded to 64 x 64 on the device; the state carries the [hs, hs] blocks (get_init_hstates.py:20-43)
+    hw = learner.guider.hs
+    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i][..., :hw, :hw] for g in gs]) for i in range(3)]),
                       torch.stack([g.policy_h[g.cur] for g in gs]))
     env_state = {f: torch.stack([getattr(g.env, f) for g in gs]) for f in gs[0].env.state_fields}
     timestep = dict(agents_view=torch.stack([g.traj["obs"][0] for g in gs]), step_count=torch.stack([g.traj["step_count"][0] for g in gs]))
@@ -85,8 +87,10 @@ def load_learner_state(learner: MagpoLearner, state: GPOLearnerState) -> None:
             grp.traj["mask"][0].copy_(state.timestep["action_mask"][gi])
         grp.traj["step_count"][0].copy_(state.timestep["step_count"][gi])
         grp.traj["done"][0].copy_(state.dones[gi])
+        hw = learner.guider.hs
         for i in range(3):
-            grp.sable_hs[i].copy_(sable[i][gi])
+            grp.sable_hs[i].zero_()
+            grp.sable_hs[i][..., :hw, :hw].copy_(sable[i][gi])
         grp.policy_h[grp.cur].copy_(hst["policy_hidden_state"][gi])
         grp.key = np.array(state.key, dtype=np.uint32).copy()
 
@@ -197,13 +201,22 @@ def run_experiment(_config) -> float:
         if not cands:
             raise FileNotFoundError(f"load_model=True but no checkpoint under {cdir}")
         learner_state, _ = restore_learner_state(cands[-1], device)
+        resume = torch.load(cands[-1], map_location="cpu", weights_only=False).get("extras") or {}
+    else:
+        resume = {}
     eval_batch = get_num_eval_envs(config, absolute_metric=False, n_devices=n_devices)
     eval_hs = {"hidden_state": torch.zeros(eval_batch * env.num_agents, 128, device=device)}
 
     max_episode_return = -np.inf
     best_params = None
     eval_metrics: Dict[str, Any] = {}
-    for eval_step in range(int(config.arch.num_evaluation)):
+    start_eval = 0
+    if resume:   # a checkpoint written by this loop: continue the evaluation counter, the evaluator's key chain and the best-params record
+        start_eval = int(resume["eval_step"]) + 1
+        key_e = np.asarray(resume["key_e"], np.uint32)
+        max_episode_return = float(resume["max_episode_return"])
+        best_params = None if resume["best_params"] is None else {k: v.to(device) for k, v in resume["best_params"].items()}
+    for eval_step in range(start_eval, int(config.arch.num_evaluation)):
         start = time.time()
         learner_output = learn(learner_state)
         torch.cuda.synchronize()
@@ -226,14 +239,16 @@ def run_experiment(_config) -> float:
         if logger:
             logger.log(eval_metrics, t, eval_step, LogEvent.EVAL)
         episode_return = float(np.mean(eval_metrics["episode_return"]))
-        if save_checkpoint:  # rec_magpo.py:779-785
-            checkpointer.save(timestep=t, unreplicated_learner_state=learner_output.learner_state, episode_return=episode_return)
         if config.arch.absolute_metric and max_episode_return <= episode_return:
             best_params = {k: v.clone() for k, v in trained_params.items()}
             max_episode_return = episode_return
+        if save_checkpoint:  # rec_magpo.py:779-785 (+ what run_experiment itself needs to continue: its loop state)
+            checkpointer.save(timestep=t, unreplicated_learner_state=learner_output.learner_state, episode_return=episode_return,
+                              extras=dict(eval_step=eval_step, key_e=key_e.copy(), max_episode_return=max_episode_return,
+                                          best_params=None if best_params is None else {k: v.cpu() for k, v in best_params.items()}))
         learner_state = learner_output.learner_state
 
-    eval_performance = float(np.mean(eval_metrics[config.env.eval_metric]))
+    eval_performance = float(np.mean(eval_metrics[config.env.eval_metric])) if eval_metrics else float("nan")
     if config.arch.absolute_metric:
         eb = get_num_eval_envs(config, absolute_metric=True, n_devices=n_devices)
         abs_hs = {"hidden_state": torch.zeros(eb * env.num_agents, 128, device=device)}

@@ -30,29 +30,30 @@ def _to_cpu(x: Any) -> Any:
 class Checkpointer:
     def __init__(self, model_name: str, metadata: Optional[Dict] = None, base_path: str = "results/", rel_dir: str = "checkpoints",
                  checkpoint_uid: Optional[str] = None, save_interval_steps: int = 1, max_to_keep: Optional[int] = 1,
-                 keep_period: Optional[int] = None):
+                 keep_period: Optional[int] = None, keep_latest: bool = False):
         uid = checkpoint_uid or time.strftime("%Y%m%d%H%M%S")
         self.dir = os.path.join(base_path, rel_dir, model_name, uid)
         os.makedirs(self.dir, exist_ok=True)
         self.interval = max(1, int(save_interval_steps))
         self.max_to_keep = max_to_keep
         self.keep_period = keep_period
+        self.keep_latest = bool(keep_latest)   # extension: rank by timestep instead of episode_return (resumable sweeps)
         self.kept: List[Tuple[float, int, str]] = []   # (episode_return, timestep, path)
         self.calls = 0
         with open(os.path.join(self.dir, "metadata.json"), "w") as f:
             json.dump({"checkpointer_version": CHECKPOINTER_VERSION, **(metadata or {})}, f, indent=1, default=str)
 
-    def save(self, timestep: int, unreplicated_learner_state: Any, episode_return: float = 0.0) -> bool:
+    def save(self, timestep: int, unreplicated_learner_state: Any, episode_return: float = 0.0, extras: Optional[Dict] = None) -> bool:
         self.calls += 1
         if (self.calls - 1) % self.interval:
             return False
         path = os.path.join(self.dir, f"{int(timestep)}.pt")
         torch.save({"learner_state": _to_cpu(unreplicated_learner_state), "timestep": int(timestep),
-                    "episode_return": float(episode_return)}, path)
+                    "episode_return": float(episode_return), "extras": extras}, path)
         self.kept.append((float(episode_return), int(timestep), path))
         if self.max_to_keep:
             # keep the best `max_to_keep` by episode_return (ties: latest), like orbax best_fn / best_mode="max"
-            self.kept.sort(key=lambda e: (e[0], e[1]))
+            self.kept.sort(key=(lambda e: e[1]) if self.keep_latest else (lambda e: (e[0], e[1])))
             while len(self.kept) > int(self.max_to_keep):
                 ret, ts, victim = self.kept[0]
                 if self.keep_period and ts % int(self.keep_period) == 0:

@@ -27,9 +27,17 @@ TUNED = {
 }
 
 
-def overrides(scen, seed, out, num_updates, num_evaluation):
+def overrides(scen, seed, out, num_updates, num_evaluation, resumable=False):
     h = TUNED[scen]
-    return ["env=coordsum", f"env/scenario={scen}", "arch.num_envs=64", f"arch.num_evaluation={num_evaluation}", "system.total_timesteps=~",
+    extra = []
+    if resumable:   # checkpoint the full learner + loop state at every evaluation; continue from it when one exists
+        uid = f"{scen}_s{seed}"
+        have = os.path.isdir(os.path.join(out, "checkpoints", "rec_magpo", uid)) and any(
+            f.endswith(".pt") for f in os.listdir(os.path.join(out, "checkpoints", "rec_magpo", uid)))
+        extra = ["logger.checkpointing.save_model=True", "logger.checkpointing.save_args.keep_latest=True",
+                 f"logger.checkpointing.save_args.checkpoint_uid={uid}", f"logger.checkpointing.load_model={have}",
+                 f"logger.checkpointing.load_args.checkpoint_uid={uid}"]
+    return extra + ["env=coordsum", f"env/scenario={scen}", "arch.num_envs=64", f"arch.num_evaluation={num_evaluation}", "system.total_timesteps=~",
             f"system.num_updates={num_updates}", f"system.seed={seed}", f"system.num_minibatches={h['M']}", f"system.max_grad_norm={h['mgn']}",
             f"system.ppo_epochs={h['P']}", f"system.clip_eps={h['clip']}", f"system.ent_coef={h['ent']}", f"system.actor_lr={h['lr']}",
             f"system.alpha={h['alpha']}", f"system.clip_gpo={h['delta']}", f"network.net_config.embed_dim={h['E']}",
@@ -46,6 +54,7 @@ def main():
     ap.add_argument("--num-updates", type=int, default=1220)
     ap.add_argument("--num-evaluation", type=int, default=122)
     ap.add_argument("--jobs", nargs="+", default=None, help="explicit job list scenario:seed (overrides --scenarios / --seeds)")
+    ap.add_argument("--resumable", action="store_true", help="checkpoint every evaluation and continue from the latest checkpoint under --out")
     ap.add_argument("--parallel", type=int, default=5, help="runs at once on the GPU (the box allows 6 GPU processes)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -58,13 +67,16 @@ def main():
         while jobs and len(running) < args.parallel:
             scen, seed = jobs.pop(0)
             log = open(os.path.join(args.out, f"{scen}_s{seed}.log"), "w")
-            cmd = [sys.executable, "-m", "magpo_amd.systems.gpo.anakin.rec_magpo", *overrides(scen, seed, args.out, args.num_updates, args.num_evaluation)]
+            cmd = [sys.executable, "-m", "magpo_amd.systems.gpo.anakin.rec_magpo", *overrides(scen, seed, args.out, args.num_updates, args.num_evaluation, args.resumable)]
             running.append((subprocess.Popen(cmd, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT), scen, seed, time.time()))
         time.sleep(5)
         for r in list(running):
             if r[0].poll() is not None:
                 running.remove(r)
                 print(f"[sweep] {r[1]} seed {r[2]} finished rc={r[0].returncode} in {time.time() - r[3]:.0f}s (elapsed {time.time() - t0:.0f}s)", flush=True)
+                if args.resumable and r[0].returncode == 0:   # a finished run needs no checkpoint any more
+                    import shutil
+                    shutil.rmtree(os.path.join(args.out, "checkpoints", "rec_magpo", f"{r[1]}_s{r[2]}"), ignore_errors=True)
         if int(time.time() - t0) % 60 < 5:
             print(f"[sweep] {len(running)} running, {len(jobs)} queued, {time.time() - t0:.0f}s", flush=True)
 
