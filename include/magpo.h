@@ -59,6 +59,27 @@ int magpo_lbf_step(int* agent_pos, int* agent_level, int* food_pos, int* food_le
                    unsigned char* mask, float* m_ep_ret, int* m_ep_len, unsigned char* m_term, int auto_reset,
                    magpo_stream_t stream);
 
+/* ---- Robot Warehouse env + wrappers (mava/wrappers/jumanji.py:137-168 RwareWrapper, AgentID, AutoReset, RecordEpisodeMetrics; the env
+ * itself is jumanji RobotWarehouse-v0 with RandomGenerator(column_height, shelf_rows, shelf_columns, num_agents, sensor_range,
+ * request_queue_size), configs/env/scenario/tiny-4ag.yaml ...).  UNPINNED DYNAMICS like LBF: csrc/rware.hip and oracle/rware.py restate
+ * the published algorithm and agree bit for bit.  State per env: grid_a / grid_s [H][W] (agents / shelves layer, 0 = empty, id + 1),
+ * agent_pos [A][2], agent_dir [A], agent_carry [A] u8, shelf_req [NS] u8, queue [Q], step_count, amask [A][5] u8, key [2], metrics_key [2],
+ * episode-metric counters (H, W, NS from magpo_rware_layout).  obs rows [N][A] of ldo floats = [one-hot id | 8 + 7 (2 r + 1)^2 features]. */
+int magpo_rware_layout(int column_height, int shelf_rows, int shelf_columns, int* out);
+int magpo_rware_reset(int* grid_a, int* grid_s, int* agent_pos, int* agent_dir, unsigned char* agent_carry,
+                      unsigned char* shelf_req, int* queue, int* step_count, unsigned char* amask, uint32_t* key,
+                      uint32_t* metrics_key, float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A,
+                      int column_height, int shelf_rows, int shelf_columns, int sensor_range, int queue_size,
+                      int time_limit, const uint32_t* env_keys, float* obs, long ldo, int* obs_step,
+                      unsigned char* mask, magpo_stream_t stream);
+int magpo_rware_step(int* grid_a, int* grid_s, int* agent_pos, int* agent_dir, unsigned char* agent_carry,
+                     unsigned char* shelf_req, int* queue, int* step_count, unsigned char* amask, uint32_t* key,
+                     uint32_t* metrics_key, float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A,
+                     int column_height, int shelf_rows, int shelf_columns, int sensor_range, int queue_size,
+                     int time_limit, const int* actions, int act_stride, float* reward, unsigned char* done,
+                     float* obs, long ldo, int* obs_step, unsigned char* mask, float* m_ep_ret, int* m_ep_len,
+                     unsigned char* m_term, int auto_reset, magpo_stream_t stream);
+
 /* input classes of wrapped CoordSum tokens (first-layer tables, csrc/classtab.hip): cls_enc = ((agent * maxval + target) * npos + pos),
  * cls_dec = prev * npos + pos per row; class_rows writes the distinct rows in class order: obs_tab [A*maxval*npos][A+1], pos_enc,
  * and prev_dec / pos_dec [(K+1)*npos].  The actor's class (agent, target) is cls_enc / npos (or cls_enc itself with pos = NULL, npos = 1;
@@ -119,6 +140,13 @@ int magpo_headmid_fwd(const float* hpre, int ldh, const float* s, float* hn, int
 int magpo_headmid_bwd(const float* hpre, int ldh, const float* s, const float* dhn, int lddhn, const float* w,
                       const float* dvalue, int dvalue_stride, float* dhpre, int lddh, float* slab_s,
                       float* slab_w, float* slab_b, long R, magpo_stream_t stream);
+/* wide observations (obs_dim > 32: rows padded to 128 columns, first layers on the MFMA dense kernels; csrc/wideobs.hip):
+ * on = RMSNorm_F(obs) * s_obs (sable_network.py:93-95), its s_obs gradient as [magpo_obsnorm_grid(R)][128] slabs, and x + pe[pos] */
+int magpo_obsnorm_grid(long R);
+int magpo_obsnorm_fwd(const float* obs, long ldo, int F, const float* s_obs, float* on, long R, magpo_stream_t stream);
+int magpo_obsnorm_bwd(const float* obs, long ldo, int F, const float* don, float* slab_s, long R, magpo_stream_t stream);
+int magpo_add_pe(const float* x, long ldx, const float* pe, const int* pos, long pos_stride, int npos, float* out,
+                 long ldout, long R, magpo_stream_t stream);
 int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, magpo_stream_t stream);
 int magpo_add_inplace(float* dst, const float* src, long n, magpo_stream_t stream);
 
@@ -140,7 +168,7 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
                                  magpo_stream_t stream);
 
 /* ---- K2 fused acting step: SableNetwork.get_actions (sable_network.py:443-482; decode.py:111-153) in ONE launch ----
- * dims_host[10] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only}; kappa_host[4] (per head);
+ * dims_host[11] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F)}; kappa_host[4] (per head);
  * keys_host [A][2] sampling keys by value, or NULL with ptrs[3] = device key table (static arguments for graph replay);
  * ptrs_host[48]: obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
  *   pe | S_enc S_d1 S_d2 ([n_block][n_head][N][64][64], updated in place) | scratch xn ([N*A] rows), done [N] u8 or NULL (envs whose

@@ -23,9 +23,11 @@ class GruActor:
                  seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
         if hidden != 128:
             raise NotImplementedError("gfx950 GRU kernels: hidden_state_dim = 128 only")
-        if obs_dim > 32 or action_dim > 32:
-            raise NotImplementedError("obs_dim <= 32 and action_dim <= 32 required")
+        if obs_dim > 128 or action_dim > 32:
+            raise NotImplementedError("obs_dim <= 128 and action_dim <= 32 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
+        self.wide = obs_dim > 32            # wide observations: rows padded to 128, pre-torso on the MFMA dense kernel (csrc/wideobs.hip)
+        self.Fld = 128 if self.wide else obs_dim
         self.dev = device
         self.L = lib()
         self.G = wgrad_groups
@@ -66,12 +68,23 @@ class GruActor:
 
     def refresh(self):
         v = self.v
+        if self.wide:   # W_pre [F, 128] as [128][128] with zero columns beyond F
+            if "pre" not in self.wt:
+                self.wt["pre"] = torch.zeros(H, 128, device=self.dev)
+            self.wt["pre"][:, :self.F].copy_(v["pre.kernel"].t())
         self._tp("wi", v["gru.wi"]); self._tp("wh", v["gru.wh"]); self._tp("post", v["post.kernel"])
         ht = self._tp("head", v["head.kernel"], 64)      # [64][128]
         self._tp("head_nat_pad", ht, H)                   # [128][64]
 
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self._st())
+
+    def pre_torso(self, obs, emb, R):
+        """emb = relu(obs W_pre + b) (MLPTorso, torsos.py:36-47) for R observation rows (stride self.Fld)."""
+        if self.wide:
+            self.lin(obs, 128, self.wt["pre"], self.v["pre.bias"], emb, H, R, 128, H, act=1)
+        else:
+            self.L.call("magpo_small_linear", obs, self.F, self.F, self.v["pre.kernel"], self.v["pre.bias"], emb, H, H, R, 1, self._st())
 
     def _groups(self, R):
         """Row slabs of a split weight gradient: no more than one per 256 rows (small minibatches: fewer partials to reduce)."""
@@ -94,7 +107,7 @@ class GruActor:
         N = obs.shape[0]
         R = N * A
         emb = b.get("s_emb", (R, H)); xi = b.get("s_xi", (R, 3 * H))
-        L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
+        self.pre_torso(obs, emb, R)
         self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
         L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h_in, None, reset_env, h_out, None, None, N, 1, A, None, st)
         if not want_logits:
@@ -117,7 +130,7 @@ class GruActor:
             L.call("magpo_gru_carry", xi_tab, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, classes[1], st)
             return
         emb = b.get("c_emb", (R, H)); xi = b.get("c_xi", (R, 3 * H))
-        L.call("magpo_small_linear", obs_tm, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
+        self.pre_torso(obs_tm, emb, R)
         self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
         L.call("magpo_gru_carry", xi, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, None, st)
 
@@ -148,7 +161,7 @@ class GruActor:
         else:
             emb = b.get("t_emb", (R, H)); xi = b.get("t_xi", (R, 3 * H))
             xi_cls = None
-            L.call("magpo_small_linear", obs, F, F, v["pre.kernel"], v["pre.bias"], emb, H, H, R, 1, st)
+            self.pre_torso(obs, emb, R)
             self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
         L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h0, h0_idx, dones, hs, gates, hprev, nseq, T, A, xi_cls, st)
         self.lin(hs, H, self.wt["post"], v["post.bias"], y, H, R, H, H, act=1)
@@ -185,6 +198,12 @@ class GruActor:
             emb = t("emb")
         self.wgrad(emb, H, dxi, 3 * H, R, H, 3 * H, gv["gru.wi"], gv["gru.bi"])
         demb = b.get("g_demb", (R, H))
+        if self.wide:   # ReLU backward fused into the dX GEMM (act 4 takes the mask), then dW_pre = obs^T demb on the dense kernel
+            self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H, act=4, Ypre=emb)
+            self.wgrad(obs, 128, demb, H, R, 128, H, gv["pre.kernel"], gv["pre.bias"], krows=F)
+            if self.overlap_wgrad and self.wgrad_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            return
         self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H)
         grid = L.call("magpo_row_grid", R)
         sw = b.get("g_slabw", (grid, 33 * H))

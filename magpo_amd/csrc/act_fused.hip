@@ -35,7 +35,7 @@ struct ActBlk {
   float *qkvg1, *q2, *kvg2;                                                                   // scratch [N*A][256|64|192]
 };
 struct ActArgs {
-  int N, A, K, F, nb, nh, hs, gs, npos, value_only;
+  int N, A, K, F, nb, nh, hs, gs, npos, value_only, ldo;   // ldo = floats between observation rows (>= F: wide observations are padded)
   const float* obs; const int* pos; const unsigned char* mask; const uint32_t* keys_dev; uint32_t keys[16][2];
   const float *s_obs, *W_obs, *s_encln, *W_act, *s_decln;
   const float *vh0_t, *vh0_b, *vh_s, *vh_w, *vh_b1;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
       const long row = ge * A + t;
       Row x;
       if (b == 0) {   // x = rms(gelu(rmsnorm_F(obs) * s_obs @ W_obs)) * s_encln   (sable_network.py:93-101,126,132)
-        const float* o = a.obs + row * a.F;
+        const float* o = a.obs + row * a.ldo;
         float ms = 0.f;
         for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
         const float rstd = rsqrtf(ms / (float)a.F + EPSN);
@@ -513,17 +513,17 @@ template <int EPW> static void launch_act(const ActArgs& a, hipStream_t st) {
 }
 
 // Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
-//   dims_host[10] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only}; kappa_host[4]; keys_host [A][2] or NULL (then
+//   dims_host[11] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride}; kappa_host[4]; keys_host [A][2] or NULL (then
 //   ptrs[3] = device key table);  ptrs_host[48] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
 extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs,
                                int nptrs, const void* const* blk_ptrs, int nblk_ptrs, hipStream_t st) {
   ActArgs a;
   memset(&a, 0, sizeof(a));
   a.N = dims_host[0]; a.A = dims_host[1]; a.K = dims_host[2]; a.F = dims_host[3]; a.nb = dims_host[4]; a.nh = dims_host[5];
-  a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9];
+  a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9]; a.ldo = dims_host[10];
   if (a.N <= 0) return MAGPO_OK;
   if (a.A < 1 || a.A > MAXA || a.nb < 1 || a.nb > MAXB || a.nh < 1 || a.nh > 4 || a.K < 1 || a.K > 64 || a.F < 1 || a.hs * a.nh != AE ||
-      a.gs < 4 || a.gs > a.hs || (a.gs & (a.gs - 1)) || a.npos < 1) {
+      a.gs < 4 || a.gs > a.hs || (a.gs & (a.gs - 1)) || a.npos < 1 || a.ldo < a.F) {
     set_error("magpo_sable_act: unsupported shape (1 <= A <= 8, n_block <= 4, n_head in {1,2,4}, K <= 64)");
     return MAGPO_EINVAL;
   }

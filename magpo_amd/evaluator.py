@@ -16,7 +16,7 @@ import torch
 
 from ._lib import lib
 from .actor import GruActor
-from .learner import host_split, make_env_batch
+from .learner import host_split, make_env_batch, obs_row_stride
 
 
 def get_num_eval_envs(config, absolute_metric: bool, n_devices: int = 1) -> int:
@@ -71,7 +71,7 @@ def get_eval_fn(eval_env, act_fn: Callable, config, absolute_metric: bool, devic
     env = make_env_batch(cfg, n_envs, device)
     f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
     i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
-    obs, obs_step = f32(n_envs, A, cfg.obs_dim), i32(n_envs)
+    obs, obs_step = f32(n_envs, A, obs_row_stride(cfg.obs_dim)), i32(n_envs)
     mask = torch.zeros(n_envs, A, cfg.num_actions, dtype=torch.uint8, device=device) if cfg.has_mask else None
     reward, done = f32(n_envs, A), torch.zeros(n_envs, dtype=torch.uint8, device=device)
     m_ret, m_len, m_term = f32(n_envs), i32(n_envs), torch.zeros(n_envs, dtype=torch.uint8, device=device)

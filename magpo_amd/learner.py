@@ -152,7 +152,69 @@ class LbfEnvBatch:
                     1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
 
 
+@dataclass
+class RwareConfig:
+    """jumanji RobotWarehouse-v0 + RandomGenerator(**task_config) (configs/env/scenario/tiny-4ag.yaml ...) under RwareWrapper."""
+    column_height: int = 8
+    shelf_rows: int = 1
+    shelf_columns: int = 3
+    num_agents: int = 4
+    sensor_range: int = 1
+    request_queue_size: int = 4
+    time_limit: int = 500
+    has_mask = True
+    class_tables = False
+    num_actions = 5
+
+    @property
+    def obs_dim(self) -> int:   # 8 + 7 (2 r + 1)^2 vector observation + one-hot agent id
+        return 8 + 7 * (2 * self.sensor_range + 1) ** 2 + self.num_agents
+
+
+class RwareEnvBatch:
+    """Device-resident batch of wrapped Robot Warehouse envs (csrc/rware.hip; UNPINNED dynamics, see oracle/rware.py)."""
+    state_fields = ("grid_a", "grid_s", "agent_pos", "agent_dir", "agent_carry", "shelf_req", "queue", "step_count", "amask", "key",
+                    "metrics_key", "run_ret", "run_len", "ep_ret", "ep_len")
+
+    def __init__(self, cfg: RwareConfig, N: int, device):
+        self.cfg, self.N, self.dev = cfg, N, device
+        self.L = lib()
+        lay = np.zeros(3, np.int32)
+        self.L.call("magpo_rware_layout", cfg.column_height, cfg.shelf_rows, cfg.shelf_columns, lay.ctypes.data)
+        self.H, self.W, self.NS = int(lay[0]), int(lay[1]), int(lay[2])
+        A = cfg.num_agents
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=device)
+        self.grid_a, self.grid_s = i32(N, self.H, self.W), i32(N, self.H, self.W)
+        self.agent_pos, self.agent_dir, self.agent_carry = i32(N, A, 2), i32(N, A), u8(N, A)
+        self.shelf_req, self.queue = u8(N, self.NS), i32(N, cfg.request_queue_size)
+        self.step_count, self.amask, self.key, self.metrics_key = i32(N), u8(N, A, 5), i32(N, 2), i32(N, 2)
+        self.run_ret, self.run_len = torch.zeros(N, device=device), i32(N)
+        self.ep_ret, self.ep_len = torch.zeros(N, device=device), i32(N)
+        self.ldo = obs_row_stride(cfg.obs_dim)
+
+    def _args(self):
+        c = self.cfg
+        return (self.grid_a, self.grid_s, self.agent_pos, self.agent_dir, self.agent_carry, self.shelf_req, self.queue, self.step_count, self.amask,
+                self.key, self.metrics_key, self.run_ret, self.run_len, self.ep_ret, self.ep_len, self.N, c.num_agents, c.column_height,
+                c.shelf_rows, c.shelf_columns, c.sensor_range, c.request_queue_size, c.time_limit)
+
+    def reset(self, env_keys: torch.Tensor, obs, obs_step, mask=None):
+        self.L.call("magpo_rware_reset", *self._args(), env_keys, obs, self.ldo, obs_step, mask, torch.cuda.current_stream().cuda_stream)
+
+    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None):
+        self.L.call("magpo_rware_step", *self._args(), actions, self.cfg.num_agents, reward, done, obs, self.ldo, obs_step, mask, m_ret, m_len,
+                    m_term, 1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
+
+
+def obs_row_stride(obs_dim: int) -> int:
+    """Floats between observation rows: obs_dim for small observations, 128 (zero-padded) for wide ones (csrc/wideobs.hip)."""
+    return obs_dim if obs_dim <= 32 else 128
+
+
 def make_env_batch(cfg, N: int, device):
+    if isinstance(cfg, RwareConfig):
+        return RwareEnvBatch(cfg, N, device)
     return LbfEnvBatch(cfg, N, device) if isinstance(cfg, LbfConfig) else CoordSumEnvBatch(cfg, N, device)
 
 
@@ -162,7 +224,7 @@ class EnvGroup:
     the parameters and the training workspaces."""
 
     def __init__(self, env_cfg, N: int, T: int, device, n_block: int = 1, n_head: int = 1):
-        A, F = env_cfg.num_agents, env_cfg.obs_dim
+        A, F = env_cfg.num_agents, obs_row_stride(env_cfg.obs_dim)
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
         u8 = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=device)
@@ -194,6 +256,7 @@ class MagpoLearner:
         A, K = env_cfg.num_agents, env_cfg.num_actions
         F = env_cfg.obs_dim  # with the AgentIDWrapper's one-hot id (observation.py:42-54), add_agent_id: True
         self.A, self.K, self.F, self.T = A, K, F, sys.rollout_length
+        self.Fld = obs_row_stride(F)
         if num_envs % sys.num_minibatches:
             raise ValueError("num_envs must be divisible by num_minibatches")
         self.L = lib()
@@ -439,7 +502,7 @@ class MagpoLearner:
     # ------------------------------------------------------------------ one minibatch (rec_magpo.py:217-435)
     def _gather(self, groups: List[int], env_idx: torch.Tensor, agent_perm: torch.Tensor):
         """Minibatch rows (j, t, a') of the listed groups, group after group, in sequence-major order."""
-        T, N, A, F, K = self.T, self.N, self.A, self.F, self.K
+        T, N, A, F, K = self.T, self.N, self.A, self.Fld, self.K   # (observation rows are copied with their padding)
         mb, U = env_idx.numel(), len(groups)
         R1 = mb * T * A
         R = U * R1

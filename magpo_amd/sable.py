@@ -52,9 +52,13 @@ class SableGuider:
         self.EL = int(embed_dim)        # logical embed_dim (what the optimiser, checkpoints and the reference see)
         self.hs = E // self.nh          # head width of the 64-wide device network
         self.gs = self.hs // self.nh    # flax GroupNorm(num_groups=n_head) on (token*head, hs) rows: hs / n_head channels per group
-        if obs_dim > 32 or action_dim > 31:
-            raise NotImplementedError("obs_dim <= 32 and action_dim <= 31 required")
+        if obs_dim > 128 or action_dim > 31:
+            raise NotImplementedError("obs_dim <= 128 and action_dim <= 31 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
+        # observation rows: F floats apart for small observations (row kernels), padded to 128 for wide ones (obs_dim > 32, e.g.
+        # Robot Warehouse: the observation-side first layer then runs on the MFMA dense kernels, csrc/wideobs.hip)
+        self.wide = obs_dim > 32
+        self.Fld = 128 if self.wide else obs_dim
         self.dev = device
         self.L = lib()
         self.kappas = decay_kappas(self.nh, decay_scaling_factor)
@@ -128,6 +132,12 @@ class SableGuider:
         if self.emb is not None:
             self.emb.expand(self.P.flat, self.PD.flat)
         v = self.v
+        if self.wide:   # W_obs [F, 64] as [64][128] (forward) and [128][64] (dOn = dz W_obs^T), zero beyond F
+            for name, shape in (("wobs", (E, 128)), ("wobs_nat_pad", (128, E))):
+                if name not in self.wt:
+                    self.wt[name] = torch.zeros(*shape, device=self.dev)
+            self.wt["wobs"][:, :self.F].copy_(v["enc.obs.dense.kernel"].t())
+            self.wt["wobs_nat_pad"][:self.F].copy_(v["enc.obs.dense.kernel"])
         self._tp("vh0", v["enc.head.dense0.kernel"])
         self._tp("h0", v["dec.head.dense0.kernel"])
         for b in range(self.nb):
@@ -298,6 +308,8 @@ class SableGuider:
         (optional): envs whose episode ended on the previous step -- their carried states are read as zero
         (rec_magpo.py:164-169), which replaces a separate zeroing pass between steps."""
         A, K, F, nb, nh = self.A, self.K, self.F, self.nb, self.nh
+        if A > 8 and self.wide:
+            raise NotImplementedError("wide observations (obs_dim > 32) with more than 8 agents")
         if A > 8:   # token staging registers of the fused kernel: larger teams take the kernel-by-kernel path
             if done is not None:
                 for k in range(nb):
@@ -334,7 +346,7 @@ class SableGuider:
                         self.wt[f"q2{k}"], self.wt[f"kvg2{k}"], self.wt[f"wo2{k}"], v[d + "ln2.scale"], v[d + "ln3.scale"],
                         v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
                         g(f"qkvg1_{k}", 4 * E), g(f"q2_{k}"), g(f"kvg2_{k}", 4 * E)]   # kvg2 rows: [k | v | - | P2] (ld 256)
-            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0], dtype=np.int32),
+            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld], dtype=np.int32),
                     np.array((self.kappas + [0.0] * 4)[:4], dtype=np.float32),
                     np.array([ptr(t) for t in glob], dtype=np.uint64), np.array([ptr(t) for t in blk], dtype=np.uint64))
             if len(self._act_tabs) > 4096:
@@ -408,6 +420,12 @@ class SableGuider:
             self.lin(kin_c, E, self.wt["qkvg0"], None, qkvg_c, 4 * E, Ce, E, 4 * E)
             L.call("magpo_gather_rows", xn_c, E, classes["enc"][0], g("xn0"), E, R, E, st)
             L.call("magpo_gather_rows", qkvg_c, 4 * E, classes["enc"][0], g("qkvg0", 4 * E), 4 * E, R, 4 * E, st)
+        elif self.wide:   # obs_encoder + ln on padded rows: RMSNorm_F -> Dense on the MFMA kernel -> GELU + RMSNorm (sable_network.py:93-101,132)
+            on, z0 = b.get("t_on", (R, 128)), g("z0")
+            L.call("magpo_obsnorm_fwd", obs, self.Fld, F, v["enc.obs.norm.scale"], on, R, st)
+            self.lin(on, 128, self.wt["wobs"], None, z0, E, R, 128, E)
+            L.call("magpo_headmid_fwd", z0, E, v["enc.ln.scale"], g("xn0"), E, None, None, None, 0, R, st)
+            L.call("magpo_add_pe", g("xn0"), E, self.pe, pos, 1, self.npos, g("kin0"), E, R, st)
         else:
             L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
                    self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, st)   # z is recomputed by the backward
@@ -655,6 +673,17 @@ class SableGuider:
                 self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
                 first_ln = False
                 e0, e1, e2 = drepb, None, None
+            elif self.wide:
+                dxn, dz, don = g("dxn0"), g("dz0"), b.get("g_don", (R, 128))
+                L.call("magpo_copy_rows", dsum0, E, dxn, E, R, E, st)
+                self.add_(dxn, dkin)
+                L.call("magpo_headmid_bwd", t("z0"), E, v["enc.ln.scale"], dxn, E, None, None, 0, dz, E, slab("a"), None, None, R, st)
+                self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
+                self.wgrad(b.t["t_on"], 128, dz, E, R, 128, E, gv["enc.obs.dense.kernel"], krows=F)
+                self.lin(dz, E, self.wt["wobs_nat_pad"], None, don, 128, R, E, 128)
+                so = b.get("s_obsn", (L.call("magpo_obsnorm_grid", R), 128))
+                L.call("magpo_obsnorm_bwd", obs, self.Fld, F, don, so, R, st)
+                self.reduce(so, gv["enc.obs.norm.scale"], P=F, stride=128)
             else:
                 L.call("magpo_embed_bwd", 0, None, 0, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], None, 0, slab("a"), slab("w", 32 * E), F,
                        obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, st)

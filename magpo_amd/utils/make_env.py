@@ -1,14 +1,14 @@
 """Environment factory (mava/utils/make_env.py:202-218, 288-315): config -> (train_env, eval_env) descriptors.
 
-CoordSum (csrc/coordsum.hip) and Level-Based Foraging (csrc/lbf.hip) are implemented.  LBF / RWARE dynamics live in
-third-party Jumanji, which is absent from the reference tree and from this image: LBF is restated from Jumanji's published
-algorithm with UNPINNED dynamics (oracle/lbf.py lists every rule); RWARE is not built and raises NotImplementedError.
+CoordSum (csrc/coordsum.hip), Level-Based Foraging (csrc/lbf.hip) and Robot Warehouse (csrc/rware.hip) are implemented.  LBF / RWARE
+dynamics live in third-party Jumanji, which is absent from the reference tree and from this image: both are restated from
+Jumanji's published algorithm with UNPINNED dynamics (oracle/lbf.py and oracle/rware.py list every rule).
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
 
-from ..learner import CoordSumConfig, LbfConfig
+from ..learner import CoordSumConfig, LbfConfig, RwareConfig
 
 COORDSUM_REGISTRY = {  # mava/coordsum/__init__.py:6-45
     "5x20-80-v0": dict(num_agents=5, num_actions=20, time_limit=100, maxval=80),
@@ -21,7 +21,7 @@ COORDSUM_REGISTRY = {  # mava/coordsum/__init__.py:6-45
 @dataclass
 class MarlEnvSpec:
     """What the system file reads from a MarlEnv (mava/types.py:45-123)."""
-    cfg: object   # CoordSumConfig | LbfConfig
+    cfg: object   # CoordSumConfig | LbfConfig | RwareConfig
     auto_reset: bool
     add_agent_id: bool = True
 
@@ -72,6 +72,28 @@ def make_lbf_env(config):
     cfg = LbfConfig(grid_size=int(tc["grid_size"]), fov=int(tc["fov"]), num_agents=int(tc["num_agents"]), num_food=int(tc["num_food"]),
                     max_agent_level=int(tc.get("max_agent_level", 2)), force_coop=bool(tc.get("force_coop", False)),
                     time_limit=int(kw.get("time_limit", 100)))
+    if cfg.obs_dim > 32:
+        raise NotImplementedError("LevelBasedForaging: num_agents + 3 (num_food + num_agents) <= 32 (the LBF kernel writes unpadded observation rows)")
+    return MarlEnvSpec(cfg, auto_reset=True), MarlEnvSpec(cfg, auto_reset=False)
+
+
+def make_rware_env(config):
+    """make_jumanji_env (make_env.py:107-135) for RobotWarehouse: generator = RandomGenerator(**scenario.task_config), env kwargs =
+    {**env.kwargs (time_limit: 500), **scenario.env_kwargs}, wrapped by RwareWrapper."""
+    tc = config.env.scenario.task_config.to_container()
+    kw = {**config.env.kwargs.to_container(), **config.env.scenario.env_kwargs.to_container()}
+    unknown = set(kw) - {"time_limit"}
+    if unknown:
+        raise NotImplementedError(f"RobotWarehouse kwargs {sorted(unknown)} are not supported")
+    add_id = bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id)
+    config.system.add_agent_id = add_id
+    if not add_id:
+        raise NotImplementedError("system.add_agent_id=False is not supported by the HIP env kernels")
+    cfg = RwareConfig(column_height=int(tc["column_height"]), shelf_rows=int(tc["shelf_rows"]), shelf_columns=int(tc["shelf_columns"]),
+                      num_agents=int(tc["num_agents"]), sensor_range=int(tc["sensor_range"]), request_queue_size=int(tc["request_queue_size"]),
+                      time_limit=int(kw.get("time_limit", 500)))
+    if cfg.sensor_range != 1:
+        raise NotImplementedError("RobotWarehouse: sensor_range 1 only (observation rows are padded to 128 floats)")
     return MarlEnvSpec(cfg, auto_reset=True), MarlEnvSpec(cfg, auto_reset=False)
 
 
@@ -81,8 +103,6 @@ def make(config):
         return make_coordsum_env(config)
     if env_name == "LevelBasedForaging":
         return make_lbf_env(config)
-    if env_name in ("RobotWarehouse",):
-        raise NotImplementedError(
-            f"{env_name}: dynamics live in Jumanji (git pin 9ced6b8), which is not part of the reference tree; "
-            "no verified HIP kernel exists yet (SURVEY 8f rank 2). Use env=coordsum.")
+    if env_name == "RobotWarehouse":
+        return make_rware_env(config)
     raise ValueError(f"{env_name} is not a supported environment.")

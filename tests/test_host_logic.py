@@ -69,8 +69,13 @@ def test_env_factory():
     c = compose("rec_magpo", ["env=coordsum", "+env.kwargs.num_agents=4", "+env.kwargs.num_actions=20", "+env.kwargs.maxval=60"])
     tr, _ = make_env.make(c)
     assert (tr.num_agents, tr.action_dim, tr.cfg.maxval) == (4, 20, 60)
+    # the default env of configs/default/rec_magpo.yaml is rware tiny-4ag: 71 vector features + 4 agent-id features
+    tr, ev = make_env.make(compose("rec_magpo"))
+    assert (tr.num_agents, tr.action_dim, tr.time_limit, tr.obs_dim) == (4, 5, 500, 75) and tr.cfg.has_mask
+    tr, _ = make_env.make(compose("rec_magpo", ["env=lbf", "env/scenario=15x15-4p-5f"]))
+    assert (tr.num_agents, tr.action_dim, tr.time_limit, tr.obs_dim, tr.cfg.fov) == (4, 6, 100, 31, 15)
     with pytest.raises(NotImplementedError):
-        make_env.make(compose("rec_magpo"))
+        make_env.make(compose("rec_magpo", ["env=rware", "env.scenario.task_config.sensor_range=2"]))
 
 
 def test_check_total_timesteps_and_logger(tmp_path, capsys):
