@@ -106,6 +106,9 @@ class KernelTimer:
         if name == "magpo_lbf_step":        # state in + out, observation + action mask + reward / metrics out
             N, A, NF = a[12], a[13], a[14]
             return "k_lbf_step", float(N) * (2.0 * (12.0 * A + 13.0 * NF + 40.0) + 4.0 * A * (A + 3 * (NF + A)) + 6.0 * A + 4.0 * A + 12.0), 0.0
+        if name == "magpo_rware_step":      # the cells a step touches + observation rows (padded to 128 floats) + masks / reward / metrics
+            N, A = a[15], a[16]
+            return "k_rware_step", float(N) * (4.0 * A * 128 + 2.0 * 4.0 * (6 * A + 9 * A) + 5.0 * A + 4.0 * A + 64.0), 0.0
         if name == "magpo_loss_fwd_bwd":
             R, K = a[19], a[20]
             return "k_magpo_loss", 4.0 * R * (4 * K + 8), 60.0 * R * K
@@ -217,9 +220,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (weak scaling)")
-    ap.add_argument("--workload", default="coordsum-4ag", choices=["coordsum-4ag", "coordsum-8x15", "lbf-8x8-2p-2f"],
+    ap.add_argument("--workload", default="coordsum-4ag", choices=["coordsum-4ag", "coordsum-8x15", "lbf-8x8-2p-2f", "rware-tiny-4ag"],
                     help="coordsum-4ag = BASELINE.json configs[1] (headline); coordsum-8x15 = configs[4] per GPU (registered 8x15-100, n_block=2, 8 minibatches); "
-                         "lbf-8x8-2p-2f = configs[2] (Level-Based Foraging 8x8-2p-2f-coop, UNPINNED dynamics: csrc/lbf.hip restates Jumanji's published algorithm)")
+                         "lbf-8x8-2p-2f = configs[2] (Level-Based Foraging 8x8-2p-2f-coop) and rware-tiny-4ag = configs[3] per GPU (Robot Warehouse tiny-4ag, run it with "
+                         "--num-envs 4096): UNPINNED dynamics, csrc/lbf.hip / csrc/rware.hip restate Jumanji's published algorithm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
@@ -229,7 +233,7 @@ def main():
 
     from magpo_amd import distributed as mdist
     from magpo_amd._lib import lib
-    from magpo_amd.learner import CoordSumConfig, LbfConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    from magpo_amd.learner import CoordSumConfig, LbfConfig, MagpoLearner, RwareConfig, SystemConfig, host_split, prng_key
     import torch.distributed as dist
 
     rank, world, local = mdist.init_from_env(args.backend)
@@ -245,6 +249,10 @@ def main():
         sysc = SystemConfig(num_minibatches=8)  # 8 agents: 8 minibatches (as the tuned run) keep R = mb*T*A at 2.1 M rows
         env_cfg = CoordSumConfig(num_agents=8, num_actions=15, time_limit=100, maxval=100)
         n_block = 2
+    elif args.workload == "rware-tiny-4ag":
+        sysc = SystemConfig()
+        env_cfg = RwareConfig(column_height=8, shelf_rows=1, shelf_columns=3, num_agents=4, sensor_range=1, request_queue_size=4, time_limit=500)
+        n_block = 1
     elif args.workload == "lbf-8x8-2p-2f":
         sysc = SystemConfig()
         env_cfg = LbfConfig(grid_size=8, fov=8, num_agents=2, num_food=2, max_agent_level=2, force_coop=True, time_limit=100)
@@ -296,7 +304,7 @@ def main():
         # The acting kernel runs inside the rollout's HIP graph, where per-launch events cannot be recorded: time it on one
         # EAGER rollout here (same kernel, same shapes, same data distribution), still outside the timed region.  Every rank
         # runs this extra update step so that the replicas stay in lock-step.
-        lib().timer, timer.enabled, timer.only = timer, True, ("magpo_sable_act", "magpo_coordsum_step", "magpo_lbf_step")
+        lib().timer, timer.enabled, timer.only = timer, True, ("magpo_sable_act", "magpo_coordsum_step", "magpo_lbf_step", "magpo_rware_step")
     learner.use_graph = False
     learner.update_step(grad_sync)
     learner.use_graph = True
@@ -333,7 +341,11 @@ def main():
         roof, table = timer.dominant(args.steps, act_keys)
         rollout_ms = round(sum(e0.elapsed_time(e1) for e0, e1 in roll_events) / max(1, len(roll_events)), 2) if roll_events else None
         env_steps = world * N * sysc.rollout_length * args.steps
-        if isinstance(env_cfg, LbfConfig):
+        if isinstance(env_cfg, RwareConfig):
+            env_name = "RobotWarehouse"
+            env_desc = ("Robot Warehouse tiny-4ag (11 x 10 grid, 32 shelves, sensor range 1, 75-wide observations, time_limit=500; UNPINNED dynamics "
+                        "restated from Jumanji's published algorithm)")
+        elif isinstance(env_cfg, LbfConfig):
             env_name = "LevelBasedForaging"
             env_desc = (f"Level-Based Foraging {env_cfg.grid_size}x{env_cfg.grid_size}-{env_cfg.num_agents}p-{env_cfg.num_food}f-coop (fov {env_cfg.fov}, "
                         "time_limit=100; UNPINNED dynamics restated from Jumanji's published algorithm)")

@@ -118,7 +118,7 @@ def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh, E):
     # compared from a COMMON starting point: the oracle takes over the device's parameters and Adam moments (the drift
     # up to there is bounded separately), while env state, PRNG keys, hidden states and trajectories keep running unsynced.
     dl._carry_over()
-    for s in (2, 3):
+    for s in ((2, 3) if T < 100 else (2,)):   # (the T = 128 cases spend their time in the oracle: one further step there)
         drift = max((v.cpu() - ref[n].reshape(v.shape)).abs().max().item() for net, ref in ((dl.guider, ol.gp), (dl.actor, ol.ap))
                     for n, v in net.named.items())
         assert drift <= 3e-5, f"parameter drift entering update step {s}: {drift:.2e}"
