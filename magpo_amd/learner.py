@@ -40,6 +40,11 @@ class SystemConfig:
     clip_gpo: float = 1.5
     alpha: float = 1.0
     actor_lr: float = 2.5e-4
+    # make_learning_rate (mava/utils/training.py:20-64): linear decay lr * (1 - (count // (ppo_epochs * num_minibatches)) / num_updates)
+    # with the optimiser step count BEFORE the step; lr_num_updates is config.system.num_updates as it stands when the optimiser is built
+    # (rec_magpo.py:581 runs before check_total_timesteps)
+    decay_learning_rates: bool = False
+    lr_num_updates: int = 1000
 
 
 @dataclass
@@ -627,7 +632,10 @@ class MagpoLearner:
             cnt = (self.g_count if which == "g" else self.a_count) + 1
             bc1 = float(np.float32(1) - np.float32(0.9) ** np.float32(cnt))
             bc2 = float(np.float32(1) - np.float32(0.999) ** np.float32(cnt))
-            self.L.call("magpo_clip_adam", net.P.flat, net.grads, mu, nu, net.P.numel, grad_scale, s.max_grad_norm, s.actor_lr,
+            lr = s.actor_lr
+            if s.decay_learning_rates:
+                lr = s.actor_lr * (1.0 - ((cnt - 1) // (s.ppo_epochs * s.num_minibatches)) / s.lr_num_updates)
+            self.L.call("magpo_clip_adam", net.P.flat, net.grads, mu, nu, net.P.numel, grad_scale, s.max_grad_norm, lr,
                         0.9, 0.999, 1e-5, bc1, bc2, self.ws64, self.gnorm[0:1] if which == "g" else self.gnorm[1:2], st)
             if which == "g":
                 self.g_count = cnt

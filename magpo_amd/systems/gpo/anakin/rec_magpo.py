@@ -38,12 +38,11 @@ LearnerState = GPOLearnerState
 
 def _system_config(config) -> SystemConfig:
     s = config.system
-    if s.get("decay_learning_rates", False):
-        raise NotImplementedError("decay_learning_rates=True (linear lr decay) is not implemented")
     return SystemConfig(rollout_length=int(s.rollout_length), ppo_epochs=int(s.ppo_epochs), num_minibatches=int(s.num_minibatches),
                         gamma=float(s.gamma), gae_lambda=float(s.gae_lambda), clip_eps=float(s.clip_eps), ent_coef=float(s.ent_coef),
                         vf_coef=float(s.vf_coef), max_grad_norm=float(s.max_grad_norm), clip_gpo=float(s.clip_gpo),
-                        alpha=float(s.alpha), actor_lr=float(s.actor_lr))
+                        alpha=float(s.alpha), actor_lr=float(s.actor_lr), decay_learning_rates=bool(s.get("decay_learning_rates", False)),
+                        lr_num_updates=int(s.num_updates) if s.get("num_updates") else 1000)
 
 
 def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:

@@ -25,7 +25,7 @@ class SystemCfg:
     def __init__(self, **kw):
         d = dict(rollout_length=128, ppo_epochs=4, num_minibatches=2, gamma=0.99, gae_lambda=0.95,
                  clip_eps=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, clip_gpo=1.5, alpha=1.0,
-                 actor_lr=2.5e-4, hidden=128)
+                 actor_lr=2.5e-4, hidden=128, decay_learning_rates=False, lr_num_updates=1000)
         d.update(kw)
         self.__dict__.update(d)
 
@@ -278,10 +278,18 @@ class OracleLearner:
                 gg, ag, info, _ = self.minibatch_grads(mb)
                 if grad_hook is not None:
                     gg, ag = grad_hook(gg, ag)
-                self.gp, self.g_opt, _ = clip_adam_step(self.gp, gg, self.g_opt, sys.actor_lr, sys.max_grad_norm)
-                self.ap, self.a_opt, _ = clip_adam_step(self.ap, ag, self.a_opt, sys.actor_lr, sys.max_grad_norm)
+                lr_g, lr_a = self._lr(self.g_opt["count"]), self._lr(self.a_opt["count"])
+                self.gp, self.g_opt, _ = clip_adam_step(self.gp, gg, self.g_opt, lr_g, sys.max_grad_norm)
+                self.ap, self.a_opt, _ = clip_adam_step(self.ap, ag, self.a_opt, lr_a, sys.max_grad_norm)
                 infos.append(info)
         return infos
+
+    def _lr(self, count: int) -> float:
+        """make_learning_rate (mava/utils/training.py:20-64): constant, or the linear schedule evaluated at the optax step count."""
+        sys = self.sys
+        if not sys.decay_learning_rates:
+            return sys.actor_lr
+        return sys.actor_lr * (1.0 - (count // (sys.ppo_epochs * sys.num_minibatches)) / sys.lr_num_updates)
 
     def update_step(self):
         m = self.rollout()

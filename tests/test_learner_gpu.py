@@ -273,3 +273,27 @@ def test_embed32_four_heads_lbf_setting():
     for n, g in dl.guider.named_grads.items():
         scale = max(gg[n].abs().max().item(), 1e-6)
         close(g / scale, gg[n].reshape(g.shape) / scale, 0, 5e-2, f"guider grad {n}")
+
+
+def test_linear_lr_decay_matches_oracle():
+    """system.decay_learning_rates (mava/utils/training.py:20-64): lr * (1 - (count // (P * M)) / num_updates), count = optax step count."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
+    A, K, TL, maxval, N, T = 3, 10, 9, 30, 6, 10
+    spec = ocs.CoordSumSpec(A, K, TL, maxval)
+    gp = onets.init_guider_params(1, 64, A + 1, K)
+    ap = onets.init_actor_params(2, A + 1, 128, K)
+    kw = dict(rollout_length=T, ppo_epochs=2, num_minibatches=2, decay_learning_rates=True, lr_num_updates=3, actor_lr=1e-3)
+    ol = olearn.OracleLearner(spec, N, olearn.SystemCfg(**kw), onets.SableCfg(A, K, A + 1), gp, ap)
+    key = oprng.split(oprng.prng_key(8), 4)[0]
+    ol.setup(key)
+    dl = MagpoLearner(CoordSumConfig(A, K, TL, maxval), N, SystemConfig(**kw), DEV, net_seed=None, wgrad_groups=4)
+    dl.guider.load_named(gp); dl.actor.load_named(ap)
+    dl.setup(key)
+    for s in range(2):   # update 1 runs at lr, update 2 at 2/3 lr
+        ol.rollout(); dl.rollout()
+        assert np.array_equal(dl.traj["action"].cpu().numpy(), ol.traj["action"].numpy())
+        before = {n: v.clone() for n, v in ol.gp.items()}
+        ol.update(); dl.update(); dl._carry_over()
+        for n, v in dl.guider.named.items():
+            close(v, ol.gp[n].reshape(v.shape), 0, 6e-5 * (s + 1), f"guider param {n} (update {s + 1})")
+    assert ol._lr(4) == pytest.approx(1e-3 * 2 / 3) and ol._lr(3) == 1e-3

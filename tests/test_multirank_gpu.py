@@ -66,3 +66,39 @@ def test_two_ranks_equal_one_process_with_two_groups():
     for r in range(2):   # rank r rolled out group r's envs
         assert np.array_equal(res[r][4], one.groups[r].traj["action"].cpu().numpy())
     assert not np.array_equal(res[0][4], res[1][4])
+
+
+def _rccl_worker(port, q):
+    """RCCL itself (backend "nccl" on ROCm) on the one GPU of the box: a single-rank group, the same all_reduce call on the same
+    flat gradient buffer and stream ordering as the multi-GPU path."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    calls = []
+
+    def sync(learner):   # what distributed.make_grad_sync returns for world > 1, forced here for world = 1
+        before = learner.grad_all.clone()
+        dist.all_reduce(learner.grad_all, op=dist.ReduceOp.SUM)
+        calls.append(bool(torch.equal(before, learner.grad_all)))
+        return 1.0
+
+    a, b = _mk(1), _mk(1)
+    a.setup(_key()); b.setup(_key())
+    for _ in range(2):
+        a.update_step(sync)
+        b.update_step(None)
+    torch.cuda.synchronize()
+    q.put((len(calls), all(calls), bool(torch.equal(a.guider.P.flat, b.guider.P.flat) and torch.equal(a.actor.P.flat, b.actor.P.flat))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_on_the_gradient_buffer():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29900 + os.getpid() % 90, q))
+    p.start()
+    ncalls, identity, same = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert ncalls == 2 * CFG["P"] * CFG["M"] and identity and same
