@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
+    ap.add_argument("--gru-split-bf16", action="store_true", help="A/B (NOT the headline): run the GRU training scans' recurrent GEMMs on split-bf16 x3 "
+                    "MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate, ~2^-16 relative per product) instead of fp32 MFMA; reported in the JSON")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
@@ -237,6 +239,8 @@ def main():
     import torch.distributed as dist
 
     rank, world, local = mdist.init_from_env(args.backend)
+    gru_split = bool(args.gru_split_bf16)
+    lib().call("magpo_gru_set_split_bf16", 1 if gru_split else 0)   # the headline is fp32 MFMA whatever MAGPO_GRU_SPLIT_BF16 says
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev)
     if world != args.gpus:
@@ -363,7 +367,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not gru_split else "f32 (GRU recurrent GEMMs: split-bf16 x3 MFMA, fp32 accumulate)",
             "data": f"synthetic (fixed-seed {env_name} episodes, random-init networks)",
             "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
                                    f"num_minibatches={sysc.num_minibatches}, Sable embed 64 / 1 head / {n_block} block, GRU 128",

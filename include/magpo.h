@@ -199,6 +199,10 @@ int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                        const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
                        const int* xi_cls, magpo_stream_t stream);
+/* A/B switch of the TRAINING scans (T > 1 with all save buffers): 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA (x = hi + lo in bf16, product
+ * = hi*hi + hi*lo + lo*hi with fp32 accumulation, ~2^-16 relative per product).  Returns the previous mode; the default comes from
+ * MAGPO_GRU_SPLIT_BF16. */
+int magpo_gru_set_split_bf16(int on);
 /* xi_cls (nullable): xi is a table over the distinct input rows and token row r takes xi[xi_cls[r]] (csrc/classtab.hip).
  * hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
 int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,

@@ -9,6 +9,7 @@
 // math runs on the accumulators with no LDS round trip.  The backward scan carries dL/dh in LDS and
 // needs one GEMM per step, dh_prev = dhh @ W_h^T, because the forward saves its gates.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace magpo {
 
@@ -193,6 +194,145 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
   GP_FLUSH();
 }
 
+// ---- split-bf16 (x3) variant of the training scan ---------------------------------------------------------------------------
+// fp32 MFMA runs at the fp32 VALU rate on gfx950 (1/16 of bf16): the recurrent GEMM h W_h of one step is 10 us of the 19 us a
+// step takes.  Here both operands are split x = hi + lo (hi = bf16(x), lo = bf16(x - hi); 16 mantissa bits together) and the
+// product is taken as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error of a product
+// ~2^-16 (SURVEY 7 names split-bf16 x3 as the alternative to fp32 MFMA), 3 x 1/16 of the MFMA time.  W_h is split once per
+// kernel (same 192 VGPRs as the fp32 fragments); h is written to LDS as two bf16 tiles when the gate phase produces it (each
+// element is produced once and read by all four waves).  The carry itself (z * h_prev) stays exact fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int GRU_SPLIT_DEFAULT = 0;
+constexpr int HB = H + 8;   // bf16 tile pitch (elements): 272-byte rows, 16-byte aligned
+
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)x;
+  lo = (__bf16)(x - (float)hi);
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void k_gru_scan_fwd_bf3(GruArgs a, int block0) {
+  __shared__ __align__(16) float hf[64 * HP];            // fp32 state (carry term), updated in place by the lane that owns the element
+  __shared__ __align__(16) __bf16 hsp[2][2][64 * HB];    // [buffer][hi | lo][row][k] MFMA A operand
+  extern __shared__ unsigned char rflag[];               // [64][T] reset flags, then (xi_cls) [64][T] int xi rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int rho0 = (block0 + blockIdx.x) * 64;
+  const int col = 32 * wave + lr;
+  const int T = a.T;
+  // B fragments: gate g, k-step s: k = 64 h + 8 s + j (j = 0..7), column col
+  bf16x8 whi[3][8], wlo[3][8];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const float* w = a.Wht + ((long)g * H + col) * H + 64 * h + 8 * s8;
+      const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { __bf16 hi, lo; split_bf16(wv[j], hi, lo); whi[g][s8][j] = hi; wlo[g][s8][j] = lo; }
+    }
+  const float bhn = a.b_hn[col];
+  for (int i = tid; i < 64 * T; i += 256) {
+    const int rl = i / T, t = i - rl * T;
+    const int rho = min(rho0 + rl, a.NR - 1);
+    rflag[i] = a.reset[(long)(rho / a.A) * T + t];
+  }
+  int* ctab = reinterpret_cast<int*>(rflag + 64 * T);
+  const bool by_cls = a.xi_cls != nullptr;
+  if (by_cls) {
+    for (int i = tid; i < 64 * T; i += 256) {
+      const int rl = i / T, t = i - rl * T;
+      ctab[i] = a.xi_cls[tok_row(min(rho0 + rl, a.NR - 1), t, T, a.A)];
+    }
+  }
+  for (int i = tid; i < 64 * (H / 4); i += 256) {   // initial carry (with the reset of step 0 applied)
+    const int r = i / (H / 4), c4 = i - r * (H / 4);
+    const int rho = rho0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rho < a.NR && !a.reset[(long)(rho / a.A) * T]) {
+      const long src = a.h0_idx ? a.h0_idx[rho] : rho;
+      v = *reinterpret_cast<const float4*>(a.h0 + src * H + 4 * c4);
+    }
+    *reinterpret_cast<float4*>(&hf[r * HP + 4 * c4]) = v;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { __bf16 hi, lo; split_bf16(vv[j], hi, lo); hsp[0][0][r * HB + 4 * c4 + j] = hi; hsp[0][1][r * HB + 4 * c4 + j] = lo; }
+  }
+  __shared__ long rbase[64];
+  if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const __bf16* ahi = hsp[t & 1][0];
+    const __bf16* alo = hsp[t & 1][1];
+    __bf16* nhi = hsp[(t + 1) & 1][0];
+    __bf16* nlo = hsp[(t + 1) & 1][1];
+#pragma unroll
+    for (int wr = 0; wr < 2; ++wr) {
+      float xr[16], xz[16], xn[16];
+      long rowi[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const long row = rbase[rl] + (long)t * a.A;
+        rowi[i] = row;
+        const float* x = a.xi + (by_cls ? (long)ctab[rl * T + t] : row) * G3;
+        xr[i] = x[col]; xz[i] = x[H + col]; xn[i] = x[2 * H + col];
+      }
+      float hpv[16];
+      unsigned char rf[16];
+      const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        hpv[i] = hf[rl * HP + col];
+        rf[i] = rflag[rl * T + tn];
+      }
+      f32x16 ar, az, an;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { ar[i] = 0.f; az[i] = 0.f; an[i] = 0.f; }
+      const int aoff = (32 * wr + lr) * HB + 64 * h;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ahi + aoff + 8 * s8);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(alo + aoff + 8 * s8);
+        ar = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, whi[0][s8], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, whi[1][s8], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, whi[2][s8], an, 0, 0, 0);
+        ar = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo[0][s8], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo[1][s8], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo[2][s8], an, 0, 0, 0);
+        ar = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, whi[0][s8], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, whi[1][s8], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, whi[2][s8], an, 0, 0, 0);
+      }
+      const bool more = t + 1 < T;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const long row = rowi[i];
+        const float hb = an[i] + bhn;
+        const float r = fast_sigmoid(xr[i] + ar[i]);
+        const float z = fast_sigmoid(xz[i] + az[i]);
+        const float n = fast_tanh(xn[i] + r * hb);
+        const float hp = hpv[i];
+        const float hn_new = (1.0f - z) * n + z * hp;
+        if (FULL || rho0 + rl < a.NR) {
+          a.hs[row * H + col] = hn_new;
+          *reinterpret_cast<float4*>(a.gates + row * (4 * H) + 4 * col) = make_float4(r, z, n, hb);
+          a.hprev[row * H + col] = hp;
+        }
+        const float nx = (more & (rf[i] != 0)) ? 0.f : hn_new;
+        hf[rl * HP + col] = nx;
+        __bf16 hi, lo;
+        split_bf16(nx, hi, lo);
+        nhi[rl * HB + col] = hi;
+        nlo[rl * HB + col] = lo;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 struct GruBwdArgs {
   const float* gates;     // [R][4H] as written by the forward scan: (r, z, n, hb) per hidden column
   const float* hprev;     // [R][H] from the forward
@@ -323,6 +463,137 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
   }
 }
 
+// split-bf16 (x3) variant of the backward scan (see k_gru_scan_fwd_bf3): the per-step GEMM dh_prev += dhh W_h^T on
+// v_mfma_f32_32x32x16_bf16; the element-wise phase writes dhh of the step to LDS as two bf16 tiles.
+constexpr int G3B = G3 + 8;   // bf16 pitch of the dhh tile
+
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void k_gru_scan_bwd_bf3(GruBwdArgs a, int block0) {
+  extern __shared__ __align__(16) float smem[];
+  float* dht = smem;                                                 // [64][HP] fp32 dL/dh carried from step t+1
+  __bf16* dsp = reinterpret_cast<__bf16*>(dht + 64 * HP);            // [2 (hi | lo)][64][G3B]
+  unsigned char* rflag = reinterpret_cast<unsigned char*>(dsp + 2 * 64 * G3B);   // [64][T]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
+  const int rho0 = (block0 + blockIdx.x) * 64;
+  const int col = 32 * wave + lr;
+  bf16x8 whi[24], wlo[24];   // B[k][col] = W_h[col][k], k = 192 h + 8 s + j
+#pragma unroll
+  for (int s8 = 0; s8 < 24; ++s8) {
+    const float* w = a.Wh + (long)col * G3 + 192 * h + 8 * s8;
+    const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { __bf16 hi, lo; split_bf16(wv[j], hi, lo); whi[s8][j] = hi; wlo[s8][j] = lo; }
+  }
+  for (int i = tid; i < 64 * HP; i += 256) dht[i] = 0.f;
+  __shared__ long rbase[64];
+  if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, a.T, a.A);
+  for (int i = tid; i < 64 * a.T; i += 256) {
+    const int rl = i / a.T, t = i - rl * a.T;
+    const int rho = min(rho0 + rl, a.NR - 1);
+    rflag[i] = a.reset[(long)(rho / a.A) * a.T + t];
+  }
+  __syncthreads();
+  const int c4 = 4 * (tid & 31), rg = tid >> 5;
+  float4 bacc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  __bf16* dhi = dsp;
+  __bf16* dlo = dsp + 64 * G3B;
+  for (int t = a.T - 1; t >= 0; --t) {
+    {
+      float4 gr[8], gz[8], gn[8], gh[8], hp[8], dh[8];
+      long rowv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rl = rg + 8 * k;
+        const long row = rbase[rl] + (long)t * a.A;
+        rowv[k] = row;
+        const float* g = a.gates + row * (4 * H) + 4 * c4;
+        const float4 q0 = *reinterpret_cast<const float4*>(g), q1 = *reinterpret_cast<const float4*>(g + 4);
+        const float4 q2 = *reinterpret_cast<const float4*>(g + 8), q3 = *reinterpret_cast<const float4*>(g + 12);
+        gr[k] = make_float4(q0.x, q1.x, q2.x, q3.x); gz[k] = make_float4(q0.y, q1.y, q2.y, q3.y);
+        gn[k] = make_float4(q0.z, q1.z, q2.z, q3.z); gh[k] = make_float4(q0.w, q1.w, q2.w, q3.w);
+        hp[k] = *reinterpret_cast<const float4*>(a.hprev + row * H + c4);
+        dh[k] = *reinterpret_cast<const float4*>(a.dhs + row * H + c4);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rl = rg + 8 * k;
+        const bool ok = FULL || rho0 + rl < a.NR;
+        const bool rst = rflag[rl * a.T + t] != 0;
+        const float4 dc = *reinterpret_cast<const float4*>(&dht[rl * HP + c4]);
+        float4 o_r, o_z, o_an, o_hb, carry;
+#define GRU_BWD_ELEM(X)                                                   \
+        {                                                                 \
+          const float r = gr[k].X, z = gz[k].X, n = gn[k].X, hb = gh[k].X; \
+          const float dht_ = dh[k].X + dc.X;                              \
+          const float dn = dht_ * (1.0f - z);                             \
+          const float dz = dht_ * (hp[k].X - n);                          \
+          const float dan = dn * (1.0f - n * n);                          \
+          o_an.X = dan;                                                   \
+          o_hb.X = dan * r;                                               \
+          o_r.X = dan * hb * r * (1.0f - r);                              \
+          o_z.X = dz * z * (1.0f - z);                                    \
+          carry.X = rst ? 0.f : dht_ * z;                                 \
+        }
+        GRU_BWD_ELEM(x) GRU_BWD_ELEM(y) GRU_BWD_ELEM(z) GRU_BWD_ELEM(w)
+#undef GRU_BWD_ELEM
+        if (ok) {
+          float* dx = a.dxi + rowv[k] * G3 + c4;
+          *reinterpret_cast<float4*>(dx) = o_r; *reinterpret_cast<float4*>(dx + H) = o_z; *reinterpret_cast<float4*>(dx + 2 * H) = o_an;
+          float* dq = a.dhh + rowv[k] * G3 + c4;
+          *reinterpret_cast<float4*>(dq) = o_r; *reinterpret_cast<float4*>(dq + H) = o_z; *reinterpret_cast<float4*>(dq + 2 * H) = o_hb;
+          bacc4.x += o_hb.x; bacc4.y += o_hb.y; bacc4.z += o_hb.z; bacc4.w += o_hb.w;
+        }
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rst || !ok) { o_r = z4; o_z = z4; o_hb = z4; }
+        if (!ok) carry = z4;
+        const float v12[12] = {o_r.x, o_r.y, o_r.z, o_r.w, o_z.x, o_z.y, o_z.z, o_z.w, o_hb.x, o_hb.y, o_hb.z, o_hb.w};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            __bf16 hi, lo;
+            split_bf16(v12[4 * q + j], hi, lo);
+            dhi[rl * G3B + q * H + c4 + j] = hi;
+            dlo[rl * G3B + q * H + c4 + j] = lo;
+          }
+        *reinterpret_cast<float4*>(&dht[rl * HP + c4]) = carry;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int wr = 0; wr < 2; ++wr) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const int aoff = (32 * wr + lr) * G3B + 192 * h;
+#pragma unroll
+      for (int s8 = 0; s8 < 24; ++s8) {
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(dhi + aoff + 8 * s8);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(dlo + aoff + 8 * s8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, whi[s8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo[s8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, whi[s8], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h;
+        dht[rl * HP + col] += acc[i];
+      }
+    }
+    __syncthreads();
+  }
+  __shared__ float bsh[8][H];
+  *reinterpret_cast<float4*>(&bsh[rg][c4]) = bacc4;
+  __syncthreads();
+  if (tid < H) {
+    float sb = 0.f;
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) sb += bsh[r8][tid];
+    a.slab_bhn[(long)(block0 + blockIdx.x) * H + tid] = sb;
+  }
+}
+
 // Y[R][N] = act(X[R][F] @ W[F][N] + b) for small F (actor pre-torso, torsos.py:36-47)
 __global__ void k_small_linear(const float* __restrict__ X, int ldx, int F, const float* __restrict__ W, const float* __restrict__ b,
                                float* __restrict__ Y, int ldy, int N, long R, int relu) {
@@ -403,6 +674,19 @@ __global__ __launch_bounds__(256) void k_small_linear128(const float* __restrict
 
 using namespace magpo;
 
+// A/B switch of the training scans: 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA.  Default from MAGPO_GRU_SPLIT_BF16 (read once);
+// magpo_gru_set_split_bf16 overrides it (returns the previous mode) so that the parity tests can compare both in one process.
+static int g_gru_split = -1;
+static int gru_split_mode() {
+  if (g_gru_split < 0) { const char* e = getenv("MAGPO_GRU_SPLIT_BF16"); g_gru_split = e ? (atoi(e) != 0) : GRU_SPLIT_DEFAULT; }
+  return g_gru_split;
+}
+extern "C" int magpo_gru_set_split_bf16(int on) {
+  const int prev = gru_split_mode();
+  g_gru_split = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                                   const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
                                   const int* xi_cls, hipStream_t st) {
@@ -411,7 +695,17 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
   const size_t lds = (size_t)64 * T * (xi_cls ? 5 : 1);   // reset flags (+ xi class rows) of the block's rows
   if (lds > (xi_cls ? 80 : 24) * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS tables"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
-  if (hs && gates && hprev) {
+  const bool split = gru_split_mode() != 0;
+  if (hs && gates && hprev && split && T > 1) {   // training scan on split-bf16 x3 MFMA (see k_gru_scan_fwd_bf3)
+    static size_t lf_set = 0;
+    if (lds > lf_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      lf_set = lds;
+    }
+    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<true>), dim3(nfull), dim3(256), lds, st, a, 0);
+    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<false>), dim3(1), dim3(256), lds, st, a, nfull);
+  } else if (hs && gates && hprev) {
     if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 0>), dim3(nfull), dim3(256), lds, st, a, 0);
     if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 0>), dim3(1), dim3(256), lds, st, a, nfull);
   } else {
@@ -451,6 +745,18 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
     lds_set = lds;
   }
   const int nfull = a.NR / 64;
+  if (gru_split_mode() != 0) {   // split-bf16 x3 MFMA (k_gru_scan_bwd_bf3): fp32 dht + two bf16 dhh tiles + flags
+    const size_t ldb = (size_t)64 * HP * sizeof(float) + (size_t)2 * 64 * G3B * sizeof(__bf16) + (size_t)64 * T;
+    static size_t ldb_set = 0;
+    if (ldb > ldb_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd_bf3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd_bf3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb);
+      ldb_set = ldb;
+    }
+    if (nfull) hipLaunchKernelGGL(k_gru_scan_bwd_bf3<true>, dim3(nfull), dim3(256), ldb, st, a, 0);
+    if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_bwd_bf3<false>, dim3(1), dim3(256), ldb, st, a, nfull);
+    return check_launch("magpo_gru_scan_bwd");
+  }
   if (nfull) hipLaunchKernelGGL(k_gru_scan_bwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
   if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_bwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_scan_bwd");

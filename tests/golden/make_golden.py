@@ -15,6 +15,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import coordsum as ocs  # noqa: E402
+from oracle import lbf as olbf  # noqa: E402
+from oracle import rware as orw  # noqa: E402
 from oracle import learner as olearn  # noqa: E402
 from oracle import networks as onets  # noqa: E402
 from oracle import prng as oprng  # noqa: E402
@@ -51,6 +53,33 @@ def env_fixture():
     np.savez_compressed(os.path.join(OUT, "coordsum.npz"), cfg=np.array([4, 20, 12, 60]), env_keys=keys, actions=np.stack(acts),
                         reward=np.stack(rews), obs_target=np.stack(obs), done=np.stack(dones), episode_return=np.stack(rets),
                         final_target=st["target"], final_record=st["record"], final_key=st["key"])
+
+
+def _legal_actions(rng, mask, prefer):
+    n, a, k = mask.shape
+    out = np.zeros((n, a), np.int32)
+    for i in range(n):
+        for j in range(a):
+            out[i, j] = prefer if (mask[i, j, prefer] and rng.random() < 0.6) else rng.choice(np.nonzero(mask[i, j])[0])
+    return out
+
+
+def grid_env_fixtures():
+    """Level-Based Foraging and Robot Warehouse episodes (UNPINNED dynamics: these vectors pin the restatement, not Jumanji)."""
+    for name, mod, spec, cfg, prefer in (("lbf", olbf, olbf.LbfSpec(8, 8, 2, 2, 2, True, 20), [8, 8, 2, 2, 2, 1, 20], 5),
+                                         ("rware", orw, orw.RwareSpec(8, 1, 3, 4, 1, 4, 25), [8, 1, 3, 4, 1, 4, 25], 1)):
+        keys = oprng.split(oprng.prng_key(11), 6)
+        st, ts = mod.reset(spec, keys)
+        rng = np.random.default_rng(9)
+        acts, rews, dones, rets, obs0 = [], [], [], [], ts["observation"]["agents_view"].copy()
+        for _ in range(60):
+            a = _legal_actions(rng, ts["observation"]["action_mask"], prefer)
+            st, ts = mod.step(spec, st, a)
+            acts.append(a); rews.append(ts["reward"][:, 0].copy()); dones.append(ts["step_type"] == 2)
+            rets.append(ts["episode_metrics"]["episode_return"].copy())
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), cfg=np.array(cfg), env_keys=keys, obs0=obs0, actions=np.stack(acts),
+                            reward=np.stack(rews), done=np.stack(dones), episode_return=np.stack(rets),
+                            final_obs=ts["observation"]["agents_view"], final_mask=ts["observation"]["action_mask"], final_key=st["key"])
 
 
 N_STEPS = 3   # consecutive update steps: from step 2 on the rollout starts from non-zero retention states, so the
@@ -91,5 +120,6 @@ if __name__ == "__main__":
     torch.set_num_threads(1)  # bit-stable reductions
     prng_fixture()
     env_fixture()
+    grid_env_fixtures()
     learner_fixture()
     print("golden fixtures written to", OUT)

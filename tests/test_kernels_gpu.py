@@ -411,7 +411,18 @@ def test_retention_recurrent(L, stream):
     assert r2.reshape(N, A, 64)[:, :2].abs().max().item() == 0 and r2.reshape(N, A, 64)[:, 3].abs().max().item() == 0
 
 
-def test_gru_scan(L, stream):
+@pytest.mark.parametrize("split", [0, 1])
+def test_gru_scan(L, stream, split):
+    """split = 1: the training scans on split-bf16 x3 MFMA (products hi*hi + hi*lo + lo*hi, ~2^-16 relative) instead of fp32 MFMA:
+    same tolerances against the fp64 oracle."""
+    prev = L.call("magpo_gru_set_split_bf16", split)
+    try:
+        _gru_scan_case(L, stream)
+    finally:
+        L.call("magpo_gru_set_split_bf16", prev)
+
+
+def _gru_scan_case(L, stream):
     g = torch.Generator().manual_seed(7)
     nseq, T, A, F, K, H = 21, 9, 4, 5, 20, 128
     p = onets.init_actor_params(3, F, H, K, dtype=torch.float64)
