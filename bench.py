@@ -376,6 +376,7 @@ def main():
                        "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},
             "roofline": roof,
             "rollout_graph_ms_per_step": rollout_ms,
+            "hbm_resident_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),   # peak of torch's allocator on rank 0 (all buffers of the path)
             "kernel_table": table,
         }
         if world == 1 and not args.no_cpu_baseline:
