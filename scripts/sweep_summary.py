@@ -13,6 +13,8 @@ rows = {}
 for f in sorted(glob.glob(os.path.join(out, "json", "*", "metrics.json"))):
     tag = os.path.basename(os.path.dirname(f))
     scen, seed = tag.rsplit("_s", 1)
+    if len(sys.argv) > 2 and scen not in sys.argv[2:]:
+        continue
     d = json.load(open(f))
     run = next(iter(next(iter(next(iter(next(iter(d.values())).values())).values())).values()))
     steps = sorted((int(k.split("_")[1]), v) for k, v in run.items() if k.startswith("step_"))
