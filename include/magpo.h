@@ -168,9 +168,9 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
                                  magpo_stream_t stream);
 
 /* ---- K2 fused acting step: SableNetwork.get_actions (sable_network.py:443-482; decode.py:111-153) in ONE launch ----
- * dims_host[12] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F), maxval (class tables)}; kappa_host[4] (per head);
+ * dims_host[11] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F)}; kappa_host[4] (per head);
  * keys_host [A][2] sampling keys by value, or NULL with ptrs[3] = device key table (static arguments for graph replay);
- * ptrs_host[52] (the last four: first-layer class tables xn_tab [Ce][64], qkvg_tab [Ce][256], x_tab [Cd][64], qkvg1_tab [Cd][256], or NULLs): obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
+ * ptrs_host[48]: obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
  *   pe | S_enc S_d1 S_d2 ([n_block][n_head][N][64][64], updated in place) | scratch xn ([N*A] rows), done [N] u8 or NULL (envs whose
  *   episode just ended: their carried states read as zero, rec_magpo.py:164-169), scratch qkvg u y rep reppe hv ([N*A] rows) |
  *   xa kin1 y1 c cpe y2 xo xope hp hn logits ([N] rows) | u1 u2 ([N*A] rows) | prev [N][A] i32 | action [N][A] i32, logp, value [N][A];

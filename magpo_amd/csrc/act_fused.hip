@@ -47,10 +47,6 @@ struct ActArgs {
   float *xn; const unsigned char* done; float *qkvg, *u, *y, *rep, *reppe, *hv;    // scratch [N*A][64 | 256]  (used: xn, qkvg, u, rep); done [N] or NULL
   float *xa, *kin1, *y1, *c, *cpe, *y2, *xo, *xope, *hp, *hn, *logits, *u1, *u2; int* prev;   // unused by this kernel (table layout kept)
   int* action; float* logp; float* value;
-  // first-layer class tables (csrc/classtab.hip; nullable): rows of the DISTINCT wrapped-CoordSum inputs, recomputed from the current
-  // parameters once per rollout -- encoder token (agent, target, step) -> xn [Ce][64], q|k|v|g [Ce][256]; decoder block-0 token
-  // (previous action, step) -> x [Cd][64], q|k|v|g [Cd][256].  The kernel then reads a row instead of evaluating the layers.
-  const float *xn_tab, *qkvg_tab, *x_tab, *qkvg1_tab; int maxval;
 };
 
 #ifdef MAGPO_ACT_PROF
@@ -312,21 +308,6 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
     for (int t = 0; t < A; ++t) {
       const long row = ge * A + t;
       Row x;
-      if (b == 0 && a.qkvg_tab) {   // class-table path: this token is input class ((agent * maxval + target) * npos + step)
-        int g_ = (int)a.obs[row * a.ldo + A];
-        g_ = g_ < 0 ? 0 : (g_ >= a.maxval ? a.maxval - 1 : g_);
-        const long cls = ((long)t * a.maxval + g_) * a.npos + p_;
-        x = row_load(a.xn_tab + cls * AE, kq);
-        if (valid) row_store(a.xn + row * AE, kq, x);
-        const float* trow = a.qkvg_tab + cls * 256;
-        float* qrow = a.qkvg + row * 256;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const float4 v4 = ld4g(trow + 16 * g + 4 * kq);
-          if (valid) st4g(qrow + 16 * g + 4 * kq, v4);
-        }
-        continue;
-      }
       if (b == 0) {   // x = rms(gelu(rmsnorm_F(obs) * s_obs @ W_obs)) * s_encln   (sable_network.py:93-101,126,132)
         const float* o = a.obs + row * a.ldo;
         float ms = 0.f;
@@ -404,24 +385,10 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
     for (int b = 0; b < nb; ++b) {
       const ActBlk& B = a.blk[b];
       Row xin;
-      const bool tab1 = b == 0 && a.qkvg1_tab != nullptr;
-      const long clsd = (long)prev * a.npos + p_;
-      if (tab1) xin = row_load(a.x_tab + clsd * AE, kq);
-      else if (b == 0) xin = row_rms(row_gelu(row_load(a.W_act + (long)prev * AE, kq)), a.s_decln, kq);   // action embedding (:258-267)
+      if (b == 0) xin = row_rms(row_gelu(row_load(a.W_act + (long)prev * AE, kq)), a.s_decln, kq);   // action embedding (:258-267)
       else xin = xo;
       if (valid) row_store(XS + env * UP, kq, xin);
-      if (tab1) {   // q|k|v|g of this token from the (previous action, step) table
-        const float* trow = a.qkvg1_tab + clsd * 256;
-        float* hrow = B.qkvg1 + row * 256;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const float4 v4 = ld4g(trow + 16 * g + 4 * kq);
-          if (valid) {
-            *reinterpret_cast<float4*>(TQ + env * QP + 16 * g + 4 * kq) = v4;
-            if (g >= 4 && g < 12) st4g(hrow + 16 * g + 4 * kq, v4);
-          }
-        }
-      } else {
+      {
         const Row kin = row_add(xin, pe);
         float* hrow = B.qkvg1 + row * 256;
         wgemm<16>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
@@ -546,21 +513,21 @@ template <int EPW> static void launch_act(const ActArgs& a, hipStream_t st) {
 }
 
 // Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
-//   dims_host[12] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride, maxval}; kappa_host[4]; keys_host [A][2] or NULL (then
-//   ptrs[3] = device key table);  ptrs_host[52] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
+//   dims_host[11] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride}; kappa_host[4]; keys_host [A][2] or NULL (then
+//   ptrs[3] = device key table);  ptrs_host[48] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
 extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs,
                                int nptrs, const void* const* blk_ptrs, int nblk_ptrs, hipStream_t st) {
   ActArgs a;
   memset(&a, 0, sizeof(a));
   a.N = dims_host[0]; a.A = dims_host[1]; a.K = dims_host[2]; a.F = dims_host[3]; a.nb = dims_host[4]; a.nh = dims_host[5];
-  a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9]; a.ldo = dims_host[10]; a.maxval = dims_host[11];
+  a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9]; a.ldo = dims_host[10];
   if (a.N <= 0) return MAGPO_OK;
   if (a.A < 1 || a.A > MAXA || a.nb < 1 || a.nb > MAXB || a.nh < 1 || a.nh > 4 || a.K < 1 || a.K > 64 || a.F < 1 || a.hs * a.nh != AE ||
       a.gs < 4 || a.gs > a.hs || (a.gs & (a.gs - 1)) || a.npos < 1 || a.ldo < a.F) {
     set_error("magpo_sable_act: unsupported shape (1 <= A <= 8, n_block <= 4, n_head in {1,2,4}, K <= 64)");
     return MAGPO_EINVAL;
   }
-  if (nptrs != 52 || nblk_ptrs != 21 * a.nb) { set_error("magpo_sable_act: pointer table size mismatch"); return MAGPO_EINVAL; }
+  if (nptrs != 48 || nblk_ptrs != 21 * a.nb) { set_error("magpo_sable_act: pointer table size mismatch"); return MAGPO_EINVAL; }
   for (int i = 0; i < 4; ++i) a.kappa[i] = kappa_host[i];
   if (keys_host) for (int i = 0; i < a.A; ++i) { a.keys[i][0] = keys_host[2 * i]; a.keys[i][1] = keys_host[2 * i + 1]; }
   int p = 0;
@@ -575,12 +542,7 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   P(float*, xa) P(float*, kin1) P(float*, y1) P(float*, c) P(float*, cpe) P(float*, y2) P(float*, xo) P(float*, xope) P(float*, hp)
   P(float*, hn) P(float*, logits) P(float*, u1) P(float*, u2) P(int*, prev)
   P(int*, action) P(float*, logp) P(float*, value)
-  P(const float*, xn_tab) P(const float*, qkvg_tab) P(const float*, x_tab) P(const float*, qkvg1_tab)
 #undef P
-  if ((a.qkvg_tab != nullptr) != (a.xn_tab != nullptr) || (a.qkvg1_tab != nullptr) != (a.x_tab != nullptr) || (a.qkvg_tab && a.maxval < 1)) {
-    set_error("magpo_sable_act: class tables come in pairs (xn + qkvg, x + qkvg1) with maxval >= 1");
-    return MAGPO_EINVAL;
-  }
   if (!keys_host && !a.keys_dev && !a.value_only) { set_error("magpo_sable_act: no sampling keys"); return MAGPO_EINVAL; }
   for (int b = 0; b < a.nb; ++b) {
     const void* const* q = blk_ptrs + 21 * b;

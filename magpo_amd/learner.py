@@ -352,13 +352,7 @@ class MagpoLearner:
     use_graph = True  # replay the whole rollout as one HIP graph (removes ~11K host launches per rollout)
     batch_groups = True  # update_batch_size > 1: the minibatches of all local groups train as one batch of sequences
 
-    act_class_tables = True   # the acting kernel reads its first layers from the class tables too (rebuilt once per rollout)
-
     def rollout(self):
-        self._act_tabs = None
-        if self.class_tables and self.act_class_tables and self.fused_act and self.A <= 8:
-            c = self._class_rows()   # from the current parameters, shared by every group's rollout (they only read it)
-            self._act_tabs = self.guider.act_tables((c["obs_enc"], c["pos_enc"], c["prev_dec"], c["pos_dec"]))
         if len(self.groups) > 1 and self.use_graph and self.fused_act and self.A <= 8 and self.class_tables and self.batched_actor_carry \
                 and all(g.graph is not None for g in self.groups):
             # the groups' rollouts are independent: replay their graphs side by side (at small num_envs a rollout is a latency
@@ -441,8 +435,7 @@ class MagpoLearner:
         side = self._actor_stream if self.overlap_actor_step else None
         fused = self.fused_act
         gtag = str(self.groups.index(g))
-        tabs = getattr(self, "_act_tabs", None)
-        act = (lambda *a, **k: self.guider.act_fused(*a, tag=gtag, tables=tabs, maxval=getattr(self.env_cfg, "maxval", 0), **k)) if fused else self.guider.act
+        act = (lambda *a, **k: self.guider.act_fused(*a, tag=gtag, **k)) if fused else self.guider.act
 
         def zero_done(done):
             for k in range(self.nb):

@@ -302,26 +302,7 @@ class SableGuider:
             L.call("magpo_sample_categorical", logits, E, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
                    k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
 
-    def act_tables(self, rows):
-        """First-layer class tables for the acting kernel (csrc/classtab.hip): rows = (obs_enc [Ce,F], pos_enc [Ce], prev_dec [Cd],
-        pos_dec [Cd]) -> (xn [Ce,64], qkvg [Ce,256], x [Cd,64], qkvg1 [Cd,256]) from the CURRENT parameters.  The same layers as in
-        train_fwd's class path, in their own buffers (a rollout may replay while nothing else runs, but the training tables are
-        rebuilt per minibatch)."""
-        L, st, F, v, b = self.L, self._st(), self.F, self.v, self.b
-        obs_c, pos_c, prev_c, posd_c = rows
-        Ce, Cd = obs_c.shape[0], prev_c.shape[0]
-        xn, kin, qkvg = b.get("r_xn0", (Ce, E)), b.get("r_kin0", (Ce, E)), b.get("r_qkvg0", (Ce, 4 * E))
-        L.call("magpo_embed_fwd", 0, obs_c, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
-               self.pe, pos_c, 1, self.npos, None, 0, xn, E, kin, E, Ce, st)
-        self.lin(kin, E, self.wt["qkvg0"], None, qkvg, 4 * E, Ce, E, 4 * E)
-        x, xpe, qkvg1 = b.get("r_x0", (Cd, E)), b.get("r_xpe0", (Cd, E)), b.get("r_qkvg10", (Cd, 4 * E))
-        L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_c, 1, v["dec.ln.scale"], self.pe, posd_c, 1, self.npos,
-               None, 0, x, E, xpe, E, Cd, st)
-        self.lin(xpe, E, self.wt["qkvg10"], None, qkvg1, 4 * E, Cd, E, 4 * E)
-        return xn, qkvg, x, qkvg1
-
-    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag="",
-                  tables=None, maxval=0):
+    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag=""):
         """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a wave carries 8 envs
         through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64].  ``done`` [N] u8
         (optional): envs whose episode ended on the previous step -- their carried states are read as zero
@@ -329,8 +310,6 @@ class SableGuider:
         A, K, F, nb, nh = self.A, self.K, self.F, self.nb, self.nh
         if A > 8 and self.wide:
             raise NotImplementedError("wide observations (obs_dim > 32) with more than 8 agents")
-        if tables is not None and A > 8:
-            tables = None
         if A > 8:   # token staging registers of the fused kernel: larger teams take the kernel-by-kernel path
             if done is not None:
                 for k in range(nb):
@@ -345,7 +324,7 @@ class SableGuider:
         cache_key = (N, bool(value_only), obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
                      None if kdev is None else kdev.data_ptr(), s_enc.data_ptr(), s_d1.data_ptr(), s_d2.data_ptr(),
                      None if action_out is None else action_out.data_ptr(), None if logp_out is None else logp_out.data_ptr(),
-                     value_out.data_ptr(), None if done is None else done.data_ptr(), None if tables is None else tables[0].data_ptr())
+                     value_out.data_ptr(), None if done is None else done.data_ptr())
         tabs = self._act_tabs.get(cache_key)
         if tabs is None:
             g = lambda n, w=E, rows=R: b.get(f"f{tag}_" + n, (rows, w))   # scratch per caller tag (env groups may act concurrently)
@@ -358,8 +337,7 @@ class SableGuider:
                     g("xn"), done, g("qkvg", 4 * E), g("u"), g("y"), g("rep"), g("reppe"), g("hv"),
                     g("xa", E, N), g("kin1", E, N), g("y1", E, N), g("c", E, N), g("cpe", E, N), g("y2", E, N), g("xo", E, N),
                     g("xope", E, N), g("hp", E, N), g("hn", E, N), g("logits", E, N), g("u1"), g("u2"),
-                    b.get(f"f{tag}_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out,
-                    *(tables if tables is not None else (None, None, None, None))]
+                    b.get(f"f{tag}_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out]
             blk = []
             for k in range(nb):
                 e, d = f"enc.block{k}.", f"dec.block{k}."
@@ -368,7 +346,7 @@ class SableGuider:
                         self.wt[f"q2{k}"], self.wt[f"kvg2{k}"], self.wt[f"wo2{k}"], v[d + "ln2.scale"], v[d + "ln3.scale"],
                         v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
                         g(f"qkvg1_{k}", 4 * E), g(f"q2_{k}"), g(f"kvg2_{k}", 4 * E)]   # kvg2 rows: [k | v | - | P2] (ld 256)
-            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld, int(maxval)], dtype=np.int32),
+            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld], dtype=np.int32),
                     np.array((self.kappas + [0.0] * 4)[:4], dtype=np.float32),
                     np.array([ptr(t) for t in glob], dtype=np.uint64), np.array([ptr(t) for t in blk], dtype=np.uint64))
             if len(self._act_tabs) > 4096:
