@@ -554,10 +554,15 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
     B.gn2_g = (const float*)q[16]; B.gn2_b = (const float*)q[17];
     B.qkvg1 = (float*)q[18]; B.q2 = (float*)q[19]; B.kvg2 = (float*)q[20];
   }
-  // 16 envs per wave (full MFMA tiles, half the weight traffic) once that still gives every SIMD a wave; 8 below
-  int epw = a.N >= 16 * 4 * 256 ? 16 : 8;
-  if (const char* e = getenv("MAGPO_ACT_EPW")) epw = atoi(e) == 16 ? 16 : 8;
-  if (epw == 16) launch_act<16>(a, st); else launch_act<8>(a, st);
+  // envs per wave, measured per launch on MI355X (scripts/debug/act_epw.py; A = 4, one block: N = 1024 -> 273 / 309 / 355 us for 4 / 8 / 16
+  // envs per wave, N = 4096 -> 456 / 398 / 383, N = 16384 -> 1360 / 922 / 775; A = 8, two blocks: N = 1024 -> 1114 / 1363 / 1882,
+  // N = 4096 -> 1691 / 1679 / 2088, N = 16384 -> 5212 / 4905 / 3019): few envs per wave while the chip is not full (a rollout step is a
+  // latency chain per wave), full MFMA tiles and half the weight traffic once it is
+  int epw;
+  if (a.A <= 4) epw = a.N >= 4096 ? 16 : 4;
+  else epw = a.N >= 16384 ? 16 : (a.N >= 4096 ? 8 : 4);
+  if (const char* e = getenv("MAGPO_ACT_EPW")) { const int v = atoi(e); epw = v == 16 ? 16 : (v == 4 ? 4 : 8); }
+  if (epw == 16) launch_act<16>(a, st); else if (epw == 4) launch_act<4>(a, st); else launch_act<8>(a, st);
   return check_launch("magpo_sable_act");
 }
 
