@@ -151,15 +151,17 @@ int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, magpo_s
 int magpo_add_inplace(float* dst, const float* src, long n, magpo_stream_t stream);
 
 /* ---- K2/K7 retention (retention.py:66-115 chunkwise + recurrent, :117-213 decay matrix / xi) ---- */
+/* qkv_rows (nullable): q | k | v are row tables (block-0 projections exist once per distinct input row, csrc/classtab.hip) and token row r
+ * reads table row qkv_rows[r]; r, dr, dq, dk, dv are always per token row. */
 int magpo_retention_num_chunks(int T, int A);
 int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               float* r, long ldr, const float* s0, const int* seq_env,
                               const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
-                              int masked, float kappa, int hs, magpo_stream_t stream);
+                              int masked, float kappa, int hs, const int* qkv_rows, magpo_stream_t stream);
 int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
                               long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
-                              int masked, float kappa, int hs, magpo_stream_t stream);
+                              int masked, float kappa, int hs, const int* qkv_rows, magpo_stream_t stream);
 int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
                               int write_state, const float* gp, long ldg, const float* gamma, const float* beta,
@@ -183,13 +185,14 @@ int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_
  *   u = swish(g) * GroupNorm(r) ; y = u W_o ; o = rms(res + y) s1 [-> rms s2] ; ope = o + pe[pos] ; then the tail
  *   tail 1 (encoder): hv = o W0 + b0, value = rms(gelu(hv)) hs . hw + hb1, q2[k] = ope Wq2[k]   tail 2: out0 = ope W0 (192 columns)
  *   tail 3 (last decoder block): hp = o W0 + b0, hn = rms(gelu(hp)) hs, logits = hn W1 + b1 (K columns)   tail 0: none
- * dims_host[6] = {tail, K, npos, ldg, ld0, nq2}; ptrs_host[33] (device pointers): r gp gamma beta wo_t res s1 s2 pe pos | u y o ope |
- *   w0_t b0 out0 | hs hw hb1 value | q2_t[4] q2[4] | hn w1_t b1 logits   (o, ope, s2 and unused tail pointers may be NULL) */
+ * dims_host[6] = {tail, K, npos, ldg, ld0, nq2}; ptrs_host[34] (device pointers): r gp gamma beta wo_t res s1 s2 pe pos | u y o ope |
+ *   w0_t b0 out0 | hs hw hb1 value | q2_t[4] q2[4] | hn w1_t b1 logits | rows   (o, ope, s2, rows and unused tail pointers may be NULL;
+ *   with rows (i32 [R]) gp and res are row tables and token row r reads table row rows[r]) */
 int magpo_seg_post(const int* dims_host, long R, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
 
 /* backward of that front: dsum = d(res + y) through the RMSNorm(s), du = dsum W_o^T, (dr, dg) through GroupNorm + swish gate, and the
- * parameter-gradient rows (s1, s2, gamma, beta) as [magpo_seg_bwd_grid(R)][64] slabs.  ptrs_host[19]: a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta |
- * dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be   (y, s2, d1, d2, slab_s2 may be NULL) */
+ * parameter-gradient rows (s1, s2, gamma, beta) as [magpo_seg_bwd_grid(R)][64] slabs.  ptrs_host[20]: a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta |
+ * dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be | rows   (y, s2, d1, d2, slab_s2, rows may be NULL; with rows, a and gp are row tables) */
 int magpo_seg_bwd_grid(long R);
 int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
 

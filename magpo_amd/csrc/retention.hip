@@ -80,6 +80,19 @@ __device__ __forceinline__ void fetch_tile(TileRegs& t, const float* __restrict_
     t.v[j] = *reinterpret_cast<const float4*>(src + (long)r * ld + 4 * c4);
   }
 }
+// q | k | v read through a row table (csrc/classtab.hip: block-0 projections exist once per distinct input row; token row r
+// reads table row rows[r]): the four table rows a thread fetches for a tile are looked up ONE CHUNK AHEAD (RowIdx), so the index
+// load is never in front of the tile loads it feeds.
+struct RowIdx { int r[4]; };
+__device__ __forceinline__ void fetch_idx(RowIdx& x, const int* __restrict__ rows, long row0, int nvalid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x.r[j] = rows[row0 + min((int)(threadIdx.x >> 4) + 16 * j, nvalid - 1)];
+}
+__device__ __forceinline__ void fetch_tile_rows(TileRegs& t, const float* __restrict__ tab, long ld, const RowIdx& x, int w4) {
+  const int c4 = min((int)(threadIdx.x & 15), w4 - 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t.v[j] = *reinterpret_cast<const float4*>(tab + (long)x.r[j] * ld + 4 * c4);
+}
 __device__ __forceinline__ void fetch_state(TileRegs& t, const float* __restrict__ src) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -242,6 +255,7 @@ struct RetArgs {
   float* states;              // [nseq][nch][64][64] chunk-entry states (nullable in fwd)
   float* s_final;             // [nseq][64][64] state after the last chunk (nullable)
   int T, A, masked; float kappa; int hs;   // hs = head width (<= 64): tiles are zero-padded to 64 columns on chip
+  const int* rows;            // nullable: q | k | v are row tables, token row r reads table row rows[r]
 };
 
 __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
@@ -264,11 +278,20 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
   if (tid < 66) sm.kpow[tid] = powf(a.kappa, (float)tid);   // (visible after the first barrier inside build_meta)
   if (pre) build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, 0, nch);
   TileRegs pq, pk, pv;
+  RowIdx ri;                          // table rows of the tile fetched next
+  const bool by_rows = a.rows != nullptr;
+#define RET_FETCH(T_, P_, LD_, ROW0_, NV_) \
+  do { if (by_rows) fetch_tile_rows(T_, a.P_, a.LD_, ri, w4); else fetch_tile(T_, a.P_ + (ROW0_) * a.LD_, a.LD_, NV_, w4); } while (0)
   {
     const int nv0 = min(Lt, a.T) * a.A;
-    fetch_tile(pq, a.q + row_base * a.ldq, a.ldq, nv0, w4);
-    fetch_tile(pk, a.k + row_base * a.ldk, a.ldk, nv0, w4);
-    fetch_tile(pv, a.v + row_base * a.ldv, a.ldv, nv0, w4);
+    if (by_rows) fetch_idx(ri, a.rows, row_base, nv0);
+    RET_FETCH(pq, q, ldq, row_base, nv0);
+    RET_FETCH(pk, k, ldk, row_base, nv0);
+    RET_FETCH(pv, v, ldv, row_base, nv0);
+    if (by_rows) {   // chunk 1 (or chunk 0 again when it is the only one)
+      const int c1 = min(1, nch - 1);
+      fetch_idx(ri, a.rows, row_base + (long)c1 * L, min(Lt, a.T - c1 * Lt) * a.A);
+    }
   }
   for (int c = 0; c < nch; ++c) {
     const int t0 = c * Lt;
@@ -287,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
     const bool more = c + 1 < nch;
     const int nvn = more ? min(Lt, a.T - (t0 + Lt)) * a.A : nvalid;
     const long rn = more ? r0 + L : r0;
-    fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
+    RET_FETCH(pq, q, ldq, rn, nvn);
     if (a.states) store_state(a.states + ((long)seq * nch + c) * 4096, Ss);
 
     f32x16 sc, o;
@@ -308,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
       sc[i] *= lm.w[i];
     }
     __syncthreads();  // everyone done reading Qs
-    fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
+    RET_FETCH(pk, k, ldk, rn, nvn);
 #pragma unroll
     for (int i = 0; i < 16; ++i) Qs[(32 * wr + acc_row(i, h)) * TL + 32 * wc + lr] = sc[i];
     __syncthreads();
@@ -322,7 +345,11 @@ __global__ __launch_bounds__(256, 2) void k_ret_chunk_fwd(RetArgs a) {
       for (int i = 0; i < 16; ++i) ov[i] = o[i];
       store_acc_rows(a.r, r0, a.ldr, ov, full, nvalid, a.hs, wr, wc, lr, h, g_ret_trash);
     }
-    fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
+    RET_FETCH(pv, v, ldv, rn, nvn);
+    if (by_rows) {   // rows of the chunk after the next one (the last chunk re-reads itself)
+      const int c2 = min(c + 2, nch - 1);
+      fetch_idx(ri, a.rows, row_base + (long)c2 * L, min(Lt, a.T - c2 * Lt) * a.A);
+    }
     // state update  S <- gamma S + (eta K)^T V
     f32x16 sn;
     const float gm = meta.gamma;
@@ -346,6 +373,7 @@ struct RetBwdArgs {
   const unsigned char* dones;
   const float* states;  // [nseq][nch][64][64] from the forward
   int T, A, masked; float kappa; int hs;
+  const int* rows;      // nullable: as in RetArgs (q | k | v only; dr / dq / dk / dv are per token row)
 };
 
 #ifdef MAGPO_RET_PROF
@@ -383,13 +411,20 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
   if (pre) build_meta(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, a.kappa, 0, nch);
   RP_DECL();
   TileRegs pq, pk, pv, pd, ps;
+  RowIdx ri;                          // table rows of the q | k | v tiles fetched next
+  const bool by_rows = a.rows != nullptr;
   {
     const int cl = nch - 1;
     const int nvl = min(Lt, a.T - cl * Lt) * a.A;
     const long rl = row_base + (long)cl * L;
-    fetch_tile(pq, a.q + rl * a.ldq, a.ldq, nvl, w4);
-    fetch_tile(pk, a.k + rl * a.ldk, a.ldk, nvl, w4);
-    fetch_tile(pv, a.v + rl * a.ldv, a.ldv, nvl, w4);
+    if (by_rows) fetch_idx(ri, a.rows, rl, nvl);
+    RET_FETCH(pq, q, ldq, rl, nvl);
+    RET_FETCH(pk, k, ldk, rl, nvl);
+    RET_FETCH(pv, v, ldv, rl, nvl);
+    if (by_rows) {   // the chunk before (chunk 0 re-reads itself)
+      const int cp = max(cl - 1, 0);
+      fetch_idx(ri, a.rows, row_base + (long)cp * L, min(Lt, a.T - cp * Lt) * a.A);
+    }
     fetch_tile(pd, a.dr + rl * a.lddr, a.lddr, nvl, w4);
     fetch_state(ps, a.states + ((long)seq * nch + cl) * 4096);
   }
@@ -414,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
     // instruction stream while the memory pipeline back-pressures
     const long rn = c > 0 ? r0 - L : r0;
     const int nvn = c > 0 ? L : nvalid;
-    fetch_tile(pq, a.q + rn * a.ldq, a.ldq, nvn, w4);
+    RET_FETCH(pq, q, ldq, rn, nvn);
 
     RP(0);
     LaneMeta lm;
@@ -438,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       }
     }
     __syncthreads();
-    fetch_tile(pk, a.k + rn * a.ldk, a.ldk, nvn, w4);
+    RET_FETCH(pk, k, ldk, rn, nvn);
     RP(1);
     // dQ = dP K + beta * (dO S_c^T)
     {
@@ -454,7 +489,11 @@ __global__ __launch_bounds__(256, 1) void k_ret_chunk_bwd(RetBwdArgs a) {
       for (int i = 0; i < 16; ++i) ov[i] = acc1[i] + lm.beta[i] * acc2[i];
       store_acc_rows(a.dq, r0, a.lddq, ov, full, nvalid, a.hs, wr, wc, lr, h, g_ret_trash);
     }
-    fetch_tile(pv, a.v + rn * a.ldv, a.ldv, nvn, w4);
+    RET_FETCH(pv, v, ldv, rn, nvn);
+    if (by_rows) {
+      const int cp = max(c - 2, 0);
+      fetch_idx(ri, a.rows, row_base + (long)cp * L, min(Lt, a.T - cp * Lt) * a.A);
+    }
     RP(2);
     // dK = dP^T Q + eta * (V G^T)
     {
@@ -613,10 +652,10 @@ extern "C" int magpo_retention_num_chunks(int T, int A) { int Lt = 64 / A; retur
 extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          float* r, long ldr, const float* s0, const int* seq_env,
                                          const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
-                                         int masked, float kappa, int hs, hipStream_t st) {
+                                         int masked, float kappa, int hs, const int* qkv_rows, hipStream_t st) {
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
-  RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs};
+  RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs, qkv_rows};
   size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(SeqMeta<FWD_MAXC>);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
@@ -627,10 +666,10 @@ extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* 
 extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
                                          long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
-                                         int masked, float kappa, int hs, hipStream_t st) {
+                                         int masked, float kappa, int hs, const int* qkv_rows, hipStream_t st) {
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
-  RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs};
+  RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs, qkv_rows};
   size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(SeqMeta<BWD_MAXC>);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }

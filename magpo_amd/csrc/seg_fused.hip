@@ -25,6 +25,7 @@ struct SegArgs {
   const float* hs; const float* hw; const float* hb1; float* value;   // ENC: head norm scale, value weights / bias
   const float* q2_t[4]; float* q2[4]; int nq2;                        // ENC: cross-retention queries of every decoder block
   float* hn; const float* w1_t; const float* b1; float* logits;       // DEC2: head
+  const int* rows;   // nullable: gp and res are row tables (csrc/classtab.hip), token row r reads table row rows[r]
 };
 
 __device__ __forceinline__ Row row_rms_reg(const Row& x, const Row& s) {
@@ -108,9 +109,10 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
     p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
     return row_load(a.pe + (long)p * AE, kq);
   };
+  auto src_row = [&](long row) { return a.rows ? (long)a.rows[row] : row; };   // an index load a whole tile ahead, like pe_row's
   {
-    const long row = rowc(tile);
-    nr = row_load(a.r + row * AE, kq); ng = row_load(a.gp + row * a.ldg, kq); nres = row_load(a.res + row * AE, kq);
+    const long row = rowc(tile), src = src_row(row);
+    nr = row_load(a.r + row * AE, kq); ng = row_load(a.gp + src * a.ldg, kq); nres = row_load(a.res + src * AE, kq);
     if (want_pe) npe = pe_row(row);
   }
   for (; tile < ntiles; tile += gridDim.x) {
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
     const long rw = min(row, a.R - 1);
     const Row r = nr, g = ng, res = nres, per = npe;
     {
-      const long nrow = rowc(min(tile + (long)gridDim.x, ntiles - 1));
-      nr = row_load(a.r + nrow * AE, kq); ng = row_load(a.gp + nrow * a.ldg, kq); nres = row_load(a.res + nrow * AE, kq);
+      const long nrow = rowc(min(tile + (long)gridDim.x, ntiles - 1)), nsrc = src_row(nrow);
+      nr = row_load(a.r + nrow * AE, kq); ng = row_load(a.gp + nsrc * a.ldg, kq); nres = row_load(a.res + nsrc * AE, kq);
       if (want_pe) npe = pe_row(nrow);   // position -> table row: two dependent loads, issued a whole tile ahead
     }
     // GroupNorm over the whole 64-wide row (n_head = 1) and the swish gate
@@ -203,6 +205,7 @@ struct SegBwdArgs {
   const float* r; const float* gp; long ldg; const float* gamma; const float* beta;
   float* dsum; float* dr; float* dgp; long lddg;
   float* slab_s1; float* slab_s2; float* slab_ga; float* slab_be;   // [grid][64]
+  const int* rows;   // nullable: a and gp are row tables, token row r reads table row rows[r]
 };
 
 __global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
@@ -219,13 +222,14 @@ __global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
   auto rowc = [&](long tile) { return min(tile * 16 + m, a.R - 1); };
   Row na, ny, nd, nd1, nd2, nr, ng;   // next tile's rows: loads only here (the sums are formed when the tile is used)
   auto fetch = [&](long row) {
-    na = row_load(a.a + row * AE, kq);
+    const long src = a.rows ? (long)a.rows[row] : row;
+    na = row_load(a.a + src * AE, kq);
     if (a.y) ny = row_load(a.y + row * AE, kq);
     nd = row_load(a.d0 + row * AE, kq);
     if (a.d1) nd1 = row_load(a.d1 + row * AE, kq);
     if (a.d2) nd2 = row_load(a.d2 + row * AE, kq);
     nr = row_load(a.r + row * AE, kq);
-    ng = row_load(a.gp + row * a.ldg, kq);
+    ng = row_load(a.gp + src * a.ldg, kq);
   };
   long tile = blockIdx.x;
   fetch(rowc(tile));
@@ -318,11 +322,11 @@ __global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
 
 using namespace magpo;
 
-// ptrs_host (device pointers, host array of 33): r gp gamma beta wo_t res s1 s2 pe pos | u y o ope | w0_t b0 out0 | hs hw hb1 value |
-//   q2_t[0..3] q2[0..3] | hn w1_t b1 logits.   dims_host[6] = {tail, K, npos, ldg, ld0, nq2}.
+// ptrs_host (device pointers, host array of 34): r gp gamma beta wo_t res s1 s2 pe pos | u y o ope | w0_t b0 out0 | hs hw hb1 value |
+//   q2_t[0..3] q2[0..3] | hn w1_t b1 logits | rows (NULL, or gp / res are row tables read through rows[r]).   dims_host[6] = {tail, K, npos, ldg, ld0, nq2}.
 extern "C" int magpo_seg_post(const int* dims_host, long R, const void* const* p, int nptrs, hipStream_t st) {
   if (R <= 0) return MAGPO_OK;
-  if (nptrs != 33) { set_error("magpo_seg_post: pointer table size mismatch"); return MAGPO_EINVAL; }
+  if (nptrs != 34) { set_error("magpo_seg_post: pointer table size mismatch"); return MAGPO_EINVAL; }
   SegArgs a;
   a.tail = dims_host[0]; a.K = dims_host[1]; a.npos = dims_host[2]; a.ldg = dims_host[3]; a.ld0 = dims_host[4]; a.nq2 = dims_host[5];
   a.R = R;
@@ -337,6 +341,7 @@ extern "C" int magpo_seg_post(const int* dims_host, long R, const void* const* p
   for (int k = 0; k < 4; ++k) a.q2_t[k] = (const float*)p[i++];
   for (int k = 0; k < 4; ++k) a.q2[k] = (float*)p[i++];
   a.hn = (float*)p[i++]; a.w1_t = (const float*)p[i++]; a.b1 = (const float*)p[i++]; a.logits = (float*)p[i++];
+  a.rows = (const int*)p[i++];
   const long ntiles = (R + 15) / 16;
   long grid = 256 * 4;   // one wave per SIMD (the weights of the segment live in its registers)
   if (grid > ntiles) grid = ntiles;
@@ -352,11 +357,11 @@ extern "C" int magpo_seg_post(const int* dims_host, long R, const void* const* p
 // Number of slab rows magpo_seg_bwd writes for R rows (= its grid size).
 extern "C" int magpo_seg_bwd_grid(long R) { const long nt = (R + 15) / 16; return (int)(nt < 1024 ? (nt < 1 ? 1 : nt) : 1024); }
 
-// ptrs_host[19] (device pointers): a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta | dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be
-// (y, s2, d1, d2, slab_s2 may be NULL); ldg / lddg: row strides of gp / dgp.  Slabs: [magpo_seg_bwd_grid(R)][64].
+// ptrs_host[20] (device pointers): a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta | dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be | rows
+// (y, s2, d1, d2, slab_s2, rows may be NULL; with rows, a and gp are row tables read through rows[r]); ldg / lddg: row strides of gp / dgp.  Slabs: [magpo_seg_bwd_grid(R)][64].
 extern "C" int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* p, int nptrs, hipStream_t st) {
   if (R <= 0) return MAGPO_OK;
-  if (nptrs != 19) { set_error("magpo_seg_bwd: pointer table size mismatch"); return MAGPO_EINVAL; }
+  if (nptrs != 20) { set_error("magpo_seg_bwd: pointer table size mismatch"); return MAGPO_EINVAL; }
   SegBwdArgs a;
   a.R = R; a.ldg = ldg; a.lddg = lddg;
   int i = 0;
@@ -365,6 +370,7 @@ extern "C" int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* p, 
   a.r = (const float*)p[i++]; a.gp = (const float*)p[i++]; a.gamma = (const float*)p[i++]; a.beta = (const float*)p[i++];
   a.dsum = (float*)p[i++]; a.dr = (float*)p[i++]; a.dgp = (float*)p[i++];
   a.slab_s1 = (float*)p[i++]; a.slab_s2 = (float*)p[i++]; a.slab_ga = (float*)p[i++]; a.slab_be = (float*)p[i++];
+  a.rows = (const int*)p[i++];
   hipLaunchKernelGGL(k_seg_bwd, dim3((unsigned)magpo_seg_bwd_grid(R)), dim3(64), 0, st, a);
   return check_launch("magpo_seg_bwd");
 }

@@ -191,21 +191,22 @@ class SableGuider:
             self.L.call("magpo_retention_recurrent", S[h], q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, env_rows, u[:, o:], ldu, N, ntok,
                         ret_from, self.kappas[h], write, gp[:, o:], ldg, gamma, beta, hs, self.gs, self._st())
 
-    def _ret_fwd(self, q, ldq, k, ldk, v, ldv, r, s0, seq_env, dones, name, nseq, T, masked):
+    def _ret_fwd(self, q, ldq, k, ldk, v, ldv, r, s0, seq_env, dones, name, nseq, T, masked, rows=None):
+        """``rows`` (i32 [R], optional): q | k | v are row tables and token row r reads table row rows[r] (csrc/classtab.hip)."""
         nch = self.L.call("magpo_retention_num_chunks", T, self.A)
         hs = self.hs
         for h in range(self.nh):
             o = h * hs
             stt = self.b.get(f"t_{name}_{h}", (nseq, nch, E, E))
             self.L.call("magpo_retention_chunk_fwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, r[:, o:], E, s0[h], seq_env, dones, stt,
-                        None, nseq, T, self.A, masked, self.kappas[h], hs, self._st())
+                        None, nseq, T, self.A, masked, self.kappas[h], hs, rows, self._st())
 
-    def _ret_bwd(self, q, ldq, k, ldk, v, ldv, dr, dq, lddq, dk, lddk, dv, lddv, dones, name, nseq, T, masked):
+    def _ret_bwd(self, q, ldq, k, ldk, v, ldv, dr, dq, lddq, dk, lddk, dv, lddv, dones, name, nseq, T, masked, rows=None):
         hs = self.hs
         for h in range(self.nh):
             o = h * hs
             self.L.call("magpo_retention_chunk_bwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, dr[:, o:], E, dq[:, o:], lddq, dk[:, o:],
-                        lddk, dv[:, o:], lddv, dones, self.b.t[f"t_{name}_{h}"], nseq, T, self.A, masked, self.kappas[h], hs, self._st())
+                        lddk, dv[:, o:], lddv, dones, self.b.t[f"t_{name}_{h}"], nseq, T, self.A, masked, self.kappas[h], hs, rows, self._st())
 
     def _retpost_fwd(self, r, gp, ldg, gamma, beta, u, R):
         self.L.call("magpo_retpost_fwd", r, E, gp, ldg, gamma, beta, u, E, R, self.hs, self.gs, self._st())
@@ -360,11 +361,11 @@ class SableGuider:
                     gp.ctypes.data, int(gp.size), bp.ctypes.data, int(bp.size), self._st())
 
     def _seg_post(self, tail, r, gp, ldg, gamma, beta, wo_t, res, s1, s2, pos, u, y, o, ope, R, w0_t=None, b0=None, out0=None, ld0=0,
-                  hs=None, hw=None, hb1=None, value=None, q2_t=(), q2=(), hn=None, w1_t=None, b1=None, logits=None):
+                  hs=None, hw=None, hb1=None, value=None, q2_t=(), q2=(), hn=None, w1_t=None, b1=None, logits=None, rows=None):
         """One fused launch for the token-local part between two retention ops (csrc/seg_fused.hip)."""
         ptr = lambda t: 0 if t is None else t.data_ptr()
         q2_t, q2 = list(q2_t) + [None] * (4 - len(q2_t)), list(q2) + [None] * (4 - len(q2))
-        tab = [r, gp, gamma, beta, wo_t, res, s1, s2, self.pe, pos, u, y, o, ope, w0_t, b0, out0, hs, hw, hb1, value, *q2_t, *q2, hn, w1_t, b1, logits]
+        tab = [r, gp, gamma, beta, wo_t, res, s1, s2, self.pe, pos, u, y, o, ope, w0_t, b0, out0, hs, hw, hb1, value, *q2_t, *q2, hn, w1_t, b1, logits, rows]
         key = (tail, R, tuple(ptr(t) for t in tab))
         ent = self._seg_tabs.get(key)
         if ent is None:
@@ -375,14 +376,14 @@ class SableGuider:
             self._seg_tabs[key] = ent
         self.L.call("magpo_seg_post", ent[0].ctypes.data, R, ent[1].ctypes.data, int(ent[1].size), self._st())
 
-    def _seg_bwd(self, a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, ldg, pfx, dsum, dr, dgp, lddg, R, g_s1, g_s2, acc_s1=False):
+    def _seg_bwd(self, a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, ldg, pfx, dsum, dr, dgp, lddg, R, g_s1, g_s2, acc_s1=False, rows=None):
         """Backward of the front of a post-retention segment in one launch (csrc/seg_fused.hip: k_seg_bwd): d(res + y) through the
         RMSNorm(s), dsum W_o^T, GroupNorm + gate backward, and the four parameter-gradient rows (reduced from per-wave slabs)."""
         v, gv, b = self.v, self.gv, self.b
         ptr = lambda t: 0 if t is None else t.data_ptr()
         G = self.L.call("magpo_seg_bwd_grid", R)
         sl = [b.get(f"sb_{i}", (G, E)) for i in range(4)]
-        tab = [a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, v[pfx + "gn.scale"], v[pfx + "gn.bias"], dsum, dr, dgp, sl[0], sl[1] if s2 is not None else None, sl[2], sl[3]]
+        tab = [a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, v[pfx + "gn.scale"], v[pfx + "gn.bias"], dsum, dr, dgp, sl[0], sl[1] if s2 is not None else None, sl[2], sl[3], rows]
         key = ("bwd", R, ldg, lddg, tuple(ptr(t) for t in tab))
         ent = self._seg_tabs.get(key)
         if ent is None:
@@ -407,7 +408,8 @@ class SableGuider:
         nch = L.call("magpo_retention_num_chunks", T, A)
         g = lambda n, w=E: b.get("t_" + n, (R, w))
         stt = lambda n: b.get("t_" + n, (nseq, nch, E, E))
-        self._saved = dict(obs=obs, prev_idx=prev_idx, pos=pos, dones=dones, nseq=nseq, T=T, R=R, classes=classes)
+        direct = classes is not None and self.fused_segments   # block-0 consumers read the class tables through the class index
+        self._saved = dict(obs=obs, prev_idx=prev_idx, pos=pos, dones=dones, nseq=nseq, T=T, R=R, classes=classes, direct=direct)
         rep, reppe, hv, value = g("rep"), g("reppe"), g("hv"), b.get("t_value", (R,))
         logits = b.get("t_logits", (R, E), zero=True)
         # ---- encoder
@@ -418,8 +420,9 @@ class SableGuider:
             L.call("magpo_embed_fwd", 0, obs_c, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
                    self.pe, pos_c, 1, self.npos, None, 0, xn_c, E, kin_c, E, Ce, st)
             self.lin(kin_c, E, self.wt["qkvg0"], None, qkvg_c, 4 * E, Ce, E, 4 * E)
-            L.call("magpo_gather_rows", xn_c, E, classes["enc"][0], g("xn0"), E, R, E, st)
-            L.call("magpo_gather_rows", qkvg_c, 4 * E, classes["enc"][0], g("qkvg0", 4 * E), 4 * E, R, 4 * E, st)
+            if not direct:   # per-token copies for the unfused segment kernels; the fused ones read the tables through the class index
+                L.call("magpo_gather_rows", xn_c, E, classes["enc"][0], g("xn0"), E, R, E, st)
+                L.call("magpo_gather_rows", qkvg_c, 4 * E, classes["enc"][0], g("qkvg0", 4 * E), 4 * E, R, 4 * E, st)
         elif self.wide:   # obs_encoder + ln on padded rows: RMSNorm_F -> Dense on the MFMA kernel -> GELU + RMSNorm (sable_network.py:93-101,132)
             on, z0 = b.get("t_on", (R, 128)), g("z0")
             L.call("magpo_obsnorm_fwd", obs, self.Fld, F, v["enc.obs.norm.scale"], on, R, st)
@@ -431,21 +434,26 @@ class SableGuider:
                    self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, st)   # z is recomputed by the backward
         for k in range(nb):
             e = f"enc.block{k}."
-            xn, qkvg, r, u, y = g(f"xn{k}"), g(f"qkvg{k}", 4 * E), g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
+            rows = classes["enc"][0] if direct and k == 0 else None
+            if rows is not None:
+                xn, qkvg = xn_c, qkvg_c
+            else:
+                xn, qkvg = g(f"xn{k}"), g(f"qkvg{k}", 4 * E)
+            r, u, y = g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
             if k > 0 or classes is None:
                 self.lin(g(f"kin{k}"), E, self.wt[f"qkvg{k}"], None, qkvg, 4 * E, R, E, 4 * E)
-            self._ret_fwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, s0[0][k], seq_env, dones, f"st_e{k}", nseq, T, 0)
+            self._ret_fwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, s0[0][k], seq_env, dones, f"st_e{k}", nseq, T, 0, rows=rows)
             if self.fused_segments and k == nb - 1:
                 # GroupNorm + gate, W_o, residual + norms, value head and the cross-retention queries of every decoder block: one launch
                 self._seg_post(1, r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], self.wt[f"wo{k}"], xn,
                                v[e + "ln1.scale"], v[e + "ln2.scale"], pos, u, y, rep, reppe, R, w0_t=self.wt["vh0"], b0=v["enc.head.dense0.bias"],
                                out0=hv, ld0=E, hs=v["enc.head.norm.scale"], hw=v["enc.head.dense1.kernel"], hb1=v["enc.head.dense1.bias"],
-                               value=value, q2_t=[self.wt[f"q2{j}"] for j in range(nb)], q2=[g(f"q2{j}") for j in range(nb)])
+                               value=value, q2_t=[self.wt[f"q2{j}"] for j in range(nb)], q2=[g(f"q2{j}") for j in range(nb)], rows=rows)
                 continue
             if self.fused_segments:
                 repb = g(f"repb{k}")
                 self._seg_post(0, r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], self.wt[f"wo{k}"], xn,
-                               v[e + "ln1.scale"], v[e + "ln2.scale"], pos, u, y, repb, None, R)
+                               v[e + "ln1.scale"], v[e + "ln2.scale"], pos, u, y, repb, None, R, rows=rows)
                 L.call("magpo_resnorm_fwd", repb, E, None, 0, v["enc.ln.scale"], None, self.pe, pos, 1, self.npos,
                        g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, st)
                 continue
@@ -471,23 +479,28 @@ class SableGuider:
             L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_c, 1, v["dec.ln.scale"], self.pe, posd_c, 1, self.npos,
                    None, 0, x_c, E, xpe_c, E, Cd, st)
             self.lin(xpe_c, E, self.wt["qkvg10"], None, qkvg1_c, 4 * E, Cd, E, 4 * E)
-            L.call("magpo_gather_rows", x_c, E, classes["dec"][0], g("x0"), E, R, E, st)
-            L.call("magpo_gather_rows", qkvg1_c, 4 * E, classes["dec"][0], g("qkvg10", 4 * E), 4 * E, R, 4 * E, st)
+            if not direct:
+                L.call("magpo_gather_rows", x_c, E, classes["dec"][0], g("x0"), E, R, E, st)
+                L.call("magpo_gather_rows", qkvg1_c, 4 * E, classes["dec"][0], g("qkvg10", 4 * E), 4 * E, R, 4 * E, st)
         else:
             L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_idx, 1, v["dec.ln.scale"], self.pe, pos, 1, self.npos,
                    None, 0, g("x0"), E, g("xpe0"), E, R, st)   # za = W_act[prev] is gathered again by the backward
         for k in range(nb):
             d = f"dec.block{k}."
-            x = g(f"x{k}")
-            qkvg1, r1, u1, y1 = g(f"qkvg1{k}", 4 * E), g(f"r1{k}"), g(f"u1{k}"), g(f"y1{k}")
+            rows = classes["dec"][0] if direct and k == 0 else None
+            if rows is not None:
+                x, qkvg1 = x_c, qkvg1_c
+            else:
+                x, qkvg1 = g(f"x{k}"), g(f"qkvg1{k}", 4 * E)
+            r1, u1, y1 = g(f"r1{k}"), g(f"u1{k}"), g(f"y1{k}")
             cpe, q2, kvg2, r2, u2, y2 = g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
             if k > 0 or classes is None:
                 self.lin(g(f"xpe{k}"), E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
-            self._ret_fwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, s0[1][k], seq_env, dones, f"st_1{k}", nseq, T, 1)
+            self._ret_fwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, s0[1][k], seq_env, dones, f"st_1{k}", nseq, T, 1, rows=rows)
             if self.fused_segments:
                 # after the self-retention: gate, W_o, residual + norm (+ pe) and the k | v | g projection of the cross-retention
                 self._seg_post(2, r1, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], self.wt[f"wo1{k}"], x,
-                               v[d + "ln1.scale"], None, pos, u1, y1, None, cpe, R, w0_t=self.wt[f"kvg2{k}"], out0=kvg2, ld0=3 * E)
+                               v[d + "ln1.scale"], None, pos, u1, y1, None, cpe, R, w0_t=self.wt[f"kvg2{k}"], out0=kvg2, ld0=3 * E, rows=rows)
                 self._ret_fwd(q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, s0[2][k], seq_env, dones, f"st_2{k}", nseq, T, 1)
                 if k == nb - 1:   # ... and after the cross-retention of the last block the logit head
                     self._seg_post(3, r2, kvg2[:, 2 * E:], 3 * E, v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"], self.wt[f"wo2{k}"], rep,
@@ -576,10 +589,11 @@ class SableGuider:
             # self-retention: c = rms(x_k + y1) * ln1
             dsum1 = g(f"dsum1_{k}")
             dr1 = g("dr"); dqkvg1 = g(f"dqkvg1_{k}", 4 * E)
-            qkvg1 = t(f"qkvg1{k}")
+            rows = cl["dec"][0] if sv["direct"] and k == 0 else None
+            qkvg1, xk = (b.t["c_qkvg10"], b.t["c_x0"]) if rows is not None else (t(f"qkvg1{k}"), t(f"x{k}"))
             if self.fused_segments:
-                self._seg_bwd(t(f"x{k}"), t(f"y1{k}"), v[d + "ln1.scale"], None, dcpe, None, None, v[d + "retn1.w_o"], t(f"r1{k}"),
-                              qkvg1[:, 3 * E:], 4 * E, d + "retn1.", dsum1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, gv[d + "ln1.scale"], None)
+                self._seg_bwd(xk, t(f"y1{k}"), v[d + "ln1.scale"], None, dcpe, None, None, v[d + "retn1.w_o"], t(f"r1{k}"),
+                              qkvg1[:, 3 * E:], 4 * E, d + "retn1.", dsum1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, gv[d + "ln1.scale"], None, rows=rows)
                 self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t(f"x{k}"), E, t(f"y1{k}"), E, v[d + "ln1.scale"], None, dcpe, E, None, 0, None, 0, dsum1, E,
@@ -590,7 +604,7 @@ class SableGuider:
                 self.lin(dsum1, E, v[d + "retn1.w_o"], None, du1, E, R, E, E)
                 self._retpost_bwd(t(f"r1{k}"), qkvg1[:, 3 * E:], 4 * E, d + "retn1.", du1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
             self._ret_bwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, dr1, dqkvg1, 4 * E, dqkvg1[:, E:], 4 * E,
-                          dqkvg1[:, 2 * E:], 4 * E, dones, f"st_1{k}", nseq, T, 1)
+                          dqkvg1[:, 2 * E:], 4 * E, dones, f"st_1{k}", nseq, T, 1, rows=rows)
             if k == 0 and cl is not None:   # block 0 on the class table: per-class sums of both gradient paths, then Cd rows
                 _, order, offsets = cl["dec"]
                 Cd = cl["rows"][2].shape[0]
@@ -629,10 +643,11 @@ class SableGuider:
             e = f"enc.block{k}."
             dsum0 = g(f"dsum0_{k}")
             dr = g("dr"); dqkvg = g(f"dqkvg_{k}", 4 * E)
-            qkvg = t(f"qkvg{k}")
+            rows = cl["enc"][0] if sv["direct"] and k == 0 else None
+            qkvg, xnk = (b.t["c_qkvg0"], b.t["c_xn0"]) if rows is not None else (t(f"qkvg{k}"), t(f"xn{k}"))
             if self.fused_segments:
-                self._seg_bwd(t(f"xn{k}"), t(f"y{k}"), v[e + "ln1.scale"], v[e + "ln2.scale"], e0, e1, e2, v[e + "retn.w_o"], t(f"r{k}"),
-                              qkvg[:, 3 * E:], 4 * E, e + "retn.", dsum0, dr, dqkvg[:, 3 * E:], 4 * E, R, gv[e + "ln1.scale"], gv[e + "ln2.scale"])
+                self._seg_bwd(xnk, t(f"y{k}"), v[e + "ln1.scale"], v[e + "ln2.scale"], e0, e1, e2, v[e + "retn.w_o"], t(f"r{k}"),
+                              qkvg[:, 3 * E:], 4 * E, e + "retn.", dsum0, dr, dqkvg[:, 3 * E:], 4 * E, R, gv[e + "ln1.scale"], gv[e + "ln2.scale"], rows=rows)
                 self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t(f"xn{k}"), E, t(f"y{k}"), E, v[e + "ln1.scale"], v[e + "ln2.scale"], e0, E, e1, E if e1 is not None else 0,
@@ -643,7 +658,7 @@ class SableGuider:
                 self.lin(dsum0, E, v[e + "retn.w_o"], None, du, E, R, E, E)
                 self._retpost_bwd(t(f"r{k}"), qkvg[:, 3 * E:], 4 * E, e + "retn.", du, dr, dqkvg[:, 3 * E:], 4 * E, R, slab("a"), slab("b"))
             self._ret_bwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, dr, dqkvg, 4 * E, dqkvg[:, E:], 4 * E, dqkvg[:, 2 * E:], 4 * E,
-                          dones, f"st_e{k}", nseq, T, 0)
+                          dones, f"st_e{k}", nseq, T, 0, rows=rows)
             if k == 0 and cl is not None:
                 _, order, offsets = cl["enc"]
                 obs_c = cl["rows"][0]

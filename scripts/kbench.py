@@ -40,9 +40,9 @@ if "ret" in which:
     dones = (torch.rand(nseq, T, device=dev, generator=g) < 0.01).to(torch.uint8)
     nch = L.call("magpo_retention_num_chunks", T, A)
     states = torch.empty(nseq, nch, 64, 64, device=dev); s0 = torch.zeros(nseq, 64, 64, device=dev)
-    timeit("ret_chunk_fwd", lambda: L.call("magpo_retention_chunk_fwd", q, 64, k, 64, v, 64, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.95, 64, st),
+    timeit("ret_chunk_fwd", lambda: L.call("magpo_retention_chunk_fwd", q, 64, k, 64, v, 64, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.95, 64, None, st),
            nseq * nch * 4 * 2.0 * 64 ** 3, 0)
-    timeit("ret_chunk_bwd", lambda: L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, st),
+    timeit("ret_chunk_bwd", lambda: L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, None, st),
            nseq * nch * 9 * 2.0 * 64 ** 3, 0)
 if "gru" in which:
     H = 128

@@ -15,14 +15,14 @@ nch = L.call("magpo_retention_num_chunks", T, A)
 states = torch.empty(nseq, nch, 64, 64, device=dev)
 s0 = torch.zeros(nseq, 64, 64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-L.call("magpo_retention_chunk_fwd", q, 64, k, 64, v, 64, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.95, 64, st)
+L.call("magpo_retention_chunk_fwd", q, 64, k, 64, v, 64, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.95, 64, None, st)
 fn = L.raw("magpo_debug_ret_prof"); out = np.zeros(8, dtype=np.uint64)
 for it in range(2):
-    L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, st)
+    L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, None, st)
 torch.cuda.synchronize(); fn(ctypes.c_void_p(out.ctypes.data), 1)
 t0 = time.time()
 for it in range(5):
-    L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, st)
+    L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, None, st)
 torch.cuda.synchronize(); t1 = time.time()
 fn(ctypes.c_void_p(out.ctypes.data), 1)
 tot = float(out[:6].sum())

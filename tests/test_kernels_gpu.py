@@ -366,13 +366,13 @@ def test_retention_chunk(L, stream, A, T, masked, hs):
     s0_store[perm.long(), :hs, :hs] = s0
     dn = dev(dones.to(torch.uint8))
     L.call("magpo_retention_chunk_fwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, r, 64, dev(s0_store), dev(perm),
-           dn, states, sfin, B, T, A, masked, kappa, hs, stream)
+           dn, states, sfin, B, T, A, masked, kappa, hs, None, stream)
     close(r[:, :hs].reshape(B, C, hs), ref, 1e-4, 1e-5, "ret fwd")
     if hs < 64:
         assert bool((r[:, hs:] == 7.0).all()), "columns of the neighbouring heads were written"
     dbuf = torch.full((B * C, 256), 9.0, device=DEV)
     L.call("magpo_retention_chunk_bwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, drb, 64,
-           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, stream)
+           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, None, stream)
     close(dbuf[:, 0:hs].reshape(B, C, hs), qd.grad, 1e-4, 1e-5, "dq")
     close(dbuf[:, 64:64 + hs].reshape(B, C, hs), kd.grad, 1e-4, 1e-5, "dk")
     close(dbuf[:, 128:128 + hs].reshape(B, C, hs), vd.grad, 1e-4, 1e-5, "dv")
@@ -388,6 +388,38 @@ def test_retention_chunk(L, stream, A, T, masked, hs):
         kt = k.double().reshape(B, T, A, hs)[:, t]; vt = v.double().reshape(B, T, A, hs)[:, t]
         S = kappa * S + kt.transpose(1, 2) @ vt
     close(sfin[:, :hs, :hs], S, 1e-4, 1e-5, "final state")
+
+
+@pytest.mark.parametrize("A,T,masked,hs", [(4, 128, 0, 64), (4, 40, 1, 64), (8, 128, 1, 64), (5, 30, 1, 64), (3, 70, 1, 16), (4, 8, 1, 64)])
+def test_retention_chunk_row_table(L, stream, A, T, masked, hs):
+    """q | k | v read through a row table (block-0 projections on the distinct input rows, csrc/classtab.hip) == the same rows
+    gathered per token first: outputs, saved chunk states and all three gradients bit-identical (forward and backward, one to many
+    chunks, ragged last chunk, narrow head)."""
+    g = torch.Generator().manual_seed(11)
+    B, kappa, C = 6, 0.775, T * A
+    R, NC = B * C, 97                                   # 97 distinct rows, every token row points at one of them
+    tab = dev(torch.randn(NC, 256, generator=g) * 0.5)
+    rows = dev(torch.randint(0, NC, (R,), generator=g).to(torch.int32))
+    buf = tab[rows.long()].contiguous()
+    drb = dev(torch.randn(R, 64, generator=g))
+    dones = torch.rand(B, T, generator=g) < 0.05
+    dn = dev(dones.to(torch.uint8))
+    s0 = dev(torch.randn(B, 64, 64, generator=g) * 0.3)
+    if hs < 64:
+        s0[:, hs:, :] = 0; s0[:, :, hs:] = 0
+    nch = L.call("magpo_retention_num_chunks", T, A)
+    out = []
+    for src, ridx in ((buf, None), (tab, rows)):
+        r = torch.full((R, 64), 7.0, device=DEV)
+        states = torch.zeros(B, nch, 64, 64, device=DEV); sfin = torch.zeros(B, 64, 64, device=DEV)
+        L.call("magpo_retention_chunk_fwd", src, 256, src[:, 64:], 256, src[:, 128:], 256, r, 64, s0, None, dn, states, sfin, B, T, A,
+               masked, kappa, hs, ridx, stream)
+        dbuf = torch.full((R, 256), 9.0, device=DEV)
+        L.call("magpo_retention_chunk_bwd", src, 256, src[:, 64:], 256, src[:, 128:], 256, drb, 64, dbuf, 256, dbuf[:, 64:], 256,
+               dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, ridx, stream)
+        out.append((r, states, sfin, dbuf))
+    for x, y, what in zip(out[0], out[1], ("ret", "chunk states", "final state", "dq | dk | dv")):
+        assert torch.equal(x, y), what
 
 
 def test_retention_recurrent(L, stream):
