@@ -206,6 +206,9 @@ int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, con
  * = hi*hi + hi*lo + lo*hi with fp32 accumulation, ~2^-16 relative per product).  Returns the previous mode; the default comes from
  * MAGPO_GRU_SPLIT_BF16. */
 int magpo_gru_set_split_bf16(int on);
+/* Recurrent rows per workgroup of the fp32 GRU scans: 0 = by size (32 when 64-row blocks would leave half of the compute units idle), or 32 / 64
+ * forced; returns the previous setting (not a status code). */
+int magpo_gru_set_block_rows(int rows);
 /* xi_cls (nullable): xi is a table over the distinct input rows and token row r takes xi[xi_cls[r]] (csrc/classtab.hip).
  * hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
 int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,

@@ -52,19 +52,21 @@ __device__ __forceinline__ long tok_row(int rho, int t, int T, int A) {
 
 // W_h^T fragments (3 gates x 128 k x 32 columns per wave = 192 VGPRs) stay in registers for the whole scan;
 // wave w owns hidden columns 32w..32w+31 for both 32-row halves.  One wave per SIMD (launch bound 1).
+// ROWS = 64 recurrent rows per workgroup, or 32 when 64-row blocks would leave compute units idle (NR / 64 < 256: the scan is a
+// latency chain of T steps, so half-size blocks on twice the CUs halve its time).
 // FULL = every one of the block's 64 rows is valid (all but the last block): loads and stores are then unconditional
 // straight-line code; a predicated access is an exec-masked block with its own wait and a per-element global flag load
 // sits on the step's critical path, so the reset flags of the block's rows are staged in LDS once.
 // MODE (compile-time, so that the training scan is branch-free with a constant row stride): 0 = training scan, h / gates /
 // h_prev of every step saved; 1 = time-major trajectory (rollout carry: rows (t, env, agent), only the last state is
 // written); 2 = any of the save buffers may be NULL (acting step)
-template <bool FULL, int MODE>
+template <bool FULL, int MODE, int ROWS>
 __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) {
   constexpr bool TM = MODE == 1;
-  __shared__ __align__(16) float hbuf[2][64 * HP];
-  extern __shared__ unsigned char rflag[];   // [64][T] reset-before-step flags of the block's rows, then (xi_cls) [64][T] int xi rows
+  __shared__ __align__(16) float hbuf[2][ROWS * HP];
+  extern __shared__ unsigned char rflag[];   // [ROWS][T] reset-before-step flags of the block's rows, then (xi_cls) [ROWS][T] int xi rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
-  const int rho0 = (block0 + blockIdx.x) * 64;
+  const int rho0 = (block0 + blockIdx.x) * ROWS;
   const int col = 32 * wave + lr;
   const int T = a.T;
   float4 wf[3][16];
@@ -73,24 +75,24 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
 #pragma unroll
     for (int u = 0; u < 16; ++u) wf[g][u] = *reinterpret_cast<const float4*>(a.Wht + ((long)g * H + col) * H + 64 * h + 4 * u);
   const float bhn = a.b_hn[col];
-  for (int i = tid; i < 64 * T; i += 256) {
+  for (int i = tid; i < ROWS * T; i += 256) {
     const int rl = i / T, t = i - rl * T;
     const int rho = min(rho0 + rl, a.NR - 1);
     rflag[i] = TM ? a.reset[(long)t * (a.NR / a.A) + rho / a.A] : a.reset[(long)(rho / a.A) * T + t];
   }
   // xi rows through the class table: the block's 64 x T class indices are staged once, like the flags (a dependent global
   // load per step would sit in front of every xi load)
-  int* ctab = reinterpret_cast<int*>(rflag + 64 * T);
+  int* ctab = reinterpret_cast<int*>(rflag + ROWS * T);
   const bool by_cls = a.xi_cls != nullptr;
   if (by_cls) {
-    for (int i = tid; i < 64 * T; i += 256) {
+    for (int i = tid; i < ROWS * T; i += 256) {
       const int rl = i / T, t = i - rl * T;
       const int rho = min(rho0 + rl, a.NR - 1);
       ctab[i] = a.xi_cls[TM ? (long)t * a.NR + rho : tok_row(rho, t, T, a.A)];
     }
   }
   // initial carry (with the reset of step 0 applied)
-  for (int i = tid; i < 64 * (H / 4); i += 256) {
+  for (int i = tid; i < ROWS * (H / 4); i += 256) {
     int r = i / (H / 4), c4 = i - r * (H / 4);
     int rho = rho0 + r;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -104,8 +106,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
     *reinterpret_cast<float4*>(&hbuf[0][r * HP + 4 * c4]) = v;
   }
   // per-row bookkeeping (no integer division inside the scan): token row of step 0 (invalid rows shadow the last valid one)
-  __shared__ long rbase[64];
-  if (tid < 64) rbase[tid] = TM ? (long)min(rho0 + tid, a.NR - 1) : tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
+  __shared__ long rbase[ROWS];
+  if (tid < ROWS) rbase[tid] = TM ? (long)min(rho0 + tid, a.NR - 1) : tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
   const long t_stride = TM ? a.NR : a.A;   // rows between consecutive steps of one recurrent row
   __syncthreads();
   GP_DECL();
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
     const float* hold = hbuf[t & 1];
     float* hnew = hbuf[(t + 1) & 1];
 #pragma unroll
-    for (int wr = 0; wr < 2; ++wr) {
+    for (int wr = 0; wr < ROWS / 32; ++wr) {
       GP(6);
       // issue this job's xi loads first: they are in flight under the 192 MFMAs below
       float xr[16], xz[16], xn[16];
@@ -345,23 +347,23 @@ struct GruBwdArgs {
   int T, A, NR;
 };
 
-template <bool FULL>
+template <bool FULL, int ROWS>
 __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block0) {
   extern __shared__ __align__(16) float smem[];
-  float* dht = smem;                 // [64][HP]   dL/dh carried from step t+1 (already includes the direct z path)
-  float* dhht = dht + 64 * HP;       // [64][G3P]  dhh of the current step
-  unsigned char* rflag = reinterpret_cast<unsigned char*>(dhht + 64 * G3P);   // [64][T] reset flags of the block's rows
+  float* dht = smem;                 // [ROWS][HP]   dL/dh carried from step t+1 (already includes the direct z path)
+  float* dhht = dht + ROWS * HP;     // [ROWS][G3P]  dhh of the current step
+  unsigned char* rflag = reinterpret_cast<unsigned char*>(dhht + ROWS * G3P);   // [ROWS][T] reset flags of the block's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
-  const int rho0 = (block0 + blockIdx.x) * 64;
+  const int rho0 = (block0 + blockIdx.x) * ROWS;
   const int col = 32 * wave + lr;
   // W_h (natural [H][3H]) as the B operand of dh_prev = dhh @ W_h^T: lane (col, h) holds k in [192 h, 192 h + 192)
   float4 wf[48];
 #pragma unroll
   for (int u = 0; u < 48; ++u) wf[u] = *reinterpret_cast<const float4*>(a.Wh + (long)col * G3 + 192 * h + 4 * u);
-  for (int i = tid; i < 64 * HP; i += 256) dht[i] = 0.f;
-  __shared__ long rbase[64];
-  if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, a.T, a.A);   // invalid rows shadow the last valid one
-  for (int i = tid; i < 64 * a.T; i += 256) {
+  for (int i = tid; i < ROWS * HP; i += 256) dht[i] = 0.f;
+  __shared__ long rbase[ROWS];
+  if (tid < ROWS) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, a.T, a.A);   // invalid rows shadow the last valid one
+  for (int i = tid; i < ROWS * a.T; i += 256) {
     const int rl = i / a.T, t = i - rl * a.T;
     const int rho = min(rho0 + rl, a.NR - 1);
     rflag[i] = a.reset[(long)(rho / a.A) * a.T + t];
@@ -374,10 +376,11 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
   float4 bacc4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = a.T - 1; t >= 0; --t) {
     {
-      float4 gr[8], gz[8], gn[8], gh[8], hp[8], dh[8];
-      long rowv[8];
+      constexpr int NK = ROWS / 8;   // rows per thread
+      float4 gr[NK], gz[NK], gn[NK], gh[NK], hp[NK], dh[NK];
+      long rowv[NK];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < NK; ++k) {
         const int rl = rg + 8 * k;
         const long row = rbase[rl] + (long)t * a.A;
         rowv[k] = row;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
         dh[k] = *reinterpret_cast<const float4*>(a.dhs + row * H + c4);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < NK; ++k) {
         const int rl = rg + 8 * k;
         const bool ok = FULL || rho0 + rl < a.NR;
         const bool rst = rflag[rl * a.T + t] != 0;
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
     __syncthreads();
     // ---- dh_prev += dhh[64][3H] @ W_h^T  -> [64][H]; wave w owns columns 32w.. for both row halves
 #pragma unroll 1
-    for (int wr = 0; wr < 2; ++wr) {
+    for (int wr = 0; wr < ROWS / 32; ++wr) {
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -459,7 +462,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
     float sb = 0.f;
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) sb += bsh[r8][tid];
-    a.slab_bhn[(long)(block0 + blockIdx.x) * H + tid] = sb;
+    if (ROWS == 64) a.slab_bhn[(long)(block0 + blockIdx.x) * H + tid] = sb;
+    else atomicAdd(&a.slab_bhn[(long)((block0 + blockIdx.x) >> 1) * H + tid], sb);   // zeroed by the launcher; exactly two addends per element
   }
 }
 
@@ -687,6 +691,24 @@ extern "C" int magpo_gru_set_split_bf16(int on) {
   return prev;
 }
 
+// 32-row blocks when 64-row blocks would occupy at most half of the compute units: the scan is a latency chain of T steps whose
+// step time is proportional to the rows of the block, so twice the blocks of half the size finish in half the time.
+static int g_gru_block_rows = 0;   // 0 = by size, 32 / 64 = forced (magpo_gru_set_block_rows: the parity tests run both)
+extern "C" int magpo_gru_set_block_rows(int rows) {
+  const int prev = g_gru_block_rows;
+  g_gru_block_rows = rows == 32 || rows == 64 ? rows : 0;
+  return prev;
+}
+static bool gru_half_blocks(int NR) {
+  if (g_gru_block_rows) return g_gru_block_rows == 32;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  return (NR + 63) / 64 <= ncu / 2;
+}
+
 extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                                   const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
                                   const int* xi_cls, hipStream_t st) {
@@ -706,11 +728,17 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
     if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<true>), dim3(nfull), dim3(256), lds, st, a, 0);
     if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<false>), dim3(1), dim3(256), lds, st, a, nfull);
   } else if (hs && gates && hprev) {
-    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 0>), dim3(nfull), dim3(256), lds, st, a, 0);
-    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 0>), dim3(1), dim3(256), lds, st, a, nfull);
+    if (gru_half_blocks(a.NR)) {
+      const int nf = a.NR / 32;
+      if (nf) hipLaunchKernelGGL((k_gru_scan_fwd<true, 0, 32>), dim3(nf), dim3(256), lds, st, a, 0);
+      if (a.NR % 32) hipLaunchKernelGGL((k_gru_scan_fwd<false, 0, 32>), dim3(1), dim3(256), lds, st, a, nf);
+    } else {
+      if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 0, 64>), dim3(nfull), dim3(256), lds, st, a, 0);
+      if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 0, 64>), dim3(1), dim3(256), lds, st, a, nfull);
+    }
   } else {
-    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 2>), dim3(nfull), dim3(256), lds, st, a, 0);
-    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 2>), dim3(1), dim3(256), lds, st, a, nfull);
+    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 2, 64>), dim3(nfull), dim3(256), lds, st, a, 0);
+    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 2, 64>), dim3(1), dim3(256), lds, st, a, nfull);
   }
   return check_launch("magpo_gru_scan_fwd");
 }
@@ -724,9 +752,15 @@ extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b
   if (a.NR <= 0 || T <= 0) return MAGPO_OK;
   const size_t lds = (size_t)64 * T * (xi_cls ? 5 : 1);
   if (lds > (xi_cls ? 80 : 24) * 1024) { set_error("magpo_gru_carry: T too large for the LDS tables"); return MAGPO_EINVAL; }
-  const int nfull = a.NR / 64;
-  if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 1>), dim3(nfull), dim3(256), lds, st, a, 0);
-  if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 1>), dim3(1), dim3(256), lds, st, a, nfull);
+  if (gru_half_blocks(a.NR)) {
+    const int nf = a.NR / 32;
+    if (nf) hipLaunchKernelGGL((k_gru_scan_fwd<true, 1, 32>), dim3(nf), dim3(256), lds, st, a, 0);
+    if (a.NR % 32) hipLaunchKernelGGL((k_gru_scan_fwd<false, 1, 32>), dim3(1), dim3(256), lds, st, a, nf);
+  } else {
+    const int nfull = a.NR / 64;
+    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd<true, 1, 64>), dim3(nfull), dim3(256), lds, st, a, 0);
+    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd<false, 1, 64>), dim3(1), dim3(256), lds, st, a, nfull);
+  }
   return check_launch("magpo_gru_carry");
 }
 
@@ -740,8 +774,10 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
   if (lds > 150 * 1024) { set_error("magpo_gru_scan_bwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }
   static size_t lds_set = 0;
   if (lds > lds_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_bwd<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_set = lds;
   }
   const int nfull = a.NR / 64;
@@ -757,8 +793,15 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
     if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_bwd_bf3<false>, dim3(1), dim3(256), ldb, st, a, nfull);
     return check_launch("magpo_gru_scan_bwd");
   }
-  if (nfull) hipLaunchKernelGGL(k_gru_scan_bwd<true>, dim3(nfull), dim3(256), lds, st, a, 0);
-  if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_bwd<false>, dim3(1), dim3(256), lds, st, a, nfull);
+  if (gru_half_blocks(a.NR)) {   // two 32-row blocks add into one slab row (two addends: the sum does not depend on their order)
+    if (hipMemsetAsync(slab_bhn, 0, sizeof(float) * H * (size_t)((a.NR + 63) / 64), st) != hipSuccess) { set_error("magpo_gru_scan_bwd: memset failed"); return MAGPO_ELAUNCH; }
+    const int nf = a.NR / 32;
+    if (nf) hipLaunchKernelGGL((k_gru_scan_bwd<true, 32>), dim3(nf), dim3(256), lds, st, a, 0);
+    if (a.NR % 32) hipLaunchKernelGGL((k_gru_scan_bwd<false, 32>), dim3(1), dim3(256), lds, st, a, nf);
+    return check_launch("magpo_gru_scan_bwd");
+  }
+  if (nfull) hipLaunchKernelGGL((k_gru_scan_bwd<true, 64>), dim3(nfull), dim3(256), lds, st, a, 0);
+  if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_bwd<false, 64>), dim3(1), dim3(256), lds, st, a, nfull);
   return check_launch("magpo_gru_scan_bwd");
 }
 

@@ -128,7 +128,16 @@ def test_wgrad_whole_matrix(L, stream, KIN, NOUT, R, G):
     close(db, dY.double().sum(0), what="db")
 
 
-def test_gru_carry_equals_stepwise_scan(L, stream):
+@pytest.mark.parametrize("rows", [64, 32])
+def test_gru_carry_equals_stepwise_scan(L, stream, rows):
+    prev_rows = L.call("magpo_gru_set_block_rows", rows)
+    try:
+        _gru_carry_case(L, stream)
+    finally:
+        L.call("magpo_gru_set_block_rows", prev_rows)
+
+
+def _gru_carry_case(L, stream):
     """magpo_gru_carry (time-major rollout trajectory, last state only) == the sequence-major scan on the same data; and xi rows
     taken through a class table (xi_cls, csrc/classtab.hip) == the materialised rows, in both row layouts, bit for bit."""
     N, T, A, H = 37, 9, 3, 128
@@ -443,15 +452,17 @@ def test_retention_recurrent(L, stream):
     assert r2.reshape(N, A, 64)[:, :2].abs().max().item() == 0 and r2.reshape(N, A, 64)[:, 3].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("split", [0, 1])
-def test_gru_scan(L, stream, split):
+@pytest.mark.parametrize("split,rows", [(0, 64), (0, 32), (1, 64)])
+def test_gru_scan(L, stream, split, rows):
     """split = 1: the training scans on split-bf16 x3 MFMA (products hi*hi + hi*lo + lo*hi, ~2^-16 relative) instead of fp32 MFMA:
     same tolerances against the fp64 oracle."""
     prev = L.call("magpo_gru_set_split_bf16", split)
+    prev_rows = L.call("magpo_gru_set_block_rows", rows)   # both block sizes (by size alone this case would only ever run 32-row blocks)
     try:
         _gru_scan_case(L, stream)
     finally:
         L.call("magpo_gru_set_split_bf16", prev)
+        L.call("magpo_gru_set_block_rows", prev_rows)
 
 
 def _gru_scan_case(L, stream):
