@@ -224,6 +224,8 @@ def main():
                     help="coordsum-4ag = BASELINE.json configs[1] (headline); coordsum-8x15 = configs[4] per GPU (registered 8x15-100, n_block=2, 8 minibatches); "
                          "lbf-8x8-2p-2f = configs[2] (Level-Based Foraging 8x8-2p-2f-coop) and rware-tiny-4ag = configs[3] per GPU (Robot Warehouse tiny-4ag, run it with "
                          "--num-envs 4096): UNPINNED dynamics, csrc/lbf.hip / csrc/rware.hip restate Jumanji's published algorithm")
+    ap.add_argument("--micro-batches", type=int, default=0, help="train every minibatch in this many slabs with accumulated gradients (same update, "
+                    "activations in HBM scale with the slab); 0 = the workload's default (1; coordsum-8x15: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
@@ -250,19 +252,20 @@ def main():
     dev = torch.device("cuda", local)
     N = args.num_envs
     if args.workload == "coordsum-8x15":
-        sysc = SystemConfig(num_minibatches=8)  # 8 agents: 8 minibatches (as the tuned run) keep R = mb*T*A at 2.1 M rows
+        # 8 agents, two blocks: the reference's num_minibatches = 2 trained as 4 slabs per minibatch (R = 2.1 M rows per pass in HBM)
+        sysc = SystemConfig(micro_batches=args.micro_batches or 4)
         env_cfg = CoordSumConfig(num_agents=8, num_actions=15, time_limit=100, maxval=100)
         n_block = 2
     elif args.workload == "rware-tiny-4ag":
-        sysc = SystemConfig()
+        sysc = SystemConfig(micro_batches=args.micro_batches or 1)
         env_cfg = RwareConfig(column_height=8, shelf_rows=1, shelf_columns=3, num_agents=4, sensor_range=1, request_queue_size=4, time_limit=500)
         n_block = 1
     elif args.workload == "lbf-8x8-2p-2f":
-        sysc = SystemConfig()
+        sysc = SystemConfig(micro_batches=args.micro_batches or 1)
         env_cfg = LbfConfig(grid_size=8, fov=8, num_agents=2, num_food=2, max_agent_level=2, force_coop=True, time_limit=100)
         n_block = 1
     else:
-        sysc = SystemConfig()  # reference defaults (configs/system/gpo/rec_magpo.yaml)
+        sysc = SystemConfig(micro_batches=args.micro_batches or 1)  # reference defaults (configs/system/gpo/rec_magpo.yaml)
         env_cfg = CoordSumConfig(num_agents=4, num_actions=20, time_limit=100, maxval=60)
         n_block = 1
     learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0, n_block=n_block)  # same seed => replicated parameters on every rank
@@ -370,7 +373,8 @@ def main():
             "dtype": "f32" if not gru_split else "f32 (GRU recurrent GEMMs: split-bf16 x3 MFMA, fp32 accumulate)",
             "data": f"synthetic (fixed-seed {env_name} episodes, random-init networks)",
             "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
-                                   f"num_minibatches={sysc.num_minibatches}, Sable embed 64 / 1 head / {n_block} block, GRU 128",
+                                   f"num_minibatches={sysc.num_minibatches}" + (f" (each in {sysc.micro_batches} slabs, gradients accumulated)" if sysc.micro_batches > 1 else "")
+                                   + f", Sable embed 64 / 1 head / {n_block} block, GRU 128",
                        "agent_steps_per_s": round(env_steps * env_cfg.num_agents / elapsed, 1),
                        "first_layer_class_tables": bool(learner.class_tables),   # exact (no caching across updates); MAGPO_CLASS_TABLES=0 = dense path
                        "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},

@@ -45,6 +45,10 @@ class SystemConfig:
     # (rec_magpo.py:581 runs before check_total_timesteps)
     decay_learning_rates: bool = False
     lr_num_updates: int = 1000
+    # not a reference key: every minibatch is trained in this many equal slabs of sequences whose gradients are accumulated before the
+    # ONE optimiser step (same gradient up to fp32 summation order; advantage statistics stay those of the whole minibatch).
+    # Activations in HBM scale with the slab, so large teams run at the reference's num_minibatches within the memory of one GPU.
+    micro_batches: int = 1
 
 
 @dataclass
@@ -272,6 +276,7 @@ class MagpoLearner:
         an = FlatParams(actor_layout(F, 128, K), "cpu").numel
         self.grad_all = torch.zeros(gn + an + 16, dtype=torch.float32, device=device)
         self.grad_acc = torch.zeros_like(self.grad_all) if num_groups > 1 else None
+        self.grad_mu = torch.zeros_like(self.grad_all) if sys.micro_batches > 1 else None
         self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
                                   max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh, embed_dim=int(embed_dim),
                                   seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn])
@@ -567,14 +572,26 @@ class MagpoLearner:
         out["act"] = (c["obs_act"], cls_act, out["enc"][1], out["enc"][2][::c["npos"]].contiguous())
         return out
 
-    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group=0, hs_idx: Optional[torch.Tensor] = None):
+    def _minibatch_adv_stats(self, group, env_idx: torch.Tensor) -> torch.Tensor:
+        """(mean, 1 / (std + eps)) of the advantages of the minibatch's envs per group [U, 2] (rec_magpo.py:283,356): what
+        minibatch_grads computes from its gathered rows, here for the WHOLE minibatch ahead of its micro-batches."""
+        groups = [group] if isinstance(group, int) else list(group)
+        out = torch.zeros(len(groups), 2, device=self.dev)
+        for u, gi in enumerate(groups):
+            sel = self.groups[gi].traj["adv"][:, env_idx.long(), :].contiguous()
+            self.L.call("magpo_adv_moments", sel, sel.numel(), self.ws64, out[u], self._st())
+        return out
+
+    def minibatch_grads(self, env_idx: torch.Tensor, agent_perm: torch.Tensor, group=0, hs_idx: Optional[torch.Tensor] = None,
+                        adv_stats: Optional[torch.Tensor] = None):
         """Forward + loss + backward of both networks for one minibatch; gradients land in guider.grads / actor.grads, loss
         scalars in self.loss_out (all inside self.grad_all, on device).  ``group``: one group index, or a list of groups that
         train as ONE batch of sequences -- every group uses the same env / agent permutation and the loss is a mean
         over rows, so the batch gradient is the unweighted mean of the groups' gradients (the pmean over the "batch" axis,
         rec_magpo.py:395-397); only the advantage normalisation stays per group (rec_magpo.py:283,356).
         ``hs_idx`` [mb]: env whose rollout-start Sable states sequence j trains on (quirk B19: in the reference
-        it differs from ``env_idx`` after the first PPO epoch); default = ``env_idx``."""
+        it differs from ``env_idx`` after the first PPO epoch); default = ``env_idx``.  ``adv_stats`` [U, 2]: advantage statistics to
+        use instead of those of the rows at hand (micro-batches: the statistics of the whole minibatch)."""
         s, T, A, K, N = self.sys, self.T, self.A, self.K, self.N
         groups = [group] if isinstance(group, int) else list(group)
         U = len(groups)
@@ -601,16 +618,19 @@ class MagpoLearner:
             a_logits = self.actor.seq_fwd(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
         st = self._st()
         if U == 1:
-            self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
-            stats = self.adv_stats
+            if adv_stats is None:
+                self.L.call("magpo_adv_moments", m["adv"], R, self.ws64, self.adv_stats, st)
+            stats = self.adv_stats if adv_stats is None else adv_stats[0]
         else:   # per-group statistics, applied in place with the loss kernel's own expression (adv - mean) * rstd; identity stats after
             if getattr(self, "_adv_stats_u", None) is None or self._adv_stats_u.shape[0] != U:
                 self._adv_stats_u = torch.zeros(U, 2, device=self.dev)
                 self._adv_ident = torch.tensor([0.0, 1.0], device=self.dev)
-            for u in range(U):
-                self.L.call("magpo_adv_moments", m["adv"][u * R1:(u + 1) * R1], R1, self.ws64, self._adv_stats_u[u], st)
+            su = self._adv_stats_u if adv_stats is None else adv_stats
+            if adv_stats is None:
+                for u in range(U):
+                    self.L.call("magpo_adv_moments", m["adv"][u * R1:(u + 1) * R1], R1, self.ws64, su[u], st)
             a2 = m["adv"].view(U, R1)
-            a2.sub_(self._adv_stats_u[:, 0:1]).mul_(self._adv_stats_u[:, 1:2])
+            a2.sub_(su[:, 0:1]).mul_(su[:, 1:2])
             stats = self._adv_ident
         self.L.call("magpo_loss_fwd_bwd", g_logits, 64, a_logits, 64, m["mask"], m["action"], m["logp"], m["value"], value, m["adv"], m["targets"],
                     stats, m["dg"], 64, m["da"], 64, m["dv"], self.ws64, self.loss_out, R, K, s.clip_eps, s.clip_gpo,
@@ -657,6 +677,24 @@ class MagpoLearner:
         # sequence i while the trajectory is gathered by batch_perm_e alone.  Only the index is composed; the 48 KiB
         # states never move.
         hs_idx = None
+        mu = max(1, int(s.micro_batches))
+        if mu > 1 and mbs % mu:
+            raise ValueError(f"micro_batches={mu} must divide the minibatch of {mbs} envs")
+
+        def grads(idx, group, hidx):
+            """Gradients of one minibatch into grad_all: in one pass, or as the mean over ``micro_batches`` equal slabs."""
+            if mu == 1:
+                self.minibatch_grads(idx, agent_perm, group, hidx)
+                return
+            stats = self._minibatch_adv_stats(group, idx)
+            step = mbs // mu
+            self.grad_mu.zero_()
+            for j in range(mu):
+                self.minibatch_grads(idx[j * step:(j + 1) * step].contiguous(), agent_perm, group, hidx[j * step:(j + 1) * step].contiguous(),
+                                     adv_stats=stats)
+                self.grad_mu.add_(self.grad_all)
+            self.grad_all.copy_(self.grad_mu).mul_(1.0 / mu)
+
         for e in range(s.ppo_epochs):
             # every group holds the same key (SURVEY B9) => one permutation serves all groups
             ks = host_split(self.groups[0].key, 4)
@@ -671,15 +709,15 @@ class MagpoLearner:
                 idx = batch_perm[mi * mbs:(mi + 1) * mbs].contiguous()
                 hidx = hs_idx[mi * mbs:(mi + 1) * mbs].contiguous()
                 if U == 1:
-                    self.minibatch_grads(idx, agent_perm, 0, hidx)
+                    grads(idx, 0, hidx)
                     scale = 1.0
                 elif self.batch_groups:   # all local groups as one batch of sequences: the row mean IS the pmean over "batch"
-                    self.minibatch_grads(idx, agent_perm, list(range(U)), hidx)
+                    grads(idx, list(range(U)), hidx)
                     scale = 1.0
                 else:  # group by group: accumulate, the 1/U goes into grad_scale
                     self.grad_acc.zero_()
                     for gi in range(U):
-                        self.minibatch_grads(idx, agent_perm, gi, hidx)
+                        grads(idx, gi, hidx)
                         self.grad_acc.add_(self.grad_all)
                     self.grad_all.copy_(self.grad_acc)
                     scale = 1.0 / U

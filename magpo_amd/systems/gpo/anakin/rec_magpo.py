@@ -42,7 +42,7 @@ def _system_config(config) -> SystemConfig:
                         gamma=float(s.gamma), gae_lambda=float(s.gae_lambda), clip_eps=float(s.clip_eps), ent_coef=float(s.ent_coef),
                         vf_coef=float(s.vf_coef), max_grad_norm=float(s.max_grad_norm), clip_gpo=float(s.clip_gpo),
                         alpha=float(s.alpha), actor_lr=float(s.actor_lr), decay_learning_rates=bool(s.get("decay_learning_rates", False)),
-                        lr_num_updates=int(s.num_updates) if s.get("num_updates") else 1000)
+                        lr_num_updates=int(s.num_updates) if s.get("num_updates") else 1000, micro_batches=int(s.get("micro_batches", 1) or 1))
 
 
 def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:

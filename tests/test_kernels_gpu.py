@@ -668,7 +668,7 @@ def test_loss_fwd_bwd(L, stream, masked):
            dev(old.float()), dev(vold), dev(value), dev(adv), dev(tgt), stats, dg, 32, da, 32, dv, ws, lo,
            R, K, sysc.clip_eps, sysc.clip_gpo, sysc.ent_coef, sysc.vf_coef, sysc.alpha, stream)
     lo = lo.cpu()
-    assert float(gi["kl_loss"]) > 0, "test must exercise the clip_gpo mask"
+    assert float(gi["kl_loss"].detach()) > 0, "test must exercise the clip_gpo mask"
     for i, ref in [(1, gi["value_loss"]), (2, ai["actor_loss"]), (3, gi["guider_loss"]), (4, gi["kl_loss"]), (5, gi["entropy"]),
                    (6, ai["actor_kl"]), (7, tl_g), (8, tl_a)]:
         close(lo[i], ref.detach(), 2e-5, 1e-6, f"loss[{i}]")

@@ -253,6 +253,31 @@ def test_class_tables_equal_dense_path(A, K, N, T, nb):
             assert float((ga - gb).abs().max()) <= 3e-5 * scale + 1e-9, f"{net} gradient {n} differs between class tables and the dense path"
 
 
+@pytest.mark.parametrize("U,mu", [(1, 2), (1, 4), (2, 2)])
+def test_micro_batches_equal_one_pass(U, mu):
+    """``system.micro_batches``: every minibatch trained in mu slabs whose gradients are accumulated before the one optimiser
+    step == the minibatch in one pass (same parameters after a whole update up to fp32 summation order; the advantage statistics
+    are those of the whole minibatch in both).  U = 2: two local groups trained as one batch of sequences."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+    A, K, N, T = 4, 20, 16, 12
+    key = host_split(prng_key(21), 4)[0]
+    ls = []
+    for m in (1, mu):
+        sysc = SystemConfig(rollout_length=T, ppo_epochs=2, num_minibatches=2, micro_batches=m)
+        l = MagpoLearner(CoordSumConfig(A, K, 7, 3 * K), N, sysc, "cuda", net_seed=5, wgrad_groups=4, num_groups=U)
+        l.setup(key, n_groups=U)
+        losses = l.update_step()
+        torch.cuda.synchronize()
+        ls.append((l, losses))
+    (a, la), (b, lb) = ls
+    for ga, gb in zip(a.groups, b.groups):
+        assert torch.equal(ga.traj["action"], gb.traj["action"])
+    close(lb, la, 2e-4, 1e-6, "loss table")
+    for net in ("guider", "actor"):
+        pa, pb = getattr(a, net).P.flat, getattr(b, net).P.flat
+        assert float((pa - pb).abs().max()) <= 2e-6, f"{net} parameters differ between {mu} micro-batches and one pass"
+
+
 def test_embed32_four_heads_lbf_setting():
     """n_embd = 32 with 4 heads (both LBF rows of experiment_data/params.csv): head width 8, GroupNorm groups of TWO channels.
     The normalised output is then +-gamma (a - b) / (2 sqrt(var + eps)) with a ~ b at init, which is ill-conditioned in fp32
