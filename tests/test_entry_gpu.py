@@ -126,3 +126,28 @@ def test_learn_is_a_function_of_its_state_and_checkpoints_resume(tmp_path):
     assert r3.opt_states.guider_opt_state["count"] == s3.opt_states.guider_opt_state["count"] == 12
     for a, b in zip(_flat(r3), _flat(s3)):
         assert torch.equal(a, b), "resumed run differs from the uninterrupted one"
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """`python bench.py` (the driver's command, here at a small shape and without the CPU baseline leg): exactly one JSON line on
+    stdout carrying the contract's fields, the roofline object of the dominant kernel and the workload description."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--num-envs", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["unit"] == "env-steps/s" and d["value"] > 0 and abs(d["value"] - 256 * 128 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    roof = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in roof, k
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
