@@ -154,6 +154,10 @@ int magpo_add_inplace(float* dst, const float* src, long n, magpo_stream_t strea
 /* qkv_rows (nullable): q | k | v are row tables (block-0 projections exist once per distinct input row, csrc/classtab.hip) and token row r
  * reads table row qkv_rows[r]; r, dr, dq, dk, dv are always per token row. */
 int magpo_retention_num_chunks(int T, int A);
+/* Tokens per chunk of the chunkwise kernels: 32 (default: two workgroups per CU, less masked work; teams of more than 32 agents fall back to 64)
+ * or 64 (also MAGPO_RET_CHUNK=64); returns the
+ * previous setting (not a status code).  Forward (saved chunk-entry states) and backward must run under the same setting. */
+int magpo_retention_set_chunk_tokens(int tokens);
 int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               float* r, long ldr, const float* s0, const int* seq_env,
                               const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,

@@ -14,6 +14,7 @@
 // One workgroup (4 waves, 2x2 quadrants of 32x32 accumulators) per sequence.  LDS tiles are
 // [64][68] floats: row-per-lane operands are read with ds_read_b128, column-per-lane with ds_read_b32.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace magpo {
 
@@ -639,7 +640,26 @@ __global__ void k_zero_states(float* __restrict__ s0, float* __restrict__ s1, fl
 
 }  // namespace magpo
 
+#include "retention32.hpp"
+
 using namespace magpo;
+
+// Tokens per chunk of the chunkwise kernels: 64 (k_ret_chunk_*), or 32 (k_ret32_*, retention32.hpp; teams of at most 32 agents).
+// The forward's saved chunk-entry states and the backward must use the same setting (magpo_retention_num_chunks follows it).
+static int g_ret_chunk_tokens = 0;   // 0 = not yet initialised: 32 unless MAGPO_RET_CHUNK=64
+static int ret_chunk_tokens() {
+  if (!g_ret_chunk_tokens) {
+    const char* e = getenv("MAGPO_RET_CHUNK");
+    g_ret_chunk_tokens = (e && atoi(e) == 64) ? 64 : 32;
+  }
+  return g_ret_chunk_tokens;
+}
+extern "C" int magpo_retention_set_chunk_tokens(int tokens) {
+  const int prev = ret_chunk_tokens();
+  g_ret_chunk_tokens = tokens == 64 ? 64 : 32;
+  return prev;
+}
+static bool ret32(int A) { return ret_chunk_tokens() == 32 && A <= 32; }
 
 static int check_ret_shape(int T, int A, long ldq, long ldk, long ldv) {
   if (A < 1 || A > 64 || T < 1) { set_error("retention: need 1 <= A <= 64, T >= 1"); return MAGPO_EINVAL; }
@@ -647,7 +667,7 @@ static int check_ret_shape(int T, int A, long ldq, long ldk, long ldv) {
   return MAGPO_OK;
 }
 
-extern "C" int magpo_retention_num_chunks(int T, int A) { int Lt = 64 / A; return (T + Lt - 1) / Lt; }
+extern "C" int magpo_retention_num_chunks(int T, int A) { int Lt = (ret32(A) ? 32 : 64) / A; return (T + Lt - 1) / Lt; }
 
 extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          float* r, long ldr, const float* s0, const int* seq_env,
@@ -656,6 +676,12 @@ extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* 
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs, qkv_rows};
+  if (ret32(A)) {
+    static bool attr32 = false;
+    if (!attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RET32_FWD_LDS); attr32 = true; }
+    hipLaunchKernelGGL(k_ret32_fwd, dim3(nseq), dim3(256), RET32_FWD_LDS, st, a);
+    return check_launch("magpo_retention_chunk_fwd");
+  }
   size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(SeqMeta<FWD_MAXC>);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
@@ -670,6 +696,12 @@ extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* 
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs, qkv_rows};
+  if (ret32(A)) {
+    static bool attr32 = false;
+    if (!attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RET32_BWD_LDS); attr32 = true; }
+    hipLaunchKernelGGL(k_ret32_bwd, dim3(nseq), dim3(256), RET32_BWD_LDS, st, a);
+    return check_launch("magpo_retention_chunk_bwd");
+  }
   size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(SeqMeta<BWD_MAXC>);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret_chunk_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }

@@ -346,7 +346,17 @@ def _ret_reference(q, k, v, s0, dones_t, A, kappa, masked):
                                            # narrow heads (n_head 2 / 4) over >= 3 chunks with a non-zero carried state: the padded-head
                                            # inter-chunk state hand-off, forward and backward
                                            (4, 48, 1, 32), (4, 48, 0, 16), (3, 70, 1, 16), (8, 128, 1, 32), (5, 128, 0, 16)])
-def test_retention_chunk(L, stream, A, T, masked, hs):
+@pytest.mark.parametrize("ct", [64, 32])
+def test_retention_chunk(L, stream, A, T, masked, hs, ct):
+    """ct = tokens per chunk: the 64-token kernels (one workgroup per CU in the backward) or the 32-token ones (retention32.hpp)."""
+    prev = L.call("magpo_retention_set_chunk_tokens", ct)
+    try:
+        _retention_chunk_case(L, stream, A, T, masked, hs)
+    finally:
+        L.call("magpo_retention_set_chunk_tokens", prev)
+
+
+def _retention_chunk_case(L, stream, A, T, masked, hs):
     g = torch.Generator().manual_seed(5)
     B, kappa = 5, 0.775
     C = T * A
@@ -400,7 +410,16 @@ def test_retention_chunk(L, stream, A, T, masked, hs):
 
 
 @pytest.mark.parametrize("A,T,masked,hs", [(4, 128, 0, 64), (4, 40, 1, 64), (8, 128, 1, 64), (5, 30, 1, 64), (3, 70, 1, 16), (4, 8, 1, 64)])
-def test_retention_chunk_row_table(L, stream, A, T, masked, hs):
+@pytest.mark.parametrize("ct", [64, 32])
+def test_retention_chunk_row_table(L, stream, A, T, masked, hs, ct):
+    prev = L.call("magpo_retention_set_chunk_tokens", ct)
+    try:
+        _retention_row_table_case(L, stream, A, T, masked, hs)
+    finally:
+        L.call("magpo_retention_set_chunk_tokens", prev)
+
+
+def _retention_row_table_case(L, stream, A, T, masked, hs):
     """q | k | v read through a row table (block-0 projections on the distinct input rows, csrc/classtab.hip) == the same rows
     gathered per token first: outputs, saved chunk states and all three gradients bit-identical (forward and backward, one to many
     chunks, ragged last chunk, narrow head)."""
