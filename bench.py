@@ -68,12 +68,17 @@ class KernelTimer:
         if name in ("magpo_retention_chunk_fwd", "magpo_retention_chunk_bwd"):
             fwd = name.endswith("fwd")
             nseq, T, A = (a[13], a[14], a[15]) if fwd else (a[16], a[17], a[18])
-            lt = 64 // A
-            nch = (T + lt - 1) // lt
-            gemms = 4 if fwd else 9
+            from magpo_amd._lib import lib as _lib
+            nch = int(_lib().raw("magpo_retention_num_chunks")(int(T), int(A)))
+            ct = 64 if nch == (T + 64 // A - 1) // (64 // A) else 32     # tokens per chunk of the kernels in use (csrc/retention32.hpp)
             rows = nseq * T * A
             byts = 4.0 * rows * 64 * (4 if fwd else 7) + 4.0 * nseq * nch * 4096
-            return ("k_ret_chunk_fwd" if fwd else "k_ret_chunk_bwd"), byts, gemms * 2.0 * 64 ** 3 * nseq * nch
+            if ct == 64:
+                return ("k_ret_chunk_fwd" if fwd else "k_ret_chunk_bwd"), byts, (4 if fwd else 9) * 2.0 * 64 ** 3 * nseq * nch
+            # executed MACs per 32-token chunk: fwd QK^T 32x32x64 + QS 32x64x64 + PV 32x64x32 + state 64x64x32; bwd P, dP 2 x 32x32x64,
+            # dQ / dK / dV 3 x (32x64x32 + 32x64x64), G 64x64x32
+            macs = 393216 if fwd else 851968
+            return ("k_ret32_fwd" if fwd else "k_ret32_bwd"), byts, 2.0 * macs * nseq * nch
         if name == "magpo_retention_recurrent":
             nenv, ntok, wr = a[10], a[11], a[14]
             return "k_ret_recurrent", 4.0 * nenv * ((2 if wr else 1) * 4096 + 4 * ntok * 64), 4.0 * nenv * ntok * 4096 + 2.0 * nenv * 4096

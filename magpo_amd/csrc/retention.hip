@@ -677,9 +677,10 @@ extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* 
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs, qkv_rows};
   if (ret32(A)) {
-    static bool attr32 = false;
-    if (!attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RET32_FWD_LDS); attr32 = true; }
-    hipLaunchKernelGGL(k_ret32_fwd, dim3(nseq), dim3(256), RET32_FWD_LDS, st, a);
+    const size_t lds32 = ret32_fwd_lds(magpo_retention_num_chunks(T, A));
+    static size_t attr32 = 0;
+    if (lds32 > attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32 = lds32; }
+    hipLaunchKernelGGL(k_ret32_fwd, dim3(nseq), dim3(256), lds32, st, a);
     return check_launch("magpo_retention_chunk_fwd");
   }
   size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(SeqMeta<FWD_MAXC>);
@@ -697,9 +698,10 @@ extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* 
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs, qkv_rows};
   if (ret32(A)) {
-    static bool attr32 = false;
-    if (!attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RET32_BWD_LDS); attr32 = true; }
-    hipLaunchKernelGGL(k_ret32_bwd, dim3(nseq), dim3(256), RET32_BWD_LDS, st, a);
+    const size_t lds32 = ret32_bwd_lds(magpo_retention_num_chunks(T, A));
+    static size_t attr32 = 0;
+    if (lds32 > attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32 = lds32; }
+    hipLaunchKernelGGL(k_ret32_bwd, dim3(nseq), dim3(256), lds32, st, a);
     return check_launch("magpo_retention_chunk_bwd");
   }
   size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(SeqMeta<BWD_MAXC>);

@@ -123,19 +123,21 @@ __device__ __forceinline__ void mma16(f32x4 (&acc)[NR], const float* __restrict_
       const float4 s4 = *reinterpret_cast<const float4*>(ascale + k0);
       sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
     }
+    float av[NR][4];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      float av[4];
       if (AROW) {
         const float4 a4 = *reinterpret_cast<const float4*>(At + (am0 + 16 * r + idx) * apitch + k0);
-        av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+        av[r][0] = a4.x; av[r][1] = a4.y; av[r][2] = a4.z; av[r][3] = a4.w;
       } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) av[c] = At[(k0 + c) * apitch + am0 + 16 * r + idx] * sc[c];
+        for (int c = 0; c < 4; ++c) av[r][c] = At[(k0 + c) * apitch + am0 + 16 * r + idx] * sc[c];
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], b[c], acc[r], 0, 0, 0);
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)   // consecutive MFMAs go to different accumulators (a dependent one waits for its predecessor's passes)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][c], b[c], acc[r], 0, 0, 0);
   }
 }
 // same with the B fragment already in registers (row form: breg[kb / 16] = B^T[bn0 + idx][kb + 4 kq .. + 3])
@@ -145,14 +147,17 @@ __device__ __forceinline__ void mma16_breg(f32x4 (&acc)[NR], const float* __rest
 #pragma unroll
   for (int kb = 0; kb < KK; kb += 16) {
     const float4 b4 = breg[kb / 16];
+    float4 a4[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const float4 a4 = *reinterpret_cast<const float4*>(At + (am0 + 16 * r + idx) * apitch + kb + 4 * kq);
-      acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[r], 0, 0, 0);
-      acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[r], 0, 0, 0);
-    }
+    for (int r = 0; r < NR; ++r) a4[r] = *reinterpret_cast<const float4*>(At + (am0 + 16 * r + idx) * apitch + kb + 4 * kq);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r].x, b4.x, acc[r], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r].y, b4.y, acc[r], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r].z, b4.z, acc[r], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r].w, b4.w, acc[r], 0, 0, 0);
   }
 }
 
@@ -167,10 +172,13 @@ __device__ __forceinline__ void store16(float* __restrict__ out, long r0, long l
   }
 }
 
-constexpr size_t RET32_FWD_LDS = (size_t)(3 * 32 * TP + 64 * TP + 32 * PP) * sizeof(float) + sizeof(SeqMeta32);
-constexpr size_t RET32_BWD_LDS = (size_t)(4 * 32 * TP + 64 * TP + 2 * 32 * PP) * sizeof(float) + sizeof(SeqMeta32);
+// LDS per workgroup: the tiles + the bookkeeping of the chunks that are built up front (all of them when the sequence has at most MAXC32,
+// else one at a time): 53.6 KB for the forward at 16 chunks (three workgroups per CU), 67 KB for the backward (two).
+__host__ __device__ inline size_t ret32_meta_bytes(int nch) { return sizeof(float) * 36 + sizeof(ChunkMeta32) * (size_t)(nch <= MAXC32 ? nch : 1); }
+__host__ __device__ inline size_t ret32_fwd_lds(int nch) { return (size_t)(3 * 32 * TP + 64 * TP + 32 * PP) * sizeof(float) + ret32_meta_bytes(nch); }
+__host__ __device__ inline size_t ret32_bwd_lds(int nch) { return (size_t)(4 * 32 * TP + 64 * TP + 2 * 32 * PP) * sizeof(float) + ret32_meta_bytes(nch); }
 
-__global__ __launch_bounds__(256, 2) void k_ret32_fwd(RetArgs a) {
+__global__ __launch_bounds__(256, 3) void k_ret32_fwd(RetArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* Qs = smem;
   float* Ks = Qs + 32 * TP;
@@ -310,16 +318,17 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
   }
   const int tr = wave >> 1, tc = wave & 1;
   const int n64 = 16 * wave + idx;
+  // tiles of the last chunk; inside the loop the next chunk's tiles are stashed behind the barrier that ends the G update, so a chunk
+  // costs three barriers (after the stash, after P / dP, before the writes to G and the tiles)
+  {
+    const int nvl = min(Lt, a.T - (nch - 1) * Lt) * a.A;
+    stash32(Qs, pq, nvl, w4); stash32(Ks, pk, nvl, w4); stash32(Vs, pv, nvl, w4); stash32(Ds, pd, nvl, w4);
+  }
   for (int c = nch - 1; c >= 0; --c) {
     const int t0 = c * Lt;
     const int nvalid = min(Lt, a.T - t0) * a.A;
     const long r0 = row_base + (long)c * L;
-    __syncthreads();
-    stash32(Qs, pq, nvalid, w4);
-    stash32(Ks, pk, nvalid, w4);
-    stash32(Vs, pv, nvalid, w4);
-    stash32(Ds, pd, nvalid, w4);
-    if (!pre) build_meta32(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, c, 1);
+    if (!pre) { __syncthreads(); build_meta32(sm.kpow, sm.ch, a.dones + (long)seq * a.T, a.T, Lt, a.A, c, 1); }
     else __syncthreads();
     const ChunkMeta32& meta = sm.ch[pre ? c : 0];
     // chunk-entry state S_c as the row-form B fragment of dO S_c^T: rows n64 of the saved state, straight from global memory
@@ -399,12 +408,13 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) gn[r][i] = gm * Gs[(16 * r + 4 * kq + i) * TP + n64];
       mma16<false, false, 32, 4>(gn, Qs, TP, 0, Ds, TP, 16 * wave, idx, kq, meta.beta);
-      __syncthreads();   // every wave is done reading Gs (dK, dV)
+      __syncthreads();   // every wave is done reading Gs (dK, dV) and this chunk's tiles
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int i = 0; i < 4; ++i) Gs[(16 * r + 4 * kq + i) * TP + n64] = gn[r][i];
     }
+    if (c > 0) { stash32(Qs, pq, nvn, w4); stash32(Ks, pk, nvn, w4); stash32(Vs, pv, nvn, w4); stash32(Ds, pd, nvn, w4); }
   }
 }
 #undef R32_FETCH
