@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
     const int nvl = min(Lt, a.T - (nch - 1) * Lt) * a.A;
     stash32(Qs, pq, nvl, w4); stash32(Ks, pk, nvl, w4); stash32(Vs, pv, nvl, w4); stash32(Ds, pd, nvl, w4);
   }
+  RP_DECL();
   for (int c = nch - 1; c >= 0; --c) {
     const int t0 = c * Lt;
     const int nvalid = min(Lt, a.T - t0) * a.A;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
     const long rn = c > 0 ? r0 - L : r0;
     const int nvn = c > 0 ? L : nvalid;
     R32_FETCH(pq, q, ldq, rn, nvn);
+    RP(0);
     // P = (Q K^T) * w ; dP = (dO V^T) * w
     {
       f32x4 p[1] = {{0.f, 0.f, 0.f, 0.f}}, dp[1] = {{0.f, 0.f, 0.f, 0.f}};
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
     }
     __syncthreads();
     R32_FETCH(pk, k, ldk, rn, nvn);
+    RP(1);
     // dQ = dP K + beta * (dO S_c^T)
     {
       f32x4 a1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, a2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -374,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
       const int cp = max(c - 2, 0);
       fetch_idx32(ri, a.rows, row_base + (long)cp * L, min(Lt, a.T - cp * Lt) * a.A);
     }
+    RP(2);
     // dK = dP^T Q + eta * (V G^T)
     {
       f32x4 a1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, a2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -387,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
       }
     }
     fetch32(pd, a.dr + rn * a.lddr, a.lddr, nvn, w4);
+    RP(3);
     // dV = P^T dO + eta * (K G)
     {
       f32x4 a1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, a2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -399,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
         store16(a.dv, r0, a.lddv, a1[r], 16 * r, n64, kq, nvalid, a.hs);
       }
     }
+    RP(4);
     // G <- gamma G + (beta Q)^T dO
     {
       f32x4 gn[4];
@@ -415,7 +421,9 @@ __global__ __launch_bounds__(256, 2) void k_ret32_bwd(RetBwdArgs a) {
         for (int i = 0; i < 4; ++i) Gs[(16 * r + 4 * kq + i) * TP + n64] = gn[r][i];
     }
     if (c > 0) { stash32(Qs, pq, nvn, w4); stash32(Ks, pk, nvn, w4); stash32(Vs, pv, nvn, w4); stash32(Ds, pd, nvn, w4); }
+    RP(5);
   }
+  RP_FLUSH();
 }
 #undef R32_FETCH
 

@@ -26,6 +26,6 @@ for it in range(5):
 torch.cuda.synchronize(); t1 = time.time()
 fn(ctypes.c_void_p(out.ctypes.data), 1)
 tot = float(out[:6].sum())
-names = ["stash+meta", "P/dP", "dQ", "dK", "dV", "G"]
+names = ["barrier+meta", "P/dP+barrier", "dQ", "dK", "dV", "G+barrier+stash"]
 nwg = len(range(0, nseq, 64)); per = tot / nwg / 5 / nch
-print(f"bwd {1e3*(t1-t0)/5:.2f} ms/launch; cycles per chunk {per:.0f} (MFMA-only 18432): " + "  ".join(f"{n} {out[i]/tot:.2f}" for i, n in enumerate(names)))
+print(f"bwd {1e3*(t1-t0)/5:.2f} ms/launch; clock ticks per chunk {per:.0f} (MFMA per wave: 6656 cycles per 32-token chunk, 18432 per 64-token chunk): " + "  ".join(f"{n} {out[i]/tot:.2f}" for i, n in enumerate(names)))
