@@ -58,6 +58,10 @@ def test_config_compose_and_overrides():
     assert d.env.env_name == "RobotWarehouse"  # reference default env is rware (configs/default/rec_magpo.yaml)
     with pytest.raises(KeyError):
         compose("rec_magpo", ["system.not_a_key=1"])
+    # the one system key that is not the reference's: a minibatch in slabs with accumulated gradients (default: one pass)
+    from magpo_amd.systems.gpo.anakin.rec_magpo import _system_config
+    assert _system_config(c).micro_batches == 1
+    assert _system_config(compose("rec_magpo", ["env=coordsum", "system.micro_batches=4"])).micro_batches == 4
 
 
 def test_env_factory():
