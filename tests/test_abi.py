@@ -35,7 +35,13 @@ def test_no_torch_types_and_plain_c_header():
 def test_host_entry_points_without_gpu(built):
     from oracle import prng
     assert built.call("magpo_abi_version") == 1
+    # chunks of at most 32 tokens by default (csrc/retention32.hpp), 64 on request or for teams of more than 32 agents
+    assert built.call("magpo_retention_num_chunks", 128, 4) == 16 and built.call("magpo_retention_num_chunks", 128, 3) == 13
+    assert built.call("magpo_retention_num_chunks", 128, 40) == 128
+    prev = built.call("magpo_retention_set_chunk_tokens", 64)
+    assert prev == 32
     assert built.call("magpo_retention_num_chunks", 128, 4) == 8 and built.call("magpo_retention_num_chunks", 128, 3) == 7
+    assert built.call("magpo_retention_set_chunk_tokens", prev) == 64
     key = prng.prng_key(99)
     out = np.zeros((5, 2), np.uint32)
     built.raw("magpo_key_split_host")(key.ctypes.data, 5, out.ctypes.data)
