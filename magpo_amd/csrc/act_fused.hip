@@ -278,6 +278,15 @@ __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const R
 #define PROF(k)
 #endif
 
+// State buffers per wave at 16 envs per wave (the -D hook exists for scripts/debug/act_nbuf.sh).  Measured on MI355X, us per launch for
+// 2 / 3 / 4 buffers: 698 / 769 / 815 (A = 4, one block, 16 384 envs), 2340 / 2863 / 4893 (A = 8, two blocks): the third buffer costs 80
+// VGPRs, which pushes 94 values into scratch, and every scratch reload waits with vmcnt(0), i.e. drains the very prefetches the buffer
+// was meant to keep in flight.
+#ifndef MAGPO_ACT_NBUF16
+#define MAGPO_ACT_NBUF16 2
+#endif
+constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
+
 template <int EPW, int NA, int NH>
 __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
     }
     wsync();
     PROF(0);
-    ret_pass<0, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
+    ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
     wsync();
     PROF(1);
     for (int t = 0; t < A; ++t) {
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
   // cross-retention pre-pass: q2_a (kappa S_d2) for every agent, one state read per env and block
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
-    ret_pass<2, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.q2, AE, 0, B.kvg2 + 192, 256, B.gn2_g,
+    ret_pass<2, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.q2, AE, 0, B.kvg2 + 192, 256, B.gn2_g,
                                             B.gn2_b, 0, dmask);
   }
   wsync();
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
       }
       wsync();
       PROF(0);
-      ret_pass<1, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, last, dmask);
+      ret_pass<1, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, last, dmask);
       wsync();
       PROF(1);
       Row cpe;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) 
         PROF(0);
         if (last) {   // all A tokens are known: S <- kappa S + sum_a k_a^T v_a  (one read + one write per env)
           wsync();
-          ret_pass<3, NA, (EPW == 16 ? 3 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, nullptr, 0, B.gn2_g,
+          ret_pass<3, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, nullptr, 0, B.gn2_g,
                                                   B.gn2_b, 1, dmask);
           PROF(1);
         }
