@@ -4,8 +4,9 @@
 // workgroup can hide is what the 64-token kernels spend in LDS round trips, barriers and vmcnt waits -- ~14 K of the backward's
 // 36 K cycles per chunk -- and the 64-token backward cannot have one: its eight 64x64 tiles take 139 KB of LDS.  With 32-token
 // chunks the token tiles are 32x64 (8.7 KB), the chunk-entry state of the backward is read as MFMA fragments straight from
-// global memory, and a workgroup needs 72 KB: two fit a CU.  The causally / episode-masked half of the intra-chunk products
-// shrinks with the chunk as well: 0.72 x the MFMA work of the 64-token kernels per token (forward 0.75 x).
+// global memory, and a workgroup needs 67 KB at 16 chunks per sequence: two fit a CU (forward: 54 KB, three).  The causally /
+// episode-masked half of the intra-chunk products shrinks with the chunk as well: 0.72 x the MFMA work of the 64-token kernels per
+// token (forward 0.75 x).  Measured at the bench minibatch: backward 3.56 -> 2.5 ms per launch, forward 1.75 -> 1.45-1.5 ms.
 //
 // Tiles are 16x16 (v_mfma_f32_16x16x4_f32, the same flop rate as 32x32x2): lane l = (idx = l & 15, kq = l >> 4) supplies
 // A[m0 + idx][k] and B[k][n0 + idx] for the k-slot k = kb + 4 kq + c of step c (c = 0..3 of a float4), and holds
