@@ -288,7 +288,7 @@ __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const R
 constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
 
 template <int EPW, int NA, int NH>
-__global__ __launch_bounds__(64, EPW == 16 ? 1 : 2) void k_sable_act(ActArgs a) {
+__global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* TQ = smem;                  // [EPW][QP]  this iteration's [q|k|v|g] rows, one per env
   float* HK = TQ + EPW * QP;         // [A][QP]    staged token rows of the env being processed
@@ -563,12 +563,13 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
     B.gn2_g = (const float*)q[16]; B.gn2_b = (const float*)q[17];
     B.qkvg1 = (float*)q[18]; B.q2 = (float*)q[19]; B.kvg2 = (float*)q[20];
   }
-  // envs per wave, measured per launch on MI355X (scripts/debug/act_epw.py; A = 4, one block: N = 1024 -> 273 / 309 / 355 us for 4 / 8 / 16
-  // envs per wave, N = 4096 -> 456 / 398 / 383, N = 16384 -> 1360 / 922 / 775; A = 8, two blocks: N = 1024 -> 1114 / 1363 / 1882,
-  // N = 4096 -> 1691 / 1679 / 2088, N = 16384 -> 5212 / 4905 / 3019): few envs per wave while the chip is not full (a rollout step is a
-  // latency chain per wave), full MFMA tiles and half the weight traffic once it is
+  // envs per wave, measured per launch on MI355X with device events (scripts/debug/act_epw_small.py, act_epw.py; A = 4, one block, 4 / 8 / 16
+  // envs per wave: N = 1024 -> 204 / 311 / 335 us, 2048 -> 237 / 331 / 348, 4096 -> 327 / 396 / 361, 8192 -> 606 / 553 / 434, 16384 -> 1360 / 922 / 698;
+  // A = 8, two blocks (before the one-wave bound of the 4-env waves): N = 1024 -> 1114 / 1363 / 1882, 4096 -> 1691 / 1679 / 2088, 16384 -> 5212 / 4905 / 2340): few envs per wave while the
+  // waves fit the chip's 1024 SIMDs (a rollout step is a latency chain per wave), full MFMA tiles and less weight traffic once they do not.
+  // 4- and 16-env waves run at one wave per SIMD (512 registers, no scratch), 8-env waves at two.
   int epw;
-  if (a.A <= 4) epw = a.N >= 4096 ? 16 : 4;
+  if (a.A <= 4) epw = a.N > 4096 ? 16 : 4;
   else epw = a.N >= 16384 ? 16 : (a.N >= 4096 ? 8 : 4);
   if (const char* e = getenv("MAGPO_ACT_EPW")) { const int v = atoi(e); epw = v == 16 ? 16 : (v == 4 ? 4 : 8); }
   if (epw == 16) launch_act<16>(a, st); else if (epw == 4) launch_act<4>(a, st); else launch_act<8>(a, st);
