@@ -208,17 +208,28 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
 // P2_i = q_i (kappa S) comes from the pre-pass (the cross-retention query is the encoder's, so it is known for every agent
 // before the decoder starts: the state is read once per step there and once more when it is updated after the last agent,
 // instead of once per agent); tokens a < i are read back from the k|v history rows (ld 256: [k | v | - | P2]).
+// hist (NA > 4 only): the k | v history rows of this env (token t at hist + t * 256, v at + 64) are then streamed through two row
+// pairs (one in use, one in flight) instead of being held for all NA - 1 earlier agents at once: 14 rows = 224 VGPRs for 8-agent
+// teams, which the register file does not have beside the state buffers (249 values went to scratch).
 template <int NH, int NA>
 __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const Row& kc, const Row& vc, const Row& gc, const Row& p2,
                                          const Row (&hk)[NA - 1], const Row (&hv)[NA - 1], int i, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, int kq) {
+                                         const float* __restrict__ beta, int kq, const float* __restrict__ hist = nullptr) {
   const int nh = NH ? NH : a.nh, hs = AE / nh;
+  constexpr bool STREAM = NA > 4;
   Row r = p2;
+  Row nk, nv;   // STREAM: rows of token t, requested while token t - 1 is being used
+  if (STREAM && i > 0) { nk = row_load(hist, kq); nv = row_load(hist + 64, kq); }
 #pragma unroll
   for (int t = 0; t < NA; ++t) {
     if (t > i) continue;
     Row kt = kc, vt = vc;   // (value selects: a select between references would pin the arrays in scratch)
-    if (t < NA - 1) {
+    if (STREAM) {
+      if (t < i) {
+        kt = nk; vt = nv;
+        if (t + 1 < i) { nk = row_load(hist + (long)(t + 1) * 256, kq); nv = row_load(hist + (long)(t + 1) * 256 + 64, kq); }
+      }
+    } else if (t < NA - 1) {
       const bool old = t < i;
 #pragma unroll
       for (int j = 0; j < 16; ++j) { kt.v[j] = old ? hk[t < NA - 1 ? t : 0].v[j] : kc.v[j]; vt.v[j] = old ? hv[t < NA - 1 ? t : 0].v[j] : vc.v[j]; }
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
         Row hk2[NA - 1], hv2[NA - 1];
 #pragma unroll
         for (int t = 0; t < NA - 1; ++t) {
-          if (t < i) { hk2[t] = row_load(B.kvg2 + (ge * A + t) * 256, kq); hv2[t] = row_load(B.kvg2 + (ge * A + t) * 256 + 64, kq); }
+          if (NA <= 4 && t < i) { hk2[t] = row_load(B.kvg2 + (ge * A + t) * 256, kq); hv2[t] = row_load(B.kvg2 + (ge * A + t) * 256 + 64, kq); }
         }
         const Row p2 = row_load(B.kvg2 + row * 256 + 192, kq);
         const Row q2 = row_load(B.q2 + row * AE, kq);
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
           }
           if (valid && g < 8) st4g(hrow + 16 * g + 4 * kq, v4);   // k, v of this token: history for the later agents / the state update
         });
-        const Row u2 = cross_ret<NH, NA>(a, q2, k2, v2, g2, p2, hk2, hv2, i, B.gn2_g, B.gn2_b, kq);
+        const Row u2 = cross_ret<NH, NA>(a, q2, k2, v2, g2, p2, hk2, hv2, i, B.gn2_g, B.gn2_b, kq, B.kvg2 + ge * A * 256);
         PROF(0);
         if (last) {   // all A tokens are known: S <- kappa S + sum_a k_a^T v_a  (one read + one write per env)
           wsync();
