@@ -69,7 +69,7 @@ class KernelTimer:
             fwd = name.endswith("fwd")
             nseq, T, A = (a[13], a[14], a[15]) if fwd else (a[16], a[17], a[18])
             from magpo_amd._lib import lib as _lib
-            nch = int(_lib().raw("magpo_retention_num_chunks")(int(T), int(A)))
+            nch = int(_lib().raw("magpo_retention_num_chunks")(int(T), int(A), int(a[20] if fwd else a[23])))
             ct = 64 if nch == (T + 64 // A - 1) // (64 // A) else 32     # tokens per chunk of the kernels in use (csrc/retention32.hpp)
             rows = nseq * T * A
             byts = 4.0 * rows * 64 * (4 if fwd else 7) + 4.0 * nseq * nch * 4096
@@ -219,6 +219,38 @@ def cpu_baseline(seconds_budget: float = 12.0):
                        f"torch-CPU fp32 oracle, {cores} threads, {dt:.1f}s")
 
 
+def launch_ranks(n: int) -> int:
+    """Start ``n`` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as a child of
+    this GPU-free process; forward their stderr, relay rank 0's ONE JSON line from stdout.  Returns the exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    for line in proc.stdout:
+        st = line.strip()
+        if st.startswith("{") and st.endswith("}"):
+            lines.append(st)
+        elif st:
+            print(st, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"[bench] a rank failed (torch.distributed.run exit status {rc})", file=sys.stderr, flush=True)
+        return rc if 0 < rc < 256 else 1
+    if len(lines) != 1:
+        print(f"[bench] expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr, flush=True)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,14 +272,22 @@ def main():
     ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without an outer launcher: this process has not touched the GPU (importing torch does not) and
+        # never will -- it starts N fresh ranks under torch.distributed.run as a CHILD, relays rank 0's JSON line and exits with
+        # the child's status.  (A process that has initialised the GPU must never exec / re-exec on this pool.)
+        raise SystemExit(launch_ranks(args.gpus))
+
     from magpo_amd import distributed as mdist
     from magpo_amd._lib import lib
     from magpo_amd.learner import CoordSumConfig, LbfConfig, MagpoLearner, RwareConfig, SystemConfig, host_split, prng_key
     import torch.distributed as dist
 
+    from magpo_amd.tuning import Tuning
     rank, world, local = mdist.init_from_env(args.backend)
     gru_split = bool(args.gru_split_bf16)
-    lib().call("magpo_gru_set_split_bf16", 1 if gru_split else 0)   # the headline is fp32 MFMA whatever MAGPO_GRU_SPLIT_BF16 says
+    tuning = Tuning.from_env()
+    tuning.gru_split_bf16 = 1 if gru_split else 0   # the headline is fp32 MFMA whatever MAGPO_GRU_SPLIT_BF16 says
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev)
     if world != args.gpus:
@@ -273,7 +313,7 @@ def main():
         sysc = SystemConfig(micro_batches=args.micro_batches or 1)  # reference defaults (configs/system/gpo/rec_magpo.yaml)
         env_cfg = CoordSumConfig(num_agents=4, num_actions=20, time_limit=100, maxval=60)
         n_block = 1
-    learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0, n_block=n_block)  # same seed => replicated parameters on every rank
+    learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0, n_block=n_block, tuning=tuning)  # same seed => replicated parameters on every rank
     key = host_split(prng_key(42), 4)[0]
     learner.setup(key, n_groups=world, group=rank)
     if args.overlap:
@@ -369,6 +409,7 @@ def main():
             "value": round(env_steps / elapsed, 1),
             "unit": "env-steps/s",
             "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,   # from the initialised process group (RCCL / gloo), not from argv
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),

@@ -8,7 +8,10 @@
  * Conventions
  *   - plain C types only; all pointers are DEVICE pointers unless the name ends in _host;
  *   - fp32 row-major; `ld*` / `*_stride` are element strides; `hipStream_t` is passed as void*;
- *   - stream-ordered and asynchronous; no allocation, no host synchronisation, no global state;
+ *   - stream-ordered and asynchronous; no allocation, no host synchronisation; no setters, no environment variables and no
+ *     mutable library state that changes results or buffer sizes: every tuning knob (retention chunk size, GRU MFMA mode and block
+ *     rows, A/B kernel variants, acting envs per wave) is a per-call argument.  The only process-level state is the thread-local
+ *     error string and memoised device queries (occupancy caps, raised dynamic-LDS limits: idempotent);
  *   - return 0 on success, <0 on error (-1 invalid argument, -2 launch failure); the message is
  *     available from magpo_last_error() (thread-local).
  *   - "slab" outputs are per-workgroup partial sums [grid][width] that the caller reduces with
@@ -92,8 +95,11 @@ int magpo_coordsum_class_rows(int A, int maxval, int npos, int K, float* obs_tab
 /* ---- dense layers on fp32 MFMA (flax nn.Dense / retention projections) ----
  * act: 0 none, 1 relu, 2 gelu(tanh), 3 swish, 4 mask: Y = (M > 0) ? XW+b : 0 with the mask M passed in the Ypre argument (same stride as Y)
  * -- the ReLU backward fused into dX = dY W^T.  Ypre (act 0-3, nullable): receives the pre-activation. */
+/* variant: 0 = fast path; A/B reference kernels with the same result up to fp32 summation order: linear bit 0 = wave-autonomous kernels
+ * instead of the shared-tile ones, bit 1 = the same for KIN = 64 only; wgrad bit mask 1 = split kernel for every shape, 2 = generic whole-matrix
+ * kernel also on full tiles, 4 = no unpadded 64 x 256 kernel, 8 = 128 x 384 as two column halves, 16 / 32 = 64 x 64 / 64 x 256 on the wave-grid kernel. */
 int magpo_linear(const float* X, int ldx, const float* Wt, const float* bias, float* Y, int ldy, float* Ypre,
-                 long R, int KIN, int NOUT, int act, magpo_stream_t stream);
+                 long R, int KIN, int NOUT, int act, int variant, magpo_stream_t stream);
 int magpo_linear_pro(int pro, const float* a, long lda, const float* y, long ldy_in, const float* s1, const float* s2,
                      const float* pe, const int* pos, long pos_stride, int npos, int use_pe, const float* W,
                      const int* idx, long idx_stride, const float* s_obs, int F, float* out, long ldout,
@@ -101,7 +107,7 @@ int magpo_linear_pro(int pro, const float* a, long lda, const float* y, long ldy
                      int NOUT, magpo_stream_t stream);
 long magpo_wgrad_workspace_floats(int KIN, int NOUT, int G);
 int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, long R, int KIN, int krows, int NOUT, float* dW,
-                float* db, float* workspace, int G, float scale, int accumulate, magpo_stream_t stream);
+                float* db, float* workspace, int G, float scale, int accumulate, int variant, magpo_stream_t stream);
 int magpo_reduce_slabs(const float* slab, float* out, int G, long P, long stride, float scale, int accumulate,
                        magpo_stream_t stream);
 int magpo_transpose_pad(const float* W, float* Wt, int K, int N, int Npad, magpo_stream_t stream);
@@ -153,19 +159,18 @@ int magpo_add_inplace(float* dst, const float* src, long n, magpo_stream_t strea
 /* ---- K2/K7 retention (retention.py:66-115 chunkwise + recurrent, :117-213 decay matrix / xi) ---- */
 /* qkv_rows (nullable): q | k | v are row tables (block-0 projections exist once per distinct input row, csrc/classtab.hip) and token row r
  * reads table row qkv_rows[r]; r, dr, dq, dk, dv are always per token row. */
-int magpo_retention_num_chunks(int T, int A);
-/* Tokens per chunk of the chunkwise kernels: 32 (default: two workgroups per CU, less masked work; teams of more than 32 agents fall back to 64)
- * or 64 (also MAGPO_RET_CHUNK=64); returns the
- * previous setting (not a status code).  Forward (saved chunk-entry states) and backward must run under the same setting. */
-int magpo_retention_set_chunk_tokens(int tokens);
+/* chunk_tokens: tokens per chunk of the chunkwise kernels, 32 (= 0, the default: two workgroups per CU, less masked work; teams of more than 32
+ * agents fall back to 64) or 64.  The forward (saved chunk-entry states [nseq][num_chunks][64][64]) and the backward of one pass must be given
+ * the same value, and so must magpo_retention_num_chunks when it sizes `states`. */
+int magpo_retention_num_chunks(int T, int A, int chunk_tokens);
 int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               float* r, long ldr, const float* s0, const int* seq_env,
                               const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
-                              int masked, float kappa, int hs, const int* qkv_rows, magpo_stream_t stream);
+                              int masked, float kappa, int hs, const int* qkv_rows, int chunk_tokens, magpo_stream_t stream);
 int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
                               long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
-                              int masked, float kappa, int hs, const int* qkv_rows, magpo_stream_t stream);
+                              int masked, float kappa, int hs, const int* qkv_rows, int chunk_tokens, magpo_stream_t stream);
 int magpo_retention_recurrent(float* S, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                               long env_stride_rows, float* r, long ldr, int nenv, int ntok, int ret_from, float decay,
                               int write_state, const float* gp, long ldg, const float* gamma, const float* beta,
@@ -174,7 +179,8 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
                                  magpo_stream_t stream);
 
 /* ---- K2 fused acting step: SableNetwork.get_actions (sable_network.py:443-482; decode.py:111-153) in ONE launch ----
- * dims_host[11] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F)}; kappa_host[4] (per head);
+ * dims_host[12] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F), envs per wave (0 = by size, or 4 / 8 / 16)};
+ * kappa_host[4] (per head);
  * keys_host [A][2] sampling keys by value, or NULL with ptrs[3] = device key table (static arguments for graph replay);
  * ptrs_host[48]: obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
  *   pe | S_enc S_d1 S_d2 ([n_block][n_head][N][64][64], updated in place) | scratch xn ([N*A] rows), done [N] u8 or NULL (envs whose
@@ -202,24 +208,21 @@ int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int
 
 /* ---- K3/K8 GRU actor (base.py:121-184; flax GRUCell) ----
  * gates [R][512] is an opaque save-for-backward buffer written by magpo_gru_scan_fwd and read by magpo_gru_scan_bwd
- * ((r, z, n, h W_hn + b_hn) interleaved per hidden column). */
+ * ((r, z, n, h W_hn + b_hn) interleaved per hidden column).
+ * Per-call tuning: split_bf16 -- the TRAINING scans (T > 1 with all save buffers) on 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA (x = hi + lo in
+ * bf16, product = hi*hi + hi*lo + lo*hi with fp32 accumulation, ~2^-16 relative per product); forward and backward of one pass take the same
+ * value.  block_rows -- recurrent rows per workgroup of the fp32 scans: 0 = by size (32 when 64-row blocks would leave half of the compute
+ * units idle), or 32 / 64 forced.
+ * xi_cls (nullable): xi is a table over the distinct input rows and token row r takes xi[xi_cls[r]] (csrc/classtab.hip). */
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                        const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
-                       const int* xi_cls, magpo_stream_t stream);
-/* A/B switch of the TRAINING scans (T > 1 with all save buffers): 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA (x = hi + lo in bf16, product
- * = hi*hi + hi*lo + lo*hi with fp32 accumulation, ~2^-16 relative per product).  Returns the previous mode; the default comes from
- * MAGPO_GRU_SPLIT_BF16. */
-int magpo_gru_set_split_bf16(int on);
-/* Recurrent rows per workgroup of the fp32 GRU scans: 0 = by size (32 when 64-row blocks would leave half of the compute units idle), or 32 / 64
- * forced; returns the previous setting (not a status code). */
-int magpo_gru_set_block_rows(int rows);
-/* xi_cls (nullable): xi is a table over the distinct input rows and token row r takes xi[xi_cls[r]] (csrc/classtab.hip).
- * hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
+                       const int* xi_cls, int split_bf16, int block_rows, magpo_stream_t stream);
+/* hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
 int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,
-                    float* h_last, int nenv, int T, int A, const int* xi_cls, magpo_stream_t stream);
+                    float* h_last, int nenv, int T, int A, const int* xi_cls, int block_rows, magpo_stream_t stream);
 int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned char* reset, const float* dhs,
                        const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
-                       magpo_stream_t stream);
+                       int split_bf16, int block_rows, magpo_stream_t stream);
 
 /* ---- K2 sampling, K5 GAE, K6 shuffle/layout, K9 losses (decode.py:128-149; multistep.py:24-68; rec_magpo.py:222-370,439-462) ---- */
 int magpo_sample_categorical(const float* logits, long ld, const unsigned char* mask, long mask_stride,

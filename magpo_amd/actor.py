@@ -14,13 +14,15 @@ import torch
 from ._lib import lib
 from .params import FlatParams, actor_layout, actor_named_views, init_actor
 from .sable import _Bufs
+from .tuning import Tuning
 
 H = 128
 
 
 class GruActor:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, hidden: int = 128, wgrad_groups: int = 512,
-                 seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
+                 seed: Optional[int] = None, grads: Optional[torch.Tensor] = None, tuning: Optional[Tuning] = None):
+        self.tuning = tuning if tuning is not None else Tuning.from_env()   # per-call kernel knobs (tuning.py); the library keeps none
         if hidden != 128:
             raise NotImplementedError("gfx950 GRU kernels: hidden_state_dim = 128 only")
         if obs_dim > 128 or action_dim > 32:
@@ -77,7 +79,7 @@ class GruActor:
         self._tp("head_nat_pad", ht, H)                   # [128][64]
 
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
-        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self._st())
+        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self.tuning.linear_variant, self._st())
 
     def pre_torso(self, obs, emb, R):
         """emb = relu(obs W_pre + b) (MLPTorso, torsos.py:36-47) for R observation rows (stride self.Fld)."""
@@ -94,11 +96,11 @@ class GruActor:
         """dW = X^T dY, queued on the side stream (off the critical path of the backward chain)."""
         side = self.wgrad_stream if self.overlap_wgrad else None
         if side is None:
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self.tuning.wgrad_variant, self._st())
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self.tuning.wgrad_variant, self._st())
 
     # one step for N envs: returns new hidden [N*A,128]; logits [N*A,64] if want_logits
     def step(self, obs, h_in, reset_env, h_out, want_logits: bool = False):
@@ -109,7 +111,7 @@ class GruActor:
         emb = b.get("s_emb", (R, H)); xi = b.get("s_xi", (R, 3 * H))
         self.pre_torso(obs, emb, R)
         self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
-        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h_in, None, reset_env, h_out, None, None, N, 1, A, None, st)
+        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h_in, None, reset_env, h_out, None, None, N, 1, A, None, 0, self.tuning.gru_block_rows, st)
         if not want_logits:
             return None
         y = b.get("s_y", (R, H)); logits = b.get("s_logits", (R, 64), zero=True)
@@ -127,12 +129,12 @@ class GruActor:
         R = T * N * A
         if classes is not None:
             _, xi_tab = self.input_table(classes[0], "r" + tag)
-            L.call("magpo_gru_carry", xi_tab, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, classes[1], st)
+            L.call("magpo_gru_carry", xi_tab, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, classes[1], self.tuning.gru_block_rows, st)
             return
         emb = b.get("c_emb", (R, H)); xi = b.get("c_xi", (R, 3 * H))
         self.pre_torso(obs_tm, emb, R)
         self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
-        L.call("magpo_gru_carry", xi, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, None, st)
+        L.call("magpo_gru_carry", xi, self.wt["wh"], v["gru.hn.bias"], h_in, reset_tm, h_out, N, T, A, None, self.tuning.gru_block_rows, st)
 
     def input_table(self, obs_tab: torch.Tensor, tag: str = ""):
         """xi of every distinct observation row: pre-torso + GRU input projection on obs_tab [C,F] -> [C,384] (the rows of a
@@ -163,7 +165,7 @@ class GruActor:
             xi_cls = None
             self.pre_torso(obs, emb, R)
             self.lin(emb, H, self.wt["wi"], v["gru.bi"], xi, 3 * H, R, H, 3 * H)
-        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h0, h0_idx, dones, hs, gates, hprev, nseq, T, A, xi_cls, st)
+        L.call("magpo_gru_scan_fwd", xi, self.wt["wh"], v["gru.hn.bias"], h0, h0_idx, dones, hs, gates, hprev, nseq, T, A, xi_cls, self.tuning.gru_split_bf16, self.tuning.gru_block_rows, st)
         self.lin(hs, H, self.wt["post"], v["post.bias"], y, H, R, H, H, act=1)
         self.lin(y, H, self.wt["head"], v["head.bias"], logits, 64, R, H, self.K)
         return logits
@@ -184,7 +186,7 @@ class GruActor:
         dxi = b.get("g_dxi", (R, 3 * H)); dhh = b.get("g_dhh", (R, 3 * H))
         nblk = (nseq * A + 63) // 64
         slab = b.get("g_slab", (nblk, H))
-        L.call("magpo_gru_scan_bwd", t("gates"), t("hprev"), dones, dhs, v["gru.wh"], dxi, dhh, slab, nseq, T, A, st)
+        L.call("magpo_gru_scan_bwd", t("gates"), t("hprev"), dones, dhs, v["gru.wh"], dxi, dhh, slab, nseq, T, A, self.tuning.gru_split_bf16, self.tuning.gru_block_rows, st)
         L.call("magpo_reduce_slabs", slab, gv["gru.hn.bias"], nblk, H, H, 1.0, 0, st)
         self.wgrad(t("hprev"), H, dhh, 3 * H, R, H, 3 * H, gv["gru.wh"])
         if sv["classes"] is not None:

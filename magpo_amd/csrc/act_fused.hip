@@ -582,7 +582,10 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   int epw;
   if (a.A <= 4) epw = a.N > 4096 ? 16 : 4;
   else epw = a.N >= 16384 ? 16 : (a.N >= 4096 ? 8 : 4);
-  if (const char* e = getenv("MAGPO_ACT_EPW")) { const int v = atoi(e); epw = v == 16 ? 16 : (v == 4 ? 4 : 8); }
+  if (dims_host[11]) {   // envs per wave forced by the caller (A/B measurements); 0 = by size as above
+    if (dims_host[11] != 4 && dims_host[11] != 8 && dims_host[11] != 16) { set_error("magpo_sable_act: envs per wave must be 0, 4, 8 or 16"); return MAGPO_EINVAL; }
+    epw = dims_host[11];
+  }
   if (epw == 16) launch_act<16>(a, st); else if (epw == 4) launch_act<4>(a, st); else launch_act<8>(a, st);
   return check_launch("magpo_sable_act");
 }

@@ -204,7 +204,6 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
 // kernel (same 192 VGPRs as the fp32 fragments); h is written to LDS as two bf16 tiles when the gate phase produces it (each
 // element is produced once and read by all four waves).  The carry itself (z * h_prev) stays exact fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int GRU_SPLIT_DEFAULT = 0;
 constexpr int HB = H + 8;   // bf16 tile pitch (elements): 272-byte rows, 16-byte aligned
 
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
@@ -678,46 +677,35 @@ __global__ __launch_bounds__(256) void k_small_linear128(const float* __restrict
 
 using namespace magpo;
 
-// A/B switch of the training scans: 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA.  Default from MAGPO_GRU_SPLIT_BF16 (read once);
-// magpo_gru_set_split_bf16 overrides it (returns the previous mode) so that the parity tests can compare both in one process.
-static int g_gru_split = -1;
-static int gru_split_mode() {
-  if (g_gru_split < 0) { const char* e = getenv("MAGPO_GRU_SPLIT_BF16"); g_gru_split = e ? (atoi(e) != 0) : GRU_SPLIT_DEFAULT; }
-  return g_gru_split;
-}
-extern "C" int magpo_gru_set_split_bf16(int on) {
-  const int prev = gru_split_mode();
-  g_gru_split = on ? 1 : 0;
-  return prev;
-}
-
-// 32-row blocks when 64-row blocks would occupy at most half of the compute units: the scan is a latency chain of T steps whose
-// step time is proportional to the rows of the block, so twice the blocks of half the size finish in half the time.
-static int g_gru_block_rows = 0;   // 0 = by size, 32 / 64 = forced (magpo_gru_set_block_rows: the parity tests run both)
-extern "C" int magpo_gru_set_block_rows(int rows) {
-  const int prev = g_gru_block_rows;
-  g_gru_block_rows = rows == 32 || rows == 64 ? rows : 0;
-  return prev;
-}
-static bool gru_half_blocks(int NR) {
-  if (g_gru_block_rows) return g_gru_block_rows == 32;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+// Per-call tuning arguments (no library state):
+//   split_bf16  the TRAINING scans (T > 1 with all save buffers) on 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA; forward and backward of one
+//               pass must be given the same value;
+//   block_rows  recurrent rows per workgroup of the fp32 scans: 0 = by size (32 when 64-row blocks would occupy at most half of the compute
+//               units: the scan is a latency chain of T steps whose step time follows the block's rows), or 32 / 64 forced.
+static int check_gru_tuning(int split_bf16, int block_rows) {
+  if ((split_bf16 != 0 && split_bf16 != 1) || (block_rows != 0 && block_rows != 32 && block_rows != 64)) {
+    set_error("gru: split_bf16 must be 0 / 1, block_rows 0 / 32 / 64");
+    return MAGPO_EINVAL;
   }
+  return MAGPO_OK;
+}
+static bool gru_half_blocks(int NR, int block_rows) {
+  if (block_rows) return block_rows == 32;
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
   return (NR + 63) / 64 <= ncu / 2;
 }
 
 extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,
                                   const unsigned char* reset, float* hs, float* gates, float* hprev, int nseq, int T, int A,
-                                  const int* xi_cls, hipStream_t st) {
+                                  const int* xi_cls, int split_bf16, int block_rows, hipStream_t st) {
   GruArgs a{xi, Wht, b_hn, h0, h0_idx, reset, hs, gates, hprev, T, A, nseq * A, 0, nullptr, xi_cls};
+  if (int e = check_gru_tuning(split_bf16, block_rows)) return e;
   if (a.NR <= 0) return MAGPO_OK;
   const size_t lds = (size_t)64 * T * (xi_cls ? 5 : 1);   // reset flags (+ xi class rows) of the block's rows
   if (lds > (xi_cls ? 80 : 24) * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS tables"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
-  const bool split = gru_split_mode() != 0;
+  const bool split = split_bf16 != 0;
   if (hs && gates && hprev && split && T > 1) {   // training scan on split-bf16 x3 MFMA (see k_gru_scan_fwd_bf3)
     static size_t lf_set = 0;
     if (lds > lf_set) {
@@ -728,7 +716,7 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
     if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<true>), dim3(nfull), dim3(256), lds, st, a, 0);
     if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<false>), dim3(1), dim3(256), lds, st, a, nfull);
   } else if (hs && gates && hprev) {
-    if (gru_half_blocks(a.NR)) {
+    if (gru_half_blocks(a.NR, block_rows)) {
       const int nf = a.NR / 32;
       if (nf) hipLaunchKernelGGL((k_gru_scan_fwd<true, 0, 32>), dim3(nf), dim3(256), lds, st, a, 0);
       if (a.NR % 32) hipLaunchKernelGGL((k_gru_scan_fwd<false, 0, 32>), dim3(1), dim3(256), lds, st, a, nf);
@@ -747,12 +735,13 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
 // only the state after the last step is written.  The carry is a pure function of (obs, done), so the rollout computes it
 // once for all T steps instead of once per env step (ScannedRNN semantics, base.py:121-149).
 extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,
-                               float* h_last, int nenv, int T, int A, const int* xi_cls, hipStream_t st) {
+                               float* h_last, int nenv, int T, int A, const int* xi_cls, int block_rows, hipStream_t st) {
+  if (int e = check_gru_tuning(0, block_rows)) return e;
   GruArgs a{xi, Wht, b_hn, h0, nullptr, reset_tm, nullptr, nullptr, nullptr, T, A, nenv * A, 1, h_last, xi_cls};
   if (a.NR <= 0 || T <= 0) return MAGPO_OK;
   const size_t lds = (size_t)64 * T * (xi_cls ? 5 : 1);
   if (lds > (xi_cls ? 80 : 24) * 1024) { set_error("magpo_gru_carry: T too large for the LDS tables"); return MAGPO_EINVAL; }
-  if (gru_half_blocks(a.NR)) {
+  if (gru_half_blocks(a.NR, block_rows)) {
     const int nf = a.NR / 32;
     if (nf) hipLaunchKernelGGL((k_gru_scan_fwd<true, 1, 32>), dim3(nf), dim3(256), lds, st, a, 0);
     if (a.NR % 32) hipLaunchKernelGGL((k_gru_scan_fwd<false, 1, 32>), dim3(1), dim3(256), lds, st, a, nf);
@@ -767,7 +756,8 @@ extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b
 // slab_bhn: [ceil(NR/64)][128]
 extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned char* reset, const float* dhs,
                                   const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
-                                  hipStream_t st) {
+                                  int split_bf16, int block_rows, hipStream_t st) {
+  if (int e = check_gru_tuning(split_bf16, block_rows)) return e;
   GruBwdArgs a{gates, hprev, reset, dhs, Wh, dxi, dhh, slab_bhn, T, A, nseq * A};
   if (a.NR <= 0) return MAGPO_OK;
   const size_t lds = (size_t)(64 * HP + 64 * G3P) * sizeof(float) + (size_t)64 * T;
@@ -781,7 +771,7 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
     lds_set = lds;
   }
   const int nfull = a.NR / 64;
-  if (gru_split_mode() != 0) {   // split-bf16 x3 MFMA (k_gru_scan_bwd_bf3): fp32 dht + two bf16 dhh tiles + flags
+  if (split_bf16) {   // split-bf16 x3 MFMA (k_gru_scan_bwd_bf3): fp32 dht + two bf16 dhh tiles + flags
     const size_t ldb = (size_t)64 * HP * sizeof(float) + (size_t)2 * 64 * G3B * sizeof(__bf16) + (size_t)64 * T;
     static size_t ldb_set = 0;
     if (ldb > ldb_set) {
@@ -793,7 +783,7 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
     if (a.NR % 64) hipLaunchKernelGGL(k_gru_scan_bwd_bf3<false>, dim3(1), dim3(256), ldb, st, a, nfull);
     return check_launch("magpo_gru_scan_bwd");
   }
-  if (gru_half_blocks(a.NR)) {   // two 32-row blocks add into one slab row (two addends: the sum does not depend on their order)
+  if (gru_half_blocks(a.NR, block_rows)) {   // two 32-row blocks add into one slab row (two addends: the sum does not depend on their order)
     if (hipMemsetAsync(slab_bhn, 0, sizeof(float) * H * (size_t)((a.NR + 63) / 64), st) != hipSuccess) { set_error("magpo_gru_scan_bwd: memset failed"); return MAGPO_ELAUNCH; }
     const int nf = a.NR / 32;
     if (nf) hipLaunchKernelGGL((k_gru_scan_bwd<true, 32>), dim3(nf), dim3(256), lds, st, a, 0);

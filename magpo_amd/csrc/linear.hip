@@ -1118,10 +1118,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_full_g(const float* __restrict
 using namespace magpo;
 
 extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const float* bias, float* Y, int ldy, float* Ypre,
-                            long R, int KIN, int NOUT, int act, hipStream_t stream) {
+                            long R, int KIN, int NOUT, int act, int variant, hipStream_t stream) {
   if (R <= 0) return MAGPO_OK;
   if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
-  static const bool lds64 = []() { const char* e = getenv("MAGPO_LINEAR_LDS64"); return !e || atoi(e) != 0; }();
+  // variant (A/B reference paths, same results up to fp32 summation order; 0 = the fast path): bit 0 = wave-autonomous k_linear_wk instead of
+  // the shared-tile k_linear_lds, bit 1 = the same for KIN = 64 only
+  if (variant < 0 || variant > 3) { set_error("magpo_linear: variant must be in [0, 3]"); return MAGPO_EINVAL; }
+  const bool lds64 = !(variant & 2);
   const float* aux = nullptr;
   if (act == ACT_MASKPOS) {   // the Ypre argument carries the mask INPUT (same shape / stride as Y), nothing else is written
     if (!Ypre) { set_error("magpo_linear: act 4 (mask) needs the mask tensor in the Ypre argument"); return MAGPO_EINVAL; }
@@ -1137,7 +1140,7 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
     long walkers = 2048 / wpb;
     if (walkers > ntiles) walkers = ntiles;
     dim3 grid((unsigned)walkers, (unsigned)(ncg / wpb)), block(64 * wpb);
-    static const bool use_lds = []() { const char* e = getenv("MAGPO_LINEAR_LDS"); return !e || atoi(e) != 0; }();
+    const bool use_lds = !(variant & 1);
     if (use_lds) {
       // shared-tile form: 4 waves per block, 2 when the column groups do not fill blocks of 4 (every wave then has MFMA work);
       // column groups past NOUT idle in the MFMA part but help loading
@@ -1147,8 +1150,7 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
       // several column blocks per row walker: all of them co-resident (walkers x column blocks <= resident workgroups), so the
       // column blocks of a walker -- same XCD, since the walker count is a multiple of 8 -- read a tile at about the same
       // time and the re-reads hit that XCD's L2 instead of HBM (in a second round they would come from HBM again)
-      static const long lds_wk_div = []() { const char* e = getenv("MAGPO_LINEAR_WKDIV"); return e ? atol(e) : 2L; }();
-      if (gy >= 3 && lds_wk_div > 1) wk2 /= lds_wk_div;
+      if (gy >= 3) wk2 /= 2;
       if (wk2 > ntiles) wk2 = ntiles;
       dim3 g2((unsigned)wk2, (unsigned)gy), b2(64 * nw);
       const size_t lds = (size_t)2 * 32 * (KIN + LDP) * sizeof(float);
@@ -1241,18 +1243,22 @@ extern "C" long magpo_wgrad_workspace_floats(int KIN, int NOUT, int G) { return 
 // dW[KIN][NOUT] (+ optional db[NOUT]) = scale * X^T dY ; workspace >= magpo_wgrad_workspace_floats floats.
 // Only the first `krows` rows of dW are written (krows < KIN for zero-padded small operands).
 extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, long R, int KIN, int krows, int NOUT, float* dW,
-                           float* db, float* workspace, int G, float scale, int accumulate, hipStream_t stream) {
+                           float* db, float* workspace, int G, float scale, int accumulate, int variant, hipStream_t stream) {
   if ((ldx & 3) || (ldy & 3) || KIN % 64) { set_error("magpo_wgrad: bad strides / KIN"); return MAGPO_EINVAL; }
+  // variant (A/B reference paths, same results up to fp32 summation order; 0 = the fast path), bit mask: 1 = split kernel k_wgrad for every
+  // shape, 2 = generic k_wgrad_full also on full tiles, 4 = no unpadded-tile 64 x 256 kernel, 8 = 128 x 384 as two column halves on the
+  // wave-grid kernel, 16 = 64 x 64 on the wave-grid kernel, 32 = 64 x 256 on the wave-grid kernel
+  if (variant < 0 || variant > 63) { set_error("magpo_wgrad: variant must be in [0, 63]"); return MAGPO_EINVAL; }
   float* slab = workspace;
   float* bslab = db ? workspace + (long)G * KIN * NOUT : nullptr;
-  static const bool use_full = []() { const char* e = getenv("MAGPO_WGRAD_FULL"); return !e || atoi(e) != 0; }();
-  static const bool use_x = []() { const char* e = getenv("MAGPO_WGRAD_FULL_X"); return !e || atoi(e) != 0; }();
+  const bool use_full = !(variant & 1);
+  const bool use_x = !(variant & 2);
   // whole-matrix form: one workgroup per slab accumulates the full KIN x NOUT block, every row read once.  128x384 always
   // (k_wgrad_full, or k_wgrad_full_x when every tile is full); with full tiles also 128x128 (two workgroups per CU: 1.53 ->
   // 1.30 ms) and 64x256 (1.84 -> 1.76 ms).  Other shapes stay on the split kernel k_wgrad.
   const bool exact = R % 64 == 0 && use_x;
-  static const bool use_pad0 = []() { const char* e = getenv("MAGPO_WGRAD_PAD0"); return !e || atoi(e) != 0; }();
-  static const int g_alt = []() { const char* e = getenv("MAGPO_WGRAD_GALT"); return e ? atoi(e) : 0; }();   // experiments (bit mask): 1 = 64x64 on the wave-grid kernel (0.43 vs 0.40 ms), 2 = 64x256 (1.63 vs 1.64 ms)
+  const bool use_pad0 = !(variant & 4);
+  const int g_alt = (variant >> 4) & 3;   // experiments (bit mask): 1 = 64x64 on the wave-grid kernel (0.43 vs 0.40 ms), 2 = 64x256 (1.63 vs 1.64 ms)
   if (use_full && exact && use_pad0 && !(g_alt & 2) && KIN == 64 && NOUT == 256 && R >= 64 * 256) {
     if (G > 512) G = 512;
     float* bsl = db ? workspace + (long)G * KIN * NOUT : nullptr;
@@ -1266,8 +1272,8 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
     return check_launch("magpo_wgrad");
   }
   // 128 x 384 on this kernel (two column halves, two workgroups per CU) measured 3.57 vs 3.63 ms for k_wgrad_full_x<4,3> while
-  // reading X twice: within noise, so the one-pass kernel stays the default (MAGPO_WGRAD_G2=1 selects this one)
-  static const int use_g2 = []() { const char* e = getenv("MAGPO_WGRAD_G2"); return e ? atoi(e) : 0; }();
+  // reading X twice: within noise, so the one-pass kernel stays the default (variant bit 3 selects this one)
+  const int use_g2 = (variant >> 3) & 1;
   int gk = 0, gn = 0;   // (KTW, NTW) of the 2 x 2 wave-grid kernel, 0 = not this kernel
   if (KIN == 64 && NOUT == 192) { gk = 1; gn = 3; }
   else if (use_g2 && KIN == 128 && NOUT == 384) { gk = 2; gn = 3; }

@@ -644,22 +644,14 @@ __global__ void k_zero_states(float* __restrict__ s0, float* __restrict__ s1, fl
 
 using namespace magpo;
 
-// Tokens per chunk of the chunkwise kernels: 64 (k_ret_chunk_*), or 32 (k_ret32_*, retention32.hpp; teams of at most 32 agents).
-// The forward's saved chunk-entry states and the backward must use the same setting (magpo_retention_num_chunks follows it).
-static int g_ret_chunk_tokens = 0;   // 0 = not yet initialised: 32 unless MAGPO_RET_CHUNK=64
-static int ret_chunk_tokens() {
-  if (!g_ret_chunk_tokens) {
-    const char* e = getenv("MAGPO_RET_CHUNK");
-    g_ret_chunk_tokens = (e && atoi(e) == 64) ? 64 : 32;
-  }
-  return g_ret_chunk_tokens;
+// Tokens per chunk of the chunkwise kernels, a per-call argument (no library state): 32 (k_ret32_*, retention32.hpp; also 0 = default;
+// teams of at most 32 agents) or 64 (k_ret_chunk_*).  The forward's saved chunk-entry states and the backward must be given the same value
+// (magpo_retention_num_chunks takes it too).
+static bool ret32(int A, int chunk_tokens) { return chunk_tokens != 64 && A <= 32; }
+static int check_chunk_tokens(int chunk_tokens) {
+  if (chunk_tokens != 0 && chunk_tokens != 32 && chunk_tokens != 64) { set_error("retention: chunk_tokens must be 0 (default), 32 or 64"); return MAGPO_EINVAL; }
+  return MAGPO_OK;
 }
-extern "C" int magpo_retention_set_chunk_tokens(int tokens) {
-  const int prev = ret_chunk_tokens();
-  g_ret_chunk_tokens = tokens == 64 ? 64 : 32;
-  return prev;
-}
-static bool ret32(int A) { return ret_chunk_tokens() == 32 && A <= 32; }
 
 static int check_ret_shape(int T, int A, long ldq, long ldk, long ldv) {
   if (A < 1 || A > 64 || T < 1) { set_error("retention: need 1 <= A <= 64, T >= 1"); return MAGPO_EINVAL; }
@@ -667,17 +659,18 @@ static int check_ret_shape(int T, int A, long ldq, long ldk, long ldv) {
   return MAGPO_OK;
 }
 
-extern "C" int magpo_retention_num_chunks(int T, int A) { int Lt = (ret32(A) ? 32 : 64) / A; return (T + Lt - 1) / Lt; }
+extern "C" int magpo_retention_num_chunks(int T, int A, int chunk_tokens) { int Lt = (ret32(A, chunk_tokens) ? 32 : 64) / A; return (T + Lt - 1) / Lt; }
 
 extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          float* r, long ldr, const float* s0, const int* seq_env,
                                          const unsigned char* dones, float* states, float* s_final, int nseq, int T, int A,
-                                         int masked, float kappa, int hs, const int* qkv_rows, hipStream_t st) {
+                                         int masked, float kappa, int hs, const int* qkv_rows, int chunk_tokens, hipStream_t st) {
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
+  if (int e = check_chunk_tokens(chunk_tokens)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs, qkv_rows};
-  if (ret32(A)) {
-    const size_t lds32 = ret32_fwd_lds(magpo_retention_num_chunks(T, A));
+  if (ret32(A, chunk_tokens)) {
+    const size_t lds32 = ret32_fwd_lds(magpo_retention_num_chunks(T, A, chunk_tokens));
     static size_t attr32 = 0;
     if (lds32 > attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32 = lds32; }
     hipLaunchKernelGGL(k_ret32_fwd, dim3(nseq), dim3(256), lds32, st, a);
@@ -693,12 +686,13 @@ extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* 
 extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                          const float* dr, long lddr, float* dq, long lddq, float* dk, long lddk, float* dv,
                                          long lddv, const unsigned char* dones, const float* states, int nseq, int T, int A,
-                                         int masked, float kappa, int hs, const int* qkv_rows, hipStream_t st) {
+                                         int masked, float kappa, int hs, const int* qkv_rows, int chunk_tokens, hipStream_t st) {
   if (int e = check_ret_shape(T, A, ldq, ldk, ldv)) return e;
+  if (int e = check_chunk_tokens(chunk_tokens)) return e;
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs, qkv_rows};
-  if (ret32(A)) {
-    const size_t lds32 = ret32_bwd_lds(magpo_retention_num_chunks(T, A));
+  if (ret32(A, chunk_tokens)) {
+    const size_t lds32 = ret32_bwd_lds(magpo_retention_num_chunks(T, A, chunk_tokens));
     static size_t attr32 = 0;
     if (lds32 > attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32 = lds32; }
     hipLaunchKernelGGL(k_ret32_bwd, dim3(nseq), dim3(256), lds32, st, a);

@@ -260,7 +260,9 @@ class EnvGroup:
 class MagpoLearner:
     def __init__(self, env_cfg, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
                  decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 512, num_groups: int = 1,
-                 n_block: int = 1, n_head: int = 1, embed_dim: int = 64):
+                 n_block: int = 1, n_head: int = 1, embed_dim: int = 64, tuning=None):
+        from .tuning import Tuning
+        self.tuning = tuning if tuning is not None else Tuning.from_env()   # ONE object shared by both networks (tuning.py)
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
         F = env_cfg.obs_dim  # with the AgentIDWrapper's one-hot id (observation.py:42-54), add_agent_id: True
@@ -279,9 +281,9 @@ class MagpoLearner:
         self.grad_mu = torch.zeros_like(self.grad_all) if sys.micro_batches > 1 else None
         self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
                                   max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh, embed_dim=int(embed_dim),
-                                  seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn])
+                                  seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn], tuning=self.tuning)
         self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
-                              grads=self.grad_all[gn:gn + an])
+                              grads=self.grad_all[gn:gn + an], tuning=self.tuning)
         self.loss_out = self.grad_all[gn + an:gn + an + 9]
         self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb, self.nh) for _ in range(num_groups)]
         # rollout-start states of all groups in ONE tensor each (group g = envs g*N .. g*N + N - 1), so that the minibatches of all

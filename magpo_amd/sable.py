@@ -18,6 +18,7 @@ import torch
 
 from ._lib import lib
 from .params import FlatParams, WidthEmbedding, guider_layout, guider_named_views, init_guider
+from .tuning import Tuning
 
 E = 64
 
@@ -44,7 +45,9 @@ class _Bufs:
 class SableGuider:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, embed_dim: int = 64, n_head: int = 1,
                  n_block: int = 1, decay_scaling_factor: float = 0.8, use_pe: bool = True, max_pos: int = 101,
-                 wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None):
+                 wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None,
+                 tuning: Optional[Tuning] = None):
+        self.tuning = tuning if tuning is not None else Tuning.from_env()   # per-call kernel knobs (tuning.py); the library keeps none
         if embed_dim not in (16, 32, 64) or n_head not in (1, 2, 4) or n_block < 1 or embed_dim % n_head or 64 // n_head // n_head < 4:
             raise NotImplementedError("gfx950 Sable kernels: embed_dim in {16, 32, 64} (narrower nets run embedded in the 64-wide "
                                       "kernels, params.WidthEmbedding) and n_head in {1, 2, 4} (SURVEY 8f rank 3)")
@@ -150,7 +153,7 @@ class SableGuider:
         self._tp("h1_nat_pad", h1t, E)                                # [64][64]: natural W padded to 64 columns
 
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
-        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self._st())
+        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self.tuning.linear_variant, self._st())
 
     def _groups(self, R):
         """Row slabs of a split weight gradient: no more than one per 256 rows (small minibatches: fewer partials to reduce)."""
@@ -162,11 +165,11 @@ class SableGuider:
         # (with n_block > 1 the d(obs_rep) sums are accumulated in place, so the side stream is not used)
         side = self.wgrad_stream if (self.overlap_wgrad and self.nb == 1) else None
         if side is None:
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self.tuning.wgrad_variant, self._st())
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self._st())
+            self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self.tuning.wgrad_variant, self._st())
 
     def reduce(self, slab, out, P=64, stride=None, accumulate=False):
         self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P, stride or slab.shape[1], 1.0, 1 if accumulate else 0, self._st())
@@ -193,20 +196,20 @@ class SableGuider:
 
     def _ret_fwd(self, q, ldq, k, ldk, v, ldv, r, s0, seq_env, dones, name, nseq, T, masked, rows=None):
         """``rows`` (i32 [R], optional): q | k | v are row tables and token row r reads table row rows[r] (csrc/classtab.hip)."""
-        nch = self.L.call("magpo_retention_num_chunks", T, self.A)
+        nch = self.L.call("magpo_retention_num_chunks", T, self.A, self.tuning.ret_chunk_tokens)
         hs = self.hs
         for h in range(self.nh):
             o = h * hs
             stt = self.b.get(f"t_{name}_{h}", (nseq, nch, E, E))
             self.L.call("magpo_retention_chunk_fwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, r[:, o:], E, s0[h], seq_env, dones, stt,
-                        None, nseq, T, self.A, masked, self.kappas[h], hs, rows, self._st())
+                        None, nseq, T, self.A, masked, self.kappas[h], hs, rows, self.tuning.ret_chunk_tokens, self._st())
 
     def _ret_bwd(self, q, ldq, k, ldk, v, ldv, dr, dq, lddq, dk, lddk, dv, lddv, dones, name, nseq, T, masked, rows=None):
         hs = self.hs
         for h in range(self.nh):
             o = h * hs
             self.L.call("magpo_retention_chunk_bwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, dr[:, o:], E, dq[:, o:], lddq, dk[:, o:],
-                        lddk, dv[:, o:], lddv, dones, self.b.t[f"t_{name}_{h}"], nseq, T, self.A, masked, self.kappas[h], hs, rows, self._st())
+                        lddk, dv[:, o:], lddv, dones, self.b.t[f"t_{name}_{h}"], nseq, T, self.A, masked, self.kappas[h], hs, rows, self.tuning.ret_chunk_tokens, self._st())
 
     def _retpost_fwd(self, r, gp, ldg, gamma, beta, u, R):
         self.L.call("magpo_retpost_fwd", r, E, gp, ldg, gamma, beta, u, E, R, self.hs, self.gs, self._st())
@@ -322,7 +325,7 @@ class SableGuider:
         v, b = self.v, self.b
         s_enc, s_d1, s_d2 = states   # value_only (bootstrap value, rec_magpo.py:202-208): the kernel writes no state
         kdev = sample_keys if torch.is_tensor(sample_keys) else None
-        cache_key = (N, bool(value_only), obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
+        cache_key = (N, bool(value_only), self.tuning.act_envs_per_wave, obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
                      None if kdev is None else kdev.data_ptr(), s_enc.data_ptr(), s_d1.data_ptr(), s_d2.data_ptr(),
                      None if action_out is None else action_out.data_ptr(), None if logp_out is None else logp_out.data_ptr(),
                      value_out.data_ptr(), None if done is None else done.data_ptr())
@@ -347,7 +350,7 @@ class SableGuider:
                         self.wt[f"q2{k}"], self.wt[f"kvg2{k}"], self.wt[f"wo2{k}"], v[d + "ln2.scale"], v[d + "ln3.scale"],
                         v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
                         g(f"qkvg1_{k}", 4 * E), g(f"q2_{k}"), g(f"kvg2_{k}", 4 * E)]   # kvg2 rows: [k | v | - | P2] (ld 256)
-            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld], dtype=np.int32),
+            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld, self.tuning.act_envs_per_wave], dtype=np.int32),
                     np.array((self.kappas + [0.0] * 4)[:4], dtype=np.float32),
                     np.array([ptr(t) for t in glob], dtype=np.uint64), np.array([ptr(t) for t in blk], dtype=np.uint64))
             if len(self._act_tabs) > 4096:
@@ -405,7 +408,7 @@ class SableGuider:
         Returns (logits [R,64] raw with K valid columns, value [R])."""
         L, st, A, K, F, v, b, nb = self.L, self._st(), self.A, self.K, self.F, self.v, self.b, self.nb
         R = nseq * T * A
-        nch = L.call("magpo_retention_num_chunks", T, A)
+        nch = L.call("magpo_retention_num_chunks", T, A, self.tuning.ret_chunk_tokens)
         g = lambda n, w=E: b.get("t_" + n, (R, w))
         stt = lambda n: b.get("t_" + n, (nseq, nch, E, E))
         direct = classes is not None and self.fused_segments   # block-0 consumers read the class tables through the class index

@@ -1,4 +1,4 @@
-"""Acting-kernel time per launch over num_envs x envs-per-wave (MAGPO_ACT_EPW): which wave shape should magpo_sable_act pick?"""
+"""Acting-kernel time per launch over num_envs x envs-per-wave (Tuning.act_envs_per_wave): which wave shape should magpo_sable_act pick?"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -10,7 +10,7 @@ for A, K, mv, nb in ((4, 20, 60, 1), (8, 15, 100, 2)):
         l.setup(host_split(prng_key(1), 4)[0])
         res = []
         for epw in (4, 8, 16):
-            os.environ["MAGPO_ACT_EPW"] = str(epw)
+            l.tuning.act_envs_per_wave = epw   # per-call argument of magpo_sable_act (dims[11])
             g = l.groups[0]; tr = g.traj
             l._rollout_keys(g)
             def call():

@@ -1,4 +1,4 @@
-"""Acting kernel, 4 vs 16 envs per wave (MAGPO_ACT_EPW) at small and medium batches (A = 4, one block)."""
+"""Acting kernel, 4 vs 16 envs per wave (Tuning.act_envs_per_wave) at small and medium batches (A = 4, one block)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,7 +11,7 @@ for N in [int(x) for x in sys.argv[1:]] or (256, 1024, 2048, 4096, 8192):
     l._rollout_keys(g)
     res = []
     for epw in (4, 8, 16):
-        os.environ["MAGPO_ACT_EPW"] = str(epw)
+        l.tuning.act_envs_per_wave = epw   # per-call argument of magpo_sable_act (dims[11])
         def call():
             l.guider.act_fused(tr["obs"][0], tr["step_count"][0], g.sable_hs, g.skeys_host[0], tr["action"][0], tr["log_prob"][0], tr["value"][0], done=tr["done"][0])
         for _ in range(10): call()

@@ -16,12 +16,12 @@ def run(nseq, T, A, reps):
     reset = (torch.rand(nseq, T, generator=g) < 0.02).to(torch.uint8).cuda()
     out = {}
     for mode in (0, 1):
-        L.call("magpo_gru_set_split_bf16", mode)
+        SPLIT = mode
         hs = torch.empty(R, H, device="cuda"); gates = torch.empty(R, 4 * H, device="cuda"); hp = torch.empty(R, H, device="cuda")
-        L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hp, nseq, T, A, None, st)
+        L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hp, nseq, T, A, None, SPLIT, 0, st)
         torch.cuda.synchronize(); t0 = time.time()
         for _ in range(reps):
-            L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hp, nseq, T, A, None, st)
+            L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hp, nseq, T, A, None, SPLIT, 0, st)
         torch.cuda.synchronize()
         out[mode] = (hs.clone(), gates.clone(), (time.time() - t0) / reps * 1e3)
     return xi, Wh, bhn, h0, reset, out

@@ -15,16 +15,15 @@ s0 = torch.randn(nseq, 64, 64, device=dev, generator=g) * 0.1
 dones = (torch.rand(nseq, T, device=dev, generator=g) < 0.01).to(torch.uint8)
 st = torch.cuda.current_stream().cuda_stream
 for ct in (64, 32):
-    L.call("magpo_retention_set_chunk_tokens", ct)
-    nch = L.call("magpo_retention_num_chunks", T, A)
+    CT = ct
+    nch = L.call("magpo_retention_num_chunks", T, A, CT)
     states = torch.empty(nseq, nch, 64, 64, device=dev)
-    fwd = lambda: L.call("magpo_retention_chunk_fwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.775, 64, None, st)
+    fwd = lambda: L.call("magpo_retention_chunk_fwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.775, 64, None, CT, st)
     bwd = lambda: L.call("magpo_retention_chunk_bwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, dr, 64, dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256,
-                         dones, states, nseq, T, A, 1, 0.775, 64, None, st)
+                         dones, states, nseq, T, A, 1, 0.775, 64, None, CT, st)
     for name, fn in (("fwd", fwd), ("bwd", bwd)):
         fn(); fn(); torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(10): fn()
         torch.cuda.synchronize()
         print(f"chunk {ct:2d} tokens ({nch:2d} chunks): {name} {1e3 * (time.time() - t0) / 10:.3f} ms per launch")
-L.call("magpo_retention_set_chunk_tokens", 32)

@@ -1,3 +1,4 @@
+import os
 """Per-kernel micro-benchmarks at the bench shapes (R = 8192 seqs x 128 steps x 4 agents rows), HIP-event timed.
 usage: python scripts/kbench.py [wgrad] [linear] [ret] [gru] [rows] [loss]"""
 import sys, os
@@ -5,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from magpo_amd._lib import lib
 L = lib(); dev = 'cuda'
+CT, SPLIT = int(os.environ.get("MAGPO_RET_CHUNK", 0)), int(os.environ.get("MAGPO_GRU_SPLIT_BF16", 0))   # per-call tuning arguments (the library keeps no state)
 which = set(sys.argv[1:]) or {"wgrad", "linear", "ret", "gru"}
 nseq, T, A = 8192, 128, 4
 R = nseq * T * A
@@ -25,24 +27,24 @@ if "wgrad" in which:
         X = torch.randn(R, KIN, device=dev, generator=g); dY = torch.randn(R, NOUT, device=dev, generator=g)
         dW = torch.empty(KIN, NOUT, device=dev); G = 512
         ws = torch.empty(L.call("magpo_wgrad_workspace_floats", KIN, NOUT, G), device=dev)
-        timeit(f"wgrad {KIN}x{NOUT}", lambda: L.call("magpo_wgrad", X, KIN, dY, NOUT, R, KIN, KIN, NOUT, dW, None, ws, G, 1.0, 0, st),
+        timeit(f"wgrad {KIN}x{NOUT}", lambda: L.call("magpo_wgrad", X, KIN, dY, NOUT, R, KIN, KIN, NOUT, dW, None, ws, G, 1.0, 0, 0, st),
                2.0 * R * KIN * NOUT, 4.0 * R * (KIN + NOUT))
 if "linear" in which:
     for KIN, NOUT in ((64, 256), (64, 64), (64, 192), (128, 384), (128, 128), (256, 64), (384, 128), (192, 64)):
         X = torch.randn(R, KIN, device=dev, generator=g); Y = torch.empty(R, NOUT, device=dev)
         npad = (NOUT + 31) // 32 * 32
         Wt = torch.randn(npad, KIN, device=dev, generator=g)
-        timeit(f"linear {KIN}->{NOUT}", lambda: L.call("magpo_linear", X, KIN, Wt, None, Y, NOUT, None, R, KIN, NOUT, 0, st),
+        timeit(f"linear {KIN}->{NOUT}", lambda: L.call("magpo_linear", X, KIN, Wt, None, Y, NOUT, None, R, KIN, NOUT, 0, 0, st),
                2.0 * R * KIN * NOUT, 4.0 * R * (KIN + NOUT))
 if "ret" in which:
     q, k, v, dr = (torch.randn(R, 64, device=dev, generator=g) * 0.3 for _ in range(4))
     dq, dk, dv, r = (torch.empty(R, 64, device=dev) for _ in range(4))
     dones = (torch.rand(nseq, T, device=dev, generator=g) < 0.01).to(torch.uint8)
-    nch = L.call("magpo_retention_num_chunks", T, A)
+    nch = L.call("magpo_retention_num_chunks", T, A, CT)
     states = torch.empty(nseq, nch, 64, 64, device=dev); s0 = torch.zeros(nseq, 64, 64, device=dev)
-    timeit("ret_chunk_fwd", lambda: L.call("magpo_retention_chunk_fwd", q, 64, k, 64, v, 64, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.95, 64, None, st),
+    timeit("ret_chunk_fwd", lambda: L.call("magpo_retention_chunk_fwd", q, 64, k, 64, v, 64, r, 64, s0, None, dones, states, None, nseq, T, A, 1, 0.95, 64, None, CT, st),
            nseq * nch * 4 * 2.0 * 64 ** 3, 0)
-    timeit("ret_chunk_bwd", lambda: L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, None, st),
+    timeit("ret_chunk_bwd", lambda: L.call("magpo_retention_chunk_bwd", q, 64, k, 64, v, 64, dr, 64, dq, 64, dk, 64, dv, 64, dones, states, nseq, T, A, 1, 0.95, 64, None, CT, st),
            nseq * nch * 9 * 2.0 * 64 ** 3, 0)
 if "gru" in which:
     H = 128
@@ -51,10 +53,10 @@ if "gru" in which:
     bhn = torch.zeros(H, device=dev); h0 = torch.zeros(nseq * A, H, device=dev)
     reset = (torch.rand(nseq, T, device=dev, generator=g) < 0.01).to(torch.uint8)
     hs = torch.empty(R, H, device=dev); gates = torch.empty(R, 4 * H, device=dev); hprev = torch.empty(R, H, device=dev)
-    timeit("gru_scan_fwd", lambda: L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hprev, nseq, T, A, None, st), 2.0 * R * H * 3 * H, 0)
+    timeit("gru_scan_fwd", lambda: L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hprev, nseq, T, A, None, SPLIT, 0, st), 2.0 * R * H * 3 * H, 0)
     dhs = torch.randn(R, H, device=dev, generator=g) * 0.1
     dxi = torch.empty(R, 3 * H, device=dev); dhh = torch.empty(R, 3 * H, device=dev); slab = torch.empty((nseq * A + 63) // 64, H, device=dev)
-    timeit("gru_scan_bwd", lambda: L.call("magpo_gru_scan_bwd", gates, hprev, reset, dhs, Wh, dxi, dhh, slab, nseq, T, A, st), 2.0 * R * H * 3 * H, 0)
+    timeit("gru_scan_bwd", lambda: L.call("magpo_gru_scan_bwd", gates, hprev, reset, dhs, Wh, dxi, dhh, slab, nseq, T, A, SPLIT, 0, st), 2.0 * R * H * 3 * H, 0)
 if "rows" in which:
     F, K = 5, 20
     obs = torch.randn(R, F, device=dev, generator=g)

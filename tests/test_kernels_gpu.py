@@ -51,7 +51,7 @@ def test_linear(L, stream, KIN, NOUT, R, act):
     ld = (NOUT + 3) // 4 * 4
     Y = torch.zeros(R, ld, device=DEV)
     Yp = torch.zeros(R, ld, device=DEV)
-    L.call("magpo_linear", Xd, KIN, Wt, bd, Y, ld, Yp, R, KIN, NOUT, act, stream)
+    L.call("magpo_linear", Xd, KIN, Wt, bd, Y, ld, Yp, R, KIN, NOUT, act, 0, stream)
     ref = X.double() @ W.double() + b.double()
     close(Yp[:, :NOUT], ref, what="pre")
     if act == 1:
@@ -72,7 +72,7 @@ def test_wgrad(L, stream, KIN, NOUT, R):
     ws = torch.empty(L.call("magpo_wgrad_workspace_floats", KIN, NOUT, G), device=DEV)
     dW = torch.zeros(KIN, NOUT, device=DEV)
     db = torch.zeros(NOUT, device=DEV)
-    L.call("magpo_wgrad", dev(X), KIN, dev(dY), ld, R, KIN, KIN, NOUT, dW, db, ws, G, 0.5, 0, stream)
+    L.call("magpo_wgrad", dev(X), KIN, dev(dY), ld, R, KIN, KIN, NOUT, dW, db, ws, G, 0.5, 0, 0, stream)
     close(dW, 0.5 * X.double().T @ dY[:, :NOUT].double(), what="dW")
     close(db, 0.5 * dY[:, :NOUT].double().sum(0), what="db")
 
@@ -89,7 +89,7 @@ def test_linear_shared_tile(L, stream, KIN, NOUT, R, act):
     Wt = transpose_pad(L, stream, dev(W))
     ld = (NOUT + 3) // 4 * 4
     Y = torch.full((R + 1, ld), 7.0, device=DEV)   # guard row: nothing may be written past R
-    L.call("magpo_linear", dev(X), KIN, Wt, dev(b), Y, ld, None, R, KIN, NOUT, act, stream)
+    L.call("magpo_linear", dev(X), KIN, Wt, dev(b), Y, ld, None, R, KIN, NOUT, act, 0, stream)
     ref = X.double() @ W.double() + b.double()
     if act == 1:
         ref = torch.relu(ref)
@@ -108,7 +108,7 @@ def test_linear_relu_mask_epilogue(L, stream):
     M = torch.relu(torch.randn(R, NOUT, generator=g))
     Wt = transpose_pad(L, stream, dev(W))
     Y = torch.zeros(R, NOUT, device=DEV)
-    L.call("magpo_linear", dev(X), KIN, Wt, None, Y, NOUT, dev(M), R, KIN, NOUT, 4, stream)
+    L.call("magpo_linear", dev(X), KIN, Wt, None, Y, NOUT, dev(M), R, KIN, NOUT, 4, 0, stream)
     close(Y, (X.double() @ W.double()) * (M > 0), what="masked dX")
 
 
@@ -123,21 +123,17 @@ def test_wgrad_whole_matrix(L, stream, KIN, NOUT, R, G):
     ws = torch.empty(L.call("magpo_wgrad_workspace_floats", KIN, NOUT, G), device=DEV)
     dW = torch.zeros(KIN, NOUT, device=DEV)
     db = torch.zeros(NOUT, device=DEV)
-    L.call("magpo_wgrad", dev(X), KIN, dev(dY), NOUT, R, KIN, KIN, NOUT, dW, db, ws, G, 1.0, 0, stream)
+    L.call("magpo_wgrad", dev(X), KIN, dev(dY), NOUT, R, KIN, KIN, NOUT, dW, db, ws, G, 1.0, 0, 0, stream)
     close(dW, X.double().T @ dY.double(), what="dW")
     close(db, dY.double().sum(0), what="db")
 
 
 @pytest.mark.parametrize("rows", [64, 32])
 def test_gru_carry_equals_stepwise_scan(L, stream, rows):
-    prev_rows = L.call("magpo_gru_set_block_rows", rows)
-    try:
-        _gru_carry_case(L, stream)
-    finally:
-        L.call("magpo_gru_set_block_rows", prev_rows)
+    _gru_carry_case(L, stream, rows)
 
 
-def _gru_carry_case(L, stream):
+def _gru_carry_case(L, stream, rows):
     """magpo_gru_carry (time-major rollout trajectory, last state only) == the sequence-major scan on the same data; and xi rows
     taken through a class table (xi_cls, csrc/classtab.hip) == the materialised rows, in both row layouts, bit for bit."""
     N, T, A, H = 37, 9, 3, 128
@@ -151,23 +147,23 @@ def _gru_carry_case(L, stream):
     h0 = torch.randn(N * A, H, generator=g) * 0.3
     reset_tm = (torch.rand(T, N, generator=g) < 0.2).to(torch.uint8)
     h_last = torch.zeros(N * A, H, device=DEV)
-    L.call("magpo_gru_carry", dev(xi_tm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last, N, T, A, None, stream)
+    L.call("magpo_gru_carry", dev(xi_tm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last, N, T, A, None, rows, stream)
     xi_sm = xi_tm.permute(1, 0, 2, 3).contiguous()                     # rows (env, t, agent)
     hs = torch.zeros(N * T * A, H, device=DEV)
     L.call("magpo_gru_scan_fwd", dev(xi_sm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), None, dev(reset_tm.t().contiguous()), hs, None, None,
-           N, T, A, None, stream)
+           N, T, A, None, 0, rows, stream)
     ref = hs.view(N, T, A, H)[:, T - 1].reshape(N * A, H)
     assert torch.equal(h_last, ref)
     h_last2 = torch.zeros(N * A, H, device=DEV)
-    L.call("magpo_gru_carry", dev(tab), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last2, N, T, A, dev(cls_tm.reshape(-1)), stream)
+    L.call("magpo_gru_carry", dev(tab), dev(Wht), dev(bhn), dev(h0), dev(reset_tm), h_last2, N, T, A, dev(cls_tm.reshape(-1)), rows, stream)
     assert torch.equal(h_last2, h_last)
     hs2 = torch.zeros(N * T * A, H, device=DEV); gates = [torch.zeros(N * T * A, 4 * H, device=DEV) for _ in range(2)]
     hp = [torch.zeros(N * T * A, H, device=DEV) for _ in range(2)]
     cls_sm = cls_tm.permute(1, 0, 2).contiguous().reshape(-1)
     L.call("magpo_gru_scan_fwd", dev(xi_sm.reshape(-1, 3 * H)), dev(Wht), dev(bhn), dev(h0), None, dev(reset_tm.t().contiguous()), hs, gates[0], hp[0],
-           N, T, A, None, stream)
+           N, T, A, None, 0, rows, stream)
     L.call("magpo_gru_scan_fwd", dev(tab), dev(Wht), dev(bhn), dev(h0), None, dev(reset_tm.t().contiguous()), hs2, gates[1], hp[1],
-           N, T, A, dev(cls_sm), stream)
+           N, T, A, dev(cls_sm), 0, rows, stream)
     assert torch.equal(hs2, hs) and torch.equal(gates[0], gates[1]) and torch.equal(hp[0], hp[1])
 
 
@@ -349,14 +345,10 @@ def _ret_reference(q, k, v, s0, dones_t, A, kappa, masked):
 @pytest.mark.parametrize("ct", [64, 32])
 def test_retention_chunk(L, stream, A, T, masked, hs, ct):
     """ct = tokens per chunk: the 64-token kernels (one workgroup per CU in the backward) or the 32-token ones (retention32.hpp)."""
-    prev = L.call("magpo_retention_set_chunk_tokens", ct)
-    try:
-        _retention_chunk_case(L, stream, A, T, masked, hs)
-    finally:
-        L.call("magpo_retention_set_chunk_tokens", prev)
+    _retention_chunk_case(L, stream, A, T, masked, hs, ct)
 
 
-def _retention_chunk_case(L, stream, A, T, masked, hs):
+def _retention_chunk_case(L, stream, A, T, masked, hs, ct):
     g = torch.Generator().manual_seed(5)
     B, kappa = 5, 0.775
     C = T * A
@@ -369,7 +361,7 @@ def _retention_chunk_case(L, stream, A, T, masked, hs):
     qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
     ref = _ret_reference(qd, kd, vd, s0.double(), dones, A, kappa, bool(masked))
     (ref * dr.double()).sum().backward()
-    nch = L.call("magpo_retention_num_chunks", T, A)
+    nch = L.call("magpo_retention_num_chunks", T, A, ct)
     assert nch >= 3 or hs == 64
     # q, k, v live in one [R, 256] buffer like the fused projection output; with narrow heads the neighbouring columns hold the
     # other heads' data (random here): the kernel must neither read them into the product nor write over them
@@ -385,13 +377,13 @@ def _retention_chunk_case(L, stream, A, T, masked, hs):
     s0_store[perm.long(), :hs, :hs] = s0
     dn = dev(dones.to(torch.uint8))
     L.call("magpo_retention_chunk_fwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, r, 64, dev(s0_store), dev(perm),
-           dn, states, sfin, B, T, A, masked, kappa, hs, None, stream)
+           dn, states, sfin, B, T, A, masked, kappa, hs, None, ct, stream)
     close(r[:, :hs].reshape(B, C, hs), ref, 1e-4, 1e-5, "ret fwd")
     if hs < 64:
         assert bool((r[:, hs:] == 7.0).all()), "columns of the neighbouring heads were written"
     dbuf = torch.full((B * C, 256), 9.0, device=DEV)
     L.call("magpo_retention_chunk_bwd", buf, 256, buf[:, 64:], 256, buf[:, 128:], 256, drb, 64,
-           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, None, stream)
+           dbuf, 256, dbuf[:, 64:], 256, dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, None, ct, stream)
     close(dbuf[:, 0:hs].reshape(B, C, hs), qd.grad, 1e-4, 1e-5, "dq")
     close(dbuf[:, 64:64 + hs].reshape(B, C, hs), kd.grad, 1e-4, 1e-5, "dk")
     close(dbuf[:, 128:128 + hs].reshape(B, C, hs), vd.grad, 1e-4, 1e-5, "dv")
@@ -412,14 +404,10 @@ def _retention_chunk_case(L, stream, A, T, masked, hs):
 @pytest.mark.parametrize("A,T,masked,hs", [(4, 128, 0, 64), (4, 40, 1, 64), (8, 128, 1, 64), (5, 30, 1, 64), (3, 70, 1, 16), (4, 8, 1, 64)])
 @pytest.mark.parametrize("ct", [64, 32])
 def test_retention_chunk_row_table(L, stream, A, T, masked, hs, ct):
-    prev = L.call("magpo_retention_set_chunk_tokens", ct)
-    try:
-        _retention_row_table_case(L, stream, A, T, masked, hs)
-    finally:
-        L.call("magpo_retention_set_chunk_tokens", prev)
+    _retention_row_table_case(L, stream, A, T, masked, hs, ct)
 
 
-def _retention_row_table_case(L, stream, A, T, masked, hs):
+def _retention_row_table_case(L, stream, A, T, masked, hs, ct):
     """q | k | v read through a row table (block-0 projections on the distinct input rows, csrc/classtab.hip) == the same rows
     gathered per token first: outputs, saved chunk states and all three gradients bit-identical (forward and backward, one to many
     chunks, ragged last chunk, narrow head)."""
@@ -435,16 +423,16 @@ def _retention_row_table_case(L, stream, A, T, masked, hs):
     s0 = dev(torch.randn(B, 64, 64, generator=g) * 0.3)
     if hs < 64:
         s0[:, hs:, :] = 0; s0[:, :, hs:] = 0
-    nch = L.call("magpo_retention_num_chunks", T, A)
+    nch = L.call("magpo_retention_num_chunks", T, A, ct)
     out = []
     for src, ridx in ((buf, None), (tab, rows)):
         r = torch.full((R, 64), 7.0, device=DEV)
         states = torch.zeros(B, nch, 64, 64, device=DEV); sfin = torch.zeros(B, 64, 64, device=DEV)
         L.call("magpo_retention_chunk_fwd", src, 256, src[:, 64:], 256, src[:, 128:], 256, r, 64, s0, None, dn, states, sfin, B, T, A,
-               masked, kappa, hs, ridx, stream)
+               masked, kappa, hs, ridx, ct, stream)
         dbuf = torch.full((R, 256), 9.0, device=DEV)
         L.call("magpo_retention_chunk_bwd", src, 256, src[:, 64:], 256, src[:, 128:], 256, drb, 64, dbuf, 256, dbuf[:, 64:], 256,
-               dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, ridx, stream)
+               dbuf[:, 128:], 256, dn, states, B, T, A, masked, kappa, hs, ridx, ct, stream)
         out.append((r, states, sfin, dbuf))
     for x, y, what in zip(out[0], out[1], ("ret", "chunk states", "final state", "dq | dk | dv")):
         assert torch.equal(x, y), what
@@ -475,16 +463,10 @@ def test_retention_recurrent(L, stream):
 def test_gru_scan(L, stream, split, rows):
     """split = 1: the training scans on split-bf16 x3 MFMA (products hi*hi + hi*lo + lo*hi, ~2^-16 relative) instead of fp32 MFMA:
     same tolerances against the fp64 oracle."""
-    prev = L.call("magpo_gru_set_split_bf16", split)
-    prev_rows = L.call("magpo_gru_set_block_rows", rows)   # both block sizes (by size alone this case would only ever run 32-row blocks)
-    try:
-        _gru_scan_case(L, stream)
-    finally:
-        L.call("magpo_gru_set_split_bf16", prev)
-        L.call("magpo_gru_set_block_rows", prev_rows)
+    _gru_scan_case(L, stream, split, rows)   # both block sizes (by size alone this case would only ever run 32-row blocks)
 
 
-def _gru_scan_case(L, stream):
+def _gru_scan_case(L, stream, split, rows):
     g = torch.Generator().manual_seed(7)
     nseq, T, A, F, K, H = 21, 9, 4, 5, 20, 128
     p = onets.init_actor_params(3, F, H, K, dtype=torch.float64)
@@ -512,7 +494,7 @@ def _gru_scan_case(L, stream):
     Wh = torch.cat([p["gru.hr.kernel"], p["gru.hz.kernel"], p["gru.hn.kernel"]], 1).detach().float()
     R = nseq * T * A
     xi = torch.empty(R, 3 * H, device=DEV)
-    L.call("magpo_linear", dev(to_rows(emb)), H, transpose_pad(L, stream, dev(Wi)), dev(bi), xi, 3 * H, None, R, H, 3 * H, 0, stream)
+    L.call("magpo_linear", dev(to_rows(emb)), H, transpose_pad(L, stream, dev(Wi)), dev(bi), xi, 3 * H, None, R, H, 3 * H, 0, 0, stream)
     hsd = torch.empty(R, H, device=DEV); gates = torch.empty(R, 4 * H, device=DEV); hprev = torch.empty(R, H, device=DEV)
     perm = torch.randperm(nseq * A, generator=g).int()
     h0_store = torch.zeros(nseq * A, H)
@@ -520,25 +502,25 @@ def _gru_scan_case(L, stream):
     rs = dev(done.to(torch.uint8))
     Wht = transpose_pad(L, stream, dev(Wh))
     L.call("magpo_gru_scan_fwd", xi, Wht, dev(p["gru.hn.bias"].detach().float()), dev(h0_store), dev(perm), rs, hsd, gates, hprev,
-           nseq, T, A, None, stream)
+           nseq, T, A, None, split, rows, stream)
     close(hsd, to_rows(hs), 1e-4, 1e-5, "hs")
     dxi = torch.empty(R, 3 * H, device=DEV); dhh = torch.empty(R, 3 * H, device=DEV)
     nblk = (nseq * A + 63) // 64
     slab = torch.zeros(nblk, H, device=DEV)
-    L.call("magpo_gru_scan_bwd", gates, hprev, rs, dev(to_rows(dhs)), dev(Wh), dxi, dhh, slab, nseq, T, A, stream)
+    L.call("magpo_gru_scan_bwd", gates, hprev, rs, dev(to_rows(dhs)), dev(Wh), dxi, dhh, slab, nseq, T, A, split, rows, stream)
     # check through the parameter gradients
     G = 3
     ws = torch.empty(L.call("magpo_wgrad_workspace_floats", H, 3 * H, G), device=DEV)
     dWi = torch.zeros(H, 3 * H, device=DEV); dbi = torch.zeros(3 * H, device=DEV); dWh = torch.zeros(H, 3 * H, device=DEV)
-    L.call("magpo_wgrad", dev(to_rows(emb)), H, dxi, 3 * H, R, H, H, 3 * H, dWi, dbi, ws, G, 1.0, 0, stream)
-    L.call("magpo_wgrad", hprev, H, dhh, 3 * H, R, H, H, 3 * H, dWh, None, ws, G, 1.0, 0, stream)
+    L.call("magpo_wgrad", dev(to_rows(emb)), H, dxi, 3 * H, R, H, H, 3 * H, dWi, dbi, ws, G, 1.0, 0, 0, stream)
+    L.call("magpo_wgrad", hprev, H, dhh, 3 * H, R, H, H, 3 * H, dWh, None, ws, G, 1.0, 0, 0, stream)
     refWi = torch.cat([p["gru.ir.kernel"].grad, p["gru.iz.kernel"].grad, p["gru.in.kernel"].grad], 1)
     refWh = torch.cat([p["gru.hr.kernel"].grad, p["gru.hz.kernel"].grad, p["gru.hn.kernel"].grad], 1)
     refbi = torch.cat([p["gru.ir.bias"].grad, p["gru.iz.bias"].grad, p["gru.in.bias"].grad])
     close(dWi, refWi, 1e-4, 1e-5, "dWi"); close(dWh, refWh, 1e-4, 1e-5, "dWh"); close(dbi, refbi, 1e-4, 1e-5, "dbi")
     close(_slabsum(slab), p["gru.hn.bias"].grad, 1e-4, 1e-5, "dbhn")
     demb = torch.empty(R, H, device=DEV)
-    L.call("magpo_linear", dxi, 3 * H, dev(Wi), None, demb, H, None, R, 3 * H, H, 0, stream)
+    L.call("magpo_linear", dxi, 3 * H, dev(Wi), None, demb, H, None, R, 3 * H, H, 0, 0, stream)
     close(demb, to_rows(emb.grad), 1e-4, 1e-5, "demb")
 
 
