@@ -35,15 +35,19 @@ int magpo_threefry_random_bits(const uint32_t* key, uint32_t* out, long num, mag
 int magpo_key_split_host(const uint32_t* key_host, int num, uint32_t* out_host);
 int magpo_random_bits_host(const uint32_t* key_host, int num, uint32_t* out_host);
 
-/* ---- K1 CoordSum env + wrappers (coordsum/env.py:55-139, wrappers/{matrax,observation,auto_reset_wrapper,episode_metrics}.py) ---- */
+/* ---- K1 CoordSum env + wrappers (coordsum/env.py:55-139, wrappers/{matrax,observation,auto_reset_wrapper,episode_metrics}.py) ----
+ * The step entry points of all three envs write one TimeStep (mava/types.py:45-123 MarlEnv.step): reward [N][A], discount [N][A]
+ * (nullable: the MAGPO learner never reads it), done [N] = timestep.last(), the next observation (the reset observation after an
+ * auto-reset), observation.step_count, the action mask where the env has one, and extras["episode_metrics"] (m_ep_ret, m_ep_len,
+ * m_term [N]).  Env state is updated in place. */
 int magpo_coordsum_reset(int* step_count, int* target, int* record, uint32_t* key, uint32_t* metrics_key,
                          float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A, int K, int TLIM,
                          int maxval, const uint32_t* env_keys, float* obs, int* obs_step, magpo_stream_t stream);
 int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key, uint32_t* metrics_key,
                         float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A, int K, int TLIM,
-                        int maxval, const int* actions, int act_stride, float* reward, unsigned char* done,
-                        float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
-                        int auto_reset, magpo_stream_t stream);
+                        int maxval, const int* actions, int act_stride, float* reward, float* discount,
+                        unsigned char* done, float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len,
+                        unsigned char* m_term, int auto_reset, magpo_stream_t stream);
 
 /* ---- Level-Based Foraging env + wrappers (mava/wrappers/jumanji.py:171-220 LbfWrapper with the always-on team reward, AgentID, AutoReset,
  * RecordEpisodeMetrics; the env itself is jumanji LevelBasedForaging-v0 with RandomGenerator(grid_size, fov, num_agents, num_food,
@@ -58,9 +62,9 @@ int magpo_lbf_reset(int* agent_pos, int* agent_level, int* food_pos, int* food_l
 int magpo_lbf_step(int* agent_pos, int* agent_level, int* food_pos, int* food_level, unsigned char* food_eaten,
                    int* step_count, uint32_t* key, uint32_t* metrics_key, float* run_ret, int* run_len, float* ep_ret,
                    int* ep_len, int N, int A, int NF, int G, int fov, int max_level, int force_coop, int time_limit,
-                   const int* actions, int act_stride, float* reward, unsigned char* done, float* obs, int* obs_step,
-                   unsigned char* mask, float* m_ep_ret, int* m_ep_len, unsigned char* m_term, int auto_reset,
-                   magpo_stream_t stream);
+                   const int* actions, int act_stride, float* reward, float* discount, unsigned char* done, float* obs,
+                   int* obs_step, unsigned char* mask, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
+                   int auto_reset, magpo_stream_t stream);
 
 /* ---- Robot Warehouse env + wrappers (mava/wrappers/jumanji.py:137-168 RwareWrapper, AgentID, AutoReset, RecordEpisodeMetrics; the env
  * itself is jumanji RobotWarehouse-v0 with RandomGenerator(column_height, shelf_rows, shelf_columns, num_agents, sensor_range,
@@ -79,8 +83,8 @@ int magpo_rware_step(int* grid_a, int* grid_s, int* agent_pos, int* agent_dir, u
                      unsigned char* shelf_req, int* queue, int* step_count, unsigned char* amask, uint32_t* key,
                      uint32_t* metrics_key, float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A,
                      int column_height, int shelf_rows, int shelf_columns, int sensor_range, int queue_size,
-                     int time_limit, const int* actions, int act_stride, float* reward, unsigned char* done,
-                     float* obs, long ldo, int* obs_step, unsigned char* mask, float* m_ep_ret, int* m_ep_len,
+                     int time_limit, const int* actions, int act_stride, float* reward, float* discount,
+                     unsigned char* done, float* obs, long ldo, int* obs_step, unsigned char* mask, float* m_ep_ret, int* m_ep_len,
                      unsigned char* m_term, int auto_reset, magpo_stream_t stream);
 
 /* input classes of wrapped CoordSum tokens (first-layer tables, csrc/classtab.hip): cls_enc = ((agent * maxval + target) * npos + pos),

@@ -16,4 +16,4 @@ int check_launch(const char* what) {
 }  // namespace magpo
 
 extern "C" const char* magpo_last_error() { return magpo::g_last_error.c_str(); }
-extern "C" int magpo_abi_version() { return 1; }
+extern "C" int magpo_abi_version() { return 2; }   // 2: per-call tuning arguments (no setters), discount output of the env steps

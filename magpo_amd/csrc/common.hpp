@@ -119,4 +119,30 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
   return -logf(-logf(u));
 }
 
+// jax.random.uniform(key, shape) element from raw bits: [0, 1) on the 2^-23 grid
+__device__ __forceinline__ float uniform01_from_bits(uint32_t bits) { return __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f; }
+// the gumbel of the sampling kernels: both logs in double, rounded once to fp32 (bit-identical to oracle/prng.py:bits_to_gumbel)
+__device__ __forceinline__ float gumbel_exact_from_bits(uint32_t bits) {
+  const float f = __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f;
+  const float u = fmaxf(1.17549435e-38f, f + 1.17549435e-38f);
+  return (float)(-log(-log((double)u)));
+}
+// jax.random.choice(key, n, shape=(), p=mask) (replace=True) over a bit mask of up to 256 cells (oracle/prng.py:choice):
+// p_cuml = cumsum(mask); r = p_cuml[-1] * (1 - uniform(key, ())); searchsorted(p_cuml, r, side='left') = the first cell whose
+// cumulative count reaches r.  The counts are integers, so that cell is the ceil(r)-th set bit; an all-zero mask gives cell 0.
+__device__ __forceinline__ int choice_mask_cumsum(const unsigned long long (&m)[4], uint32_t k0, uint32_t k1) {
+  const int total = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+  const float r = __fmul_rn((float)total, 1.0f - uniform01_from_bits(random_bits32(k0, k1, 0u)));
+  int cum = 0;
+  for (int w = 0; w < 4; ++w) {
+    unsigned long long bits = m[w];
+    while (bits) {
+      const int b = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      if ((float)(++cum) >= r) return 64 * w + b;
+    }
+  }
+  return 0;
+}
+
 }  // namespace magpo

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_coordsum_reset(CoordSumState s, CoordSu
 
 struct StepOut {
   float* reward;          // [N][A]
+  float* discount;        // [N][A] or NULL: 0 on termination (done), 1 otherwise (timestep.discount)
   unsigned char* done;    // [N]   timestep.last()
   float* obs;             // [N][A][A+1]  next observation (reset obs after auto-reset)
   int* obs_step;          // [N]          observation.step_count
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void k_coordsum_step(CoordSumState s, CoordSum
     obs_step = 0;
   }
   for (int a = lane; a < c.A; a += 64) o.reward[n * c.A + a] = reward;
+  if (o.discount) for (int a = lane; a < c.A; a += 64) o.discount[n * c.A + a] = done ? 0.f : 1.f;   // termination() at the time limit (coordsum/env.py:121-129)
   write_obs(o.obs, o.obs_step, n, c, obs_target, obs_step, lane);
   if (lane == 0) {
     o.done[n] = done ? 1 : 0;
@@ -179,14 +181,14 @@ extern "C" int magpo_coordsum_reset(int* step_count, int* target, int* record, u
 
 extern "C" int magpo_coordsum_step(int* step_count, int* target, int* record, uint32_t* key, uint32_t* metrics_key,
                                    float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A, int K, int TLIM,
-                                   int maxval, const int* actions, int act_stride, float* reward, unsigned char* done,
-                                   float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
+                                   int maxval, const int* actions, int act_stride, float* reward, float* discount,
+                                   unsigned char* done, float* obs, int* obs_step, float* m_ep_ret, int* m_ep_len, unsigned char* m_term,
                                    int auto_reset, hipStream_t st) {
   if (int e = check_cfg(N, A, K, TLIM)) return e;
   if (N == 0) return MAGPO_OK;
   CoordSumState s{step_count, target, record, key, metrics_key, run_ret, run_len, ep_ret, ep_len};
   CoordSumCfg c{N, A, K, TLIM, maxval};
-  StepOut o{reward, done, obs, obs_step, m_ep_ret, m_ep_len, m_term};
+  StepOut o{reward, discount, done, obs, obs_step, m_ep_ret, m_ep_len, m_term};
   hipLaunchKernelGGL(k_coordsum_step, dim3((N + 3) / 4), dim3(256), 0, st, s, c, actions, act_stride, o, auto_reset);
   return check_launch("magpo_coordsum_step");
 }

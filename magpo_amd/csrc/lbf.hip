@@ -44,21 +44,6 @@ __device__ __forceinline__ int lbf_randint(uint32_t k0, uint32_t k1, uint32_t i,
   mult = (mult * mult) % span;
   return lo + (int)(((h % span) * mult + (l % span)) % span);
 }
-// the (bits mod n)-th set bit of a G*G <= 256-cell validity mask in row-major order
-__device__ __forceinline__ int draw_cell(const unsigned long long (&valid)[4], uint32_t k0, uint32_t k1) {
-  const int n = __popcll(valid[0]) + __popcll(valid[1]) + __popcll(valid[2]) + __popcll(valid[3]);
-  int j = (int)(rb32(k0, k1) % (uint32_t)(n > 0 ? n : 1));
-  for (int w = 0; w < 4; ++w) {
-    const int pc = __popcll(valid[w]);
-    if (j < pc) {
-      unsigned long long m = valid[w];
-      for (int t = 0; t < j; ++t) m &= m - 1;
-      return 64 * w + __ffsll((long long)m) - 1;
-    }
-    j -= pc;
-  }
-  return 0;
-}
 __device__ __forceinline__ void clr(unsigned long long (&m)[4], int cell) { m[cell >> 6] &= ~(1ull << (cell & 63)); }
 
 // RandomGenerator.__call__ (see oracle/lbf.py:_generate); returns the State.key
@@ -80,7 +65,7 @@ __device__ __forceinline__ void lbf_generate(const LbfCfg& c, uint32_t k0, uint3
   for (int f = 0; f < c.NF; ++f) {
     uint32_t s0, s1;
     threefry2x32(kf0, kf1, 0u, (uint32_t)f, s0, s1);
-    const int cell = draw_cell(valid, s0, s1);
+    const int cell = choice_mask_cumsum(valid, s0, s1);   // take_positions: choice(key_f, G*G, (), p=mask)
     const int r = cell / G, q = cell - r * G;
     e.fr[f] = r; e.fc[f] = q; e.fe[f] = false;
     clr(valid, cell);
@@ -90,13 +75,26 @@ __device__ __forceinline__ void lbf_generate(const LbfCfg& c, uint32_t k0, uint3
     if (q > 0) clr(valid, cell - 1);
     clr(freec, cell);
   }
-  for (int a = 0; a < c.A; ++a) {
-    uint32_t s0, s1;
-    threefry2x32(ka0, ka1, 0u, (uint32_t)a, s0, s1);
-    const int cell = draw_cell(freec, s0, s1);
-    e.ar[a] = cell / G; e.ac[a] = cell - e.ar[a] * G;
-    clr(freec, cell);
-    e.al[a] = lbf_randint(kal0, kal1, (uint32_t)a, 1, c.max_level + 1);
+  // sample_agents: ONE choice(key_agents, G*G, (A,), replace=False, p=mask) = Gumbel top-k (oracle/prng.py:choice): cell i carries
+  // g_i = gumbel(key, (G*G,))[i] + log(mask_i); the A largest in descending order, equal values by lower index.  Cells with food
+  // (log 0 = -inf) come last, in index order, exactly as a stable descending sort leaves them.
+  {
+    float bg[LBF_MAXA];
+    int bc[LBF_MAXA];
+    for (int a = 0; a < c.A; ++a) { bg[a] = -INFINITY; bc[a] = -1; }
+    for (int cell = 0; cell < G * G; ++cell) {
+      const bool ok = (freec[cell >> 6] >> (cell & 63)) & 1ull;
+      const float g = ok ? gumbel_exact_from_bits(random_bits32(ka0, ka1, (uint32_t)cell)) : -INFINITY;
+      // insert behind every entry that is >= g (earlier cells win ties); empty slots (bc < 0) lose against everything
+      int pos = c.A;
+      for (int a = c.A - 1; a >= 0; --a) if (bc[a] < 0 || g > bg[a]) pos = a;
+      for (int a = c.A - 1; a > pos; --a) { bg[a] = bg[a - 1]; bc[a] = bc[a - 1]; }
+      if (pos < c.A) { bg[pos] = g; bc[pos] = cell; }
+    }
+    for (int a = 0; a < c.A; ++a) {
+      e.ar[a] = bc[a] / G; e.ac[a] = bc[a] - e.ar[a] * G;
+      e.al[a] = lbf_randint(kal0, kal1, (uint32_t)a, 1, c.max_level + 1);
+    }
   }
   // sum of the (up to) three smallest agent levels
   int m1 = 1 << 30, m2 = 1 << 30, m3 = 1 << 30;
@@ -190,7 +188,7 @@ __global__ __launch_bounds__(64) void k_lbf_reset(LbfState s, LbfCfg c, const ui
 }
 
 struct LbfOut {
-  float* reward; unsigned char* done; float* obs; int* obs_step; unsigned char* mask;
+  float* reward; float* discount; unsigned char* done; float* obs; int* obs_step; unsigned char* mask;
   float* m_ep_ret; int* m_ep_len; unsigned char* m_term;
 };
 
@@ -258,6 +256,7 @@ __global__ __launch_bounds__(64) void k_lbf_step(LbfState s, LbfCfg c, const int
   lbf_observe(c, e, o.obs + n * (long)A * F, o.mask + n * (long)A * LBF_NACT);
   o.obs_step[n] = obs_step;
   for (int a = 0; a < A; ++a) o.reward[n * A + a] = team;
+  if (o.discount) for (int a = 0; a < A; ++a) o.discount[n * A + a] = all ? 0.f : 1.f;   // termination = all food eaten; the time limit truncates (discount 1)
   o.done[n] = done ? 1 : 0;
   // episode_metrics.py:79-112: mean over agents of the (identical) team rewards, as a sum / A in fp32
   float msum = 0.f;
@@ -284,6 +283,11 @@ static int lbf_check(const LbfCfg& c) {
     set_error("lbf: 1 <= num_agents <= 8, 1 <= num_food <= 8, 3 <= grid_size <= 16");
     return MAGPO_EINVAL;
   }
+  // every food draw must find a valid cell whatever came before it: a food blocks at most 5 interior cells; and the agents need free cells
+  if ((c.G - 2) * (c.G - 2) < 5 * (c.NF - 1) + 1 || c.G * c.G - c.NF < c.A) {
+    set_error("lbf: the grid cannot hold that many food items / agents (need (G - 2)^2 >= 5 (num_food - 1) + 1 and G^2 - num_food >= num_agents)");
+    return MAGPO_EINVAL;
+  }
   return MAGPO_OK;
 }
 
@@ -302,13 +306,13 @@ extern "C" int magpo_lbf_reset(int* agent_pos, int* agent_level, int* food_pos, 
 extern "C" int magpo_lbf_step(int* agent_pos, int* agent_level, int* food_pos, int* food_level, unsigned char* food_eaten, int* step_count,
                               uint32_t* key, uint32_t* metrics_key, float* run_ret, int* run_len, float* ep_ret, int* ep_len, int N, int A,
                               int NF, int G, int fov, int max_level, int force_coop, int time_limit, const int* actions, int act_stride,
-                              float* reward, unsigned char* done, float* obs, int* obs_step, unsigned char* mask, float* m_ep_ret,
+                              float* reward, float* discount, unsigned char* done, float* obs, int* obs_step, unsigned char* mask, float* m_ep_ret,
                               int* m_ep_len, unsigned char* m_term, int auto_reset, hipStream_t st) {
   LbfState s{agent_pos, agent_level, food_pos, food_level, food_eaten, step_count, key, metrics_key, run_ret, run_len, ep_ret, ep_len};
   LbfCfg c{N, A, NF, G, fov, max_level, force_coop, time_limit};
   if (int e = lbf_check(c)) return e;
   if (N <= 0) return MAGPO_OK;
-  LbfOut o{reward, done, obs, obs_step, mask, m_ep_ret, m_ep_len, m_term};
+  LbfOut o{reward, discount, done, obs, obs_step, mask, m_ep_ret, m_ep_len, m_term};
   hipLaunchKernelGGL(k_lbf_step, dim3((N + 63) / 64), dim3(64), 0, st, s, c, actions, act_stride, o, auto_reset);
   return check_launch("magpo_lbf_step");
 }

@@ -41,6 +41,29 @@ __device__ __forceinline__ int rw_randint4(uint32_t k0, uint32_t k1, uint32_t i)
   return (int)(((h % 4u) * mult + (l % 4u)) % 4u);
 }
 
+// jax.random.choice(key, n, (num,), replace=False) without p = permutation(key, n)[:num] (oracle/prng.py:choice / permutation): for
+// n < 1626 the shuffle is ONE round -- key, sub = split(key); stable sort of 0..n-1 by random_bits(sub, n) -- so the prefix is the num
+// smallest (bits, index) pairs in order.  num <= RW_MAXPICK.
+constexpr int RW_MAXPICK = 16;
+__device__ __forceinline__ void rw_perm_prefix(uint32_t k0, uint32_t k1, int n, int num, int* __restrict__ out) {
+  uint32_t s0, s1;
+  threefry2x32(k0, k1, 0u, 1u, s0, s1);   // sub = split(key)[1]
+  uint32_t bb[RW_MAXPICK];
+  int bi[RW_MAXPICK];
+  int filled = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint32_t b = random_bits32(s0, s1, (uint32_t)i);
+    int pos = filled;                       // behind every entry with bits <= b (earlier indices win ties)
+    for (int a = filled - 1; a >= 0; --a) if (b < bb[a]) pos = a;
+    if (pos >= num) continue;
+    const int last = filled < num ? filled : num - 1;
+    for (int a = last; a > pos; --a) { bb[a] = bb[a - 1]; bi[a] = bi[a - 1]; }
+    bb[pos] = b; bi[pos] = i;
+    if (filled < num) ++filled;
+  }
+  for (int a = 0; a < num; ++a) out[a] = bi[a];
+}
+
 __device__ __forceinline__ void rw_mask(const RwCfg& c, const RwState& s, long n) {
   const int HW = c.H * c.W;
   const int* ga = s.grid_a + n * HW; const int* gs = s.grid_s + n * HW;
@@ -68,14 +91,10 @@ __device__ __forceinline__ void rw_generate(const RwCfg& c, const RwState& s, lo
       ga[y * c.W + x] = 0;
       gs[y * c.W + x] = rw_highway(c, y, x) ? 0 : ++sid;
     }
-  for (int a = 0; a < c.A; ++a) {   // the (bits mod n)-th free cell, cells taken by earlier agents excluded
-    uint32_t s0, s1;
-    threefry2x32(kp0, kp1, 0u, (uint32_t)a, s0, s1);
-    int j = (int)(random_bits32(s0, s1, 0u) % (uint32_t)(HW - a));
-    int cell = 0;
-    for (int i = 0; i < HW; ++i) {
-      if (ga[i] == 0) { if (j == 0) { cell = i; break; } --j; }
-    }
+  int picks[RW_MAXPICK];
+  rw_perm_prefix(kp0, kp1, HW, c.A, picks);   // agent cells: choice(key_pos, H*W, (A,), replace=False)
+  for (int a = 0; a < c.A; ++a) {
+    const int cell = picks[a];
     ga[cell] = a + 1;
     s.agent_pos[(n * c.A + a) * 2] = cell / c.W;
     s.agent_pos[(n * c.A + a) * 2 + 1] = cell % c.W;
@@ -84,16 +103,10 @@ __device__ __forceinline__ void rw_generate(const RwCfg& c, const RwState& s, lo
   }
   unsigned char* req = s.shelf_req + n * c.NS;
   for (int i = 0; i < c.NS; ++i) req[i] = 0;
+  rw_perm_prefix(kq0, kq1, c.NS, c.Q, picks);   // request queue: choice(key_queue, shelf ids, (Q,), replace=False)
   for (int q = 0; q < c.Q; ++q) {
-    uint32_t s0, s1;
-    threefry2x32(kq0, kq1, 0u, (uint32_t)q, s0, s1);
-    int j = (int)(random_bits32(s0, s1, 0u) % (uint32_t)(c.NS - q));
-    int pick = 0;
-    for (int i = 0; i < c.NS; ++i) {
-      if (!req[i]) { if (j == 0) { pick = i; break; } --j; }
-    }
-    req[pick] = 1;
-    s.queue[n * c.Q + q] = pick + 1;
+    req[picks[q]] = 1;
+    s.queue[n * c.Q + q] = picks[q] + 1;
   }
   s.step_count[n] = 0;
   s.key[2 * n] = ks0; s.key[2 * n + 1] = ks1;
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(64) void k_rware_reset(RwState s, RwCfg c, const ui
 }
 
 struct RwOut {
-  float* reward; unsigned char* done; float* obs; long ldo; int* obs_step; unsigned char* mask;
+  float* reward; float* discount; unsigned char* done; float* obs; long ldo; int* obs_step; unsigned char* mask;
   float* m_ep_ret; int* m_ep_len; unsigned char* m_term;
 };
 
@@ -196,10 +209,15 @@ __global__ __launch_bounds__(64) void k_rware_step(RwState s, RwCfg c, const int
       threefry2x32(k0, k1, 0u, 0u, n0, n1);   // key, sub = split(key)
       threefry2x32(k0, k1, 0u, 1u, s0, s1);
       k0 = n0; k1 = n1;
-      int j = (int)(random_bits32(s0, s1, 0u) % (uint32_t)(c.NS - c.Q));
+      // the replacement request: choice(sub, NS, (), replace=False, p=not requested) = Gumbel top-1 (oracle/prng.py:choice): the first
+      // maximum of gumbel(sub, (NS,))[i] over the shelves that are not in the queue (the delivered one still counts as requested)
       int pick = 0;
+      float best = -INFINITY;
+      bool have = false;
       for (int i = 0; i < c.NS; ++i) {
-        if (!req[i]) { if (j == 0) { pick = i; break; } --j; }
+        if (req[i]) continue;
+        const float g = gumbel_exact_from_bits(random_bits32(s0, s1, (uint32_t)i));
+        if (!have || g > best) { best = g; pick = i; have = true; }
       }
       for (int q = 0; q < c.Q; ++q) {
         if (s.queue[n * c.Q + q] == sid) { s.queue[n * c.Q + q] = pick + 1; break; }
@@ -224,6 +242,7 @@ __global__ __launch_bounds__(64) void k_rware_step(RwState s, RwCfg c, const int
   rw_observe(c, s, n, o.obs + n * (long)A * o.ldo, o.ldo, o.mask + n * (long)A * RW_NACT);
   o.obs_step[n] = obs_step;
   for (int a = 0; a < A; ++a) o.reward[n * A + a] = reward;
+  if (o.discount) for (int a = 0; a < A; ++a) o.discount[n * A + a] = done ? 0.f : 1.f;   // collision or horizon: termination
   o.done[n] = done ? 1 : 0;
   float msum = 0.f;   // episode_metrics.py:79-112: mean over agents of the repeated reward, as a sum / A in fp32
   for (int a = 0; a < A; ++a) msum += reward;
@@ -255,6 +274,7 @@ static int rw_cfg(RwCfg& c, int N, int A, int CH, int SR, int SC, int R, int Q, 
     for (int x = 0; x < c.W; ++x) ns += rw_highway(c, y, x) ? 0 : 1;
   c.NS = ns;
   if (Q >= ns || A >= c.H * c.W) { set_error("rware: request queue / agents do not fit the layout"); return MAGPO_EINVAL; }
+  if (Q > RW_MAXPICK || c.H * c.W > 1625) { set_error("rware: request_queue_size <= 16 and at most 1625 cells (one-round shuffle)"); return MAGPO_EINVAL; }
   return MAGPO_OK;
 }
 
@@ -283,13 +303,13 @@ extern "C" int magpo_rware_step(int* grid_a, int* grid_s, int* agent_pos, int* a
                                 int* queue, int* step_count, unsigned char* amask, uint32_t* key, uint32_t* metrics_key, float* run_ret,
                                 int* run_len, float* ep_ret, int* ep_len, int N, int A, int column_height, int shelf_rows, int shelf_columns,
                                 int sensor_range, int queue_size, int time_limit, const int* actions, int act_stride, float* reward,
-                                unsigned char* done, float* obs, long ldo, int* obs_step, unsigned char* mask, float* m_ep_ret, int* m_ep_len,
+                                float* discount, unsigned char* done, float* obs, long ldo, int* obs_step, unsigned char* mask, float* m_ep_ret, int* m_ep_len,
                                 unsigned char* m_term, int auto_reset, hipStream_t st) {
   RwCfg c;
   if (int e = rw_cfg(c, N, A, column_height, shelf_rows, shelf_columns, sensor_range, queue_size, time_limit)) return e;
   if (N <= 0) return MAGPO_OK;
   RwState s{grid_a, grid_s, agent_pos, agent_dir, agent_carry, shelf_req, queue, step_count, amask, key, metrics_key, run_ret, run_len, ep_ret, ep_len};
-  RwOut o{reward, done, obs, ldo, obs_step, mask, m_ep_ret, m_ep_len, m_term};
+  RwOut o{reward, discount, done, obs, ldo, obs_step, mask, m_ep_ret, m_ep_len, m_term};
   hipLaunchKernelGGL(k_rware_step, dim3((N + 63) / 64), dim3(64), 0, st, s, c, actions, act_stride, o, auto_reset);
   return check_launch("magpo_rware_step");
 }

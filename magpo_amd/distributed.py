@@ -51,3 +51,17 @@ def shard_env_keys(total_keys: torch.Tensor, num_envs: int, rank: int) -> torch.
     """Row-major (group, env) layout of the reset keys (rec_magpo.py:642-653): rank r owns rows
     1 + r*N .. 1 + (r+1)*N of split(key, G*N + 1)."""
     return total_keys[1 + rank * num_envs: 1 + (rank + 1) * num_envs]
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def broadcast_object(obj, src: int = 0):
+    """One small Python object from rank ``src`` to all ranks (identity for a single process)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]

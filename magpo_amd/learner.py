@@ -41,8 +41,8 @@ class SystemConfig:
     alpha: float = 1.0
     actor_lr: float = 2.5e-4
     # make_learning_rate (mava/utils/training.py:20-64): linear decay lr * (1 - (count // (ppo_epochs * num_minibatches)) / num_updates)
-    # with the optimiser step count BEFORE the step; lr_num_updates is config.system.num_updates as it stands when the optimiser is built
-    # (rec_magpo.py:581 runs before check_total_timesteps)
+    # with the optimiser step count BEFORE the step; lr_num_updates is config.system.num_updates as the schedule reads it when the learner
+    # is TRACED (first learn() call), i.e. the value check_total_timesteps derived: the system file refreshes it on every learn() call
     decay_learning_rates: bool = False
     lr_num_updates: int = 1000
     # not a reference key: every minibatch is trained in this many equal slabs of sequences whose gradients are accumulated before the
@@ -126,8 +126,8 @@ class CoordSumEnvBatch:
     def reset(self, env_keys: torch.Tensor, obs, obs_step, mask=None):
         self.L.call("magpo_coordsum_reset", *self._state(), *self._cfg(), env_keys, obs, obs_step, torch.cuda.current_stream().cuda_stream)
 
-    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None):
-        self.L.call("magpo_coordsum_step", *self._state(), *self._cfg(), actions, self.cfg.num_agents, reward, done, obs, obs_step,
+    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None, discount=None):
+        self.L.call("magpo_coordsum_step", *self._state(), *self._cfg(), actions, self.cfg.num_agents, reward, discount, done, obs, obs_step,
                     m_ret, m_len, m_term, 1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
 
 
@@ -156,8 +156,8 @@ class LbfEnvBatch:
     def reset(self, env_keys: torch.Tensor, obs, obs_step, mask=None):
         self.L.call("magpo_lbf_reset", *self._args(), env_keys, obs, obs_step, mask, torch.cuda.current_stream().cuda_stream)
 
-    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None):
-        self.L.call("magpo_lbf_step", *self._args(), actions, self.cfg.num_agents, reward, done, obs, obs_step, mask, m_ret, m_len, m_term,
+    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None, discount=None):
+        self.L.call("magpo_lbf_step", *self._args(), actions, self.cfg.num_agents, reward, discount, done, obs, obs_step, mask, m_ret, m_len, m_term,
                     1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
 
 
@@ -211,8 +211,8 @@ class RwareEnvBatch:
     def reset(self, env_keys: torch.Tensor, obs, obs_step, mask=None):
         self.L.call("magpo_rware_reset", *self._args(), env_keys, obs, self.ldo, obs_step, mask, torch.cuda.current_stream().cuda_stream)
 
-    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None):
-        self.L.call("magpo_rware_step", *self._args(), actions, self.cfg.num_agents, reward, done, obs, self.ldo, obs_step, mask, m_ret, m_len,
+    def step(self, actions, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=True, mask=None, discount=None):
+        self.L.call("magpo_rware_step", *self._args(), actions, self.cfg.num_agents, reward, discount, done, obs, self.ldo, obs_step, mask, m_ret, m_len,
                     m_term, 1 if auto_reset else 0, torch.cuda.current_stream().cuda_stream)
 
 
@@ -657,6 +657,7 @@ class MagpoLearner:
             lr = s.actor_lr
             if s.decay_learning_rates:
                 lr = s.actor_lr * (1.0 - ((cnt - 1) // (s.ppo_epochs * s.num_minibatches)) / s.lr_num_updates)
+            self.last_lr = lr
             self.L.call("magpo_clip_adam", net.P.flat, net.grads, mu, nu, net.P.numel, grad_scale, s.max_grad_norm, lr,
                         0.9, 0.999, 1e-5, bc1, bc2, self.ws64, self.gnorm[0:1] if which == "g" else self.gnorm[1:2], st)
             if which == "g":

@@ -29,7 +29,7 @@ from magpo_amd.evaluator import get_eval_fn, get_num_eval_envs, make_rec_eval_ac
 from magpo_amd.learner import MagpoLearner, SystemConfig, host_split, prng_key
 from magpo_amd.types import ExperimentOutput, GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
 from magpo_amd.utils import make_env as environments
-from magpo_amd.utils.checkpointing import Checkpointer, restore_learner_state
+from magpo_amd.utils.checkpointing import Checkpointer, latest_valid_checkpoint, load_checkpoint, restore_learner_state
 from magpo_amd.utils.config import check_total_timesteps
 from magpo_amd.utils.logger import LogEvent, MavaLogger
 
@@ -53,9 +53,11 @@ def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:
     params = Params({k: v.clone() for k, v in learner.guider.named.items()}, {k: v.clone() for k, v in learner.actor.named.items()})
     opt = OptStates(dict(count=learner.g_count, mu=learner.g_mu.clone(), nu=learner.g_nu.clone()),
                     dict(count=learner.a_count, mu=learner.a_mu.clone(), nu=learner.a_nu.clone()))
-    # head states are zero-padded to 64 x 64 on the device; the state carries the [hs, hs] blocks (get_init_hstates.py:20-43)
-    hw = learner.guider.hs
-    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i][..., :hw, :hw] for g in gs]) for i in range(3)]),
+    # The state carries the reference's [embed_dim / n_head, embed_dim / n_head] head states (get_init_hstates.py:20-43).  On the
+    # device a head state sits in a zero-padded 64 x 64 tile, and a narrow net (embed_dim < 64, params.WidthEmbedding) keeps logical
+    # entry (i, j) at device rows m i (q / k live in the first copy) and columns m j .. m j + m - 1 (v is duplicated), m = 64 / embed_dim.
+    hw, m = learner.guider.hs, 64 // learner.guider.EL
+    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i][..., :hw:m, :hw:m] for g in gs]) for i in range(3)]),
                       torch.stack([g.policy_h[g.cur] for g in gs]))
     env_state = {f: torch.stack([getattr(g.env, f) for g in gs]) for f in gs[0].env.state_fields}
     timestep = dict(agents_view=torch.stack([g.traj["obs"][0] for g in gs]), step_count=torch.stack([g.traj["step_count"][0] for g in gs]))
@@ -86,10 +88,11 @@ def load_learner_state(learner: MagpoLearner, state: GPOLearnerState) -> None:
             grp.traj["mask"][0].copy_(state.timestep["action_mask"][gi])
         grp.traj["step_count"][0].copy_(state.timestep["step_count"][gi])
         grp.traj["done"][0].copy_(state.dones[gi])
-        hw = learner.guider.hs
+        hw, m = learner.guider.hs, 64 // learner.guider.EL
         for i in range(3):
             grp.sable_hs[i].zero_()
-            grp.sable_hs[i][..., :hw, :hw].copy_(sable[i][gi])
+            for c in range(m):   # rows m i, every column copy (inverse of the collapse in _snapshot_state)
+                grp.sable_hs[i][..., :hw:m, c:hw:m].copy_(sable[i][gi])
         grp.policy_h[grp.cur].copy_(hst["policy_hidden_state"][gi])
         grp.key = np.array(state.key, dtype=np.uint32).copy()
 
@@ -111,6 +114,9 @@ def get_learner_fn(env, apply_fns, update_fn, config):
         if learner_state is not getattr(learner, "_live_state", None):
             load_learner_state(learner, learner_state)
         n_up = int(config.system.num_updates_per_eval)
+        # linear_scedule reads config.system.num_updates when the learner is traced, i.e. at the first learn() call -- AFTER
+        # check_total_timesteps has rewritten it on the same config object (mava/utils/training.py:37-43; rec_magpo.py:581 vs :717)
+        learner.sys.lr_num_updates = int(config.system.num_updates)
         ep: Dict[str, List[np.ndarray]] = {"episode_return": [], "episode_length": [], "is_terminal_step": []}
         train = []
         for _ in range(n_up):
@@ -185,22 +191,24 @@ def run_experiment(_config) -> float:
     steps_per_rollout = (n_devices * config.system.num_updates_per_eval * config.system.rollout_length
                          * config.system.update_batch_size * config.arch.num_envs)
     logger = MavaLogger(config) if rank == 0 else None
-    save_checkpoint = bool(config.logger.checkpointing.save_model) and rank == 0
+    # every rank saves: rank 0 the full state, the others their own rollout state (their envs, keys and hidden states differ)
+    save_checkpoint = bool(config.logger.checkpointing.save_model)
     if save_checkpoint:
+        sa = config.logger.checkpointing.save_args.to_container()
+        if world > 1 and not sa.get("checkpoint_uid"):   # one directory for all ranks
+            sa["checkpoint_uid"] = mdist.broadcast_object(time.strftime("%Y%m%d%H%M%S"))
         checkpointer = Checkpointer(metadata=config.to_container(), model_name=config.logger.system_name,
-                                    base_path=config.logger.base_exp_path, **config.logger.checkpointing.save_args.to_container())
+                                    base_path=config.logger.base_exp_path, rank=rank, world=world, **sa)
     if bool(config.logger.checkpointing.load_model):
-        # Resume from the latest checkpoint of load_args.checkpoint_uid (the reference saves the full learner state,
-        # checkpointing.py:108-145, but rec_magpo.py never reads it back: this closes the loop for long sweeps).
-        import glob
+        # Resume from the latest loadable checkpoint of load_args.checkpoint_uid (the reference saves the full learner state,
+        # checkpointing.py:108-145, but rec_magpo.py never reads it back: this closes the loop for long sweeps).  Rank-aware:
+        # parameters / optimiser state from rank 0's file, env state / keys / hidden states from the rank's own file.
         import os
         la = config.logger.checkpointing.load_args
         cdir = os.path.join(config.logger.base_exp_path, la.rel_dir, config.logger.system_name, str(la.checkpoint_uid))
-        cands = sorted(glob.glob(os.path.join(cdir, "*.pt")), key=lambda f: int(os.path.basename(f)[:-3]))
-        if not cands:
-            raise FileNotFoundError(f"load_model=True but no checkpoint under {cdir}")
-        learner_state, _ = restore_learner_state(cands[-1], device)
-        resume = torch.load(cands[-1], map_location="cpu", weights_only=False).get("extras") or {}
+        latest = latest_valid_checkpoint(cdir, rank, world)
+        learner_state, _ = restore_learner_state(latest, device, rank, world)
+        resume = load_checkpoint(latest).get("extras") or {}
     else:
         resume = {}
     eval_batch = get_num_eval_envs(config, absolute_metric=False, n_devices=n_devices)
@@ -242,6 +250,7 @@ def run_experiment(_config) -> float:
             best_params = {k: v.clone() for k, v in trained_params.items()}
             max_episode_return = episode_return
         if save_checkpoint:  # rec_magpo.py:779-785 (+ what run_experiment itself needs to continue: its loop state)
+            mdist.barrier()
             checkpointer.save(timestep=t, unreplicated_learner_state=learner_output.learner_state, episode_return=episode_return,
                               extras=dict(eval_step=eval_step, key_e=key_e.copy(), max_episode_return=max_episode_return,
                                           best_params=None if best_params is None else {k: v.cpu() for k, v in best_params.items()}))

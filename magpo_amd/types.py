@@ -13,9 +13,9 @@ Metrics = Dict[str, Any]
 
 
 class Observation(NamedTuple):  # mava/types.py:126-136
-    agents_view: torch.Tensor   # (N, A, F)
-    action_mask: Optional[torch.Tensor]  # (N, A, K) bool; None = every action legal (CoordSum)
-    step_count: torch.Tensor    # (N, A) or (N,)
+    agents_view: torch.Tensor   # (N, A, F) f32 (a view of rows ``stride(1)`` floats apart: wide observations are padded to 128)
+    action_mask: torch.Tensor   # (N, A, K) u8 / bool (all ones for CoordSum, matrax.py:117-134)
+    step_count: torch.Tensor    # (N, A) i32
 
 
 class Params(NamedTuple):  # gpo/types.py:25-29
@@ -39,15 +39,25 @@ class HiddenStates(NamedTuple):  # gpo/types.py:55-59
     policy_hidden_state: torch.Tensor
 
 
-class TimeStep(NamedTuple):
-    step_type: torch.Tensor
-    reward: torch.Tensor
-    discount: torch.Tensor
+class StepType:  # jumanji.types.StepType
+    FIRST, MID, LAST = 0, 1, 2
+
+
+class TimeStep(NamedTuple):  # jumanji.types.TimeStep as the wrappers leave it (mava/wrappers/episode_metrics.py:79-112)
+    step_type: torch.Tensor     # (N,) i8: 0 first, 1 mid, 2 last
+    reward: torch.Tensor        # (N, A) f32
+    discount: torch.Tensor      # (N, A) f32
     observation: Observation
-    extras: Dict[str, Any]
+    extras: Dict[str, Any]      # {"episode_metrics": {episode_return, episode_length, is_terminal_step}, "env_metrics": {}}
+
+    def first(self) -> torch.Tensor:
+        return self.step_type == StepType.FIRST
+
+    def mid(self) -> torch.Tensor:
+        return self.step_type == StepType.MID
 
     def last(self) -> torch.Tensor:
-        return self.step_type == 2
+        return self.step_type == StepType.LAST
 
 
 class GPOLearnerState(NamedTuple):  # gpo/types.py:62-71

@@ -57,8 +57,11 @@ class JsonLogger:
         self.env, self.task, self.algo, self.seed = env_name, task_name, system_name, f"seed_{seed}"
         self.data: Dict[str, Any] = {}
         if os.path.exists(self.file):
-            with open(self.file) as f:
-                self.data = json.load(f)
+            try:
+                with open(self.file) as f:
+                    self.data = json.load(f)
+            except json.JSONDecodeError:   # cannot happen with the atomic writes below; a file from an older run may be truncated
+                os.replace(self.file, self.file + ".corrupt")
         self.run = self.data.setdefault(self.env, {}).setdefault(self.task, {}).setdefault(self.algo, {}).setdefault(self.seed, {})
 
     def log_dict(self, data, step, eval_step, event):
@@ -73,8 +76,10 @@ class JsonLogger:
             else:
                 st = self.run.setdefault(f"step_{eval_step}", {"step_count": int(step)})
                 st[k] = [float(value)]
-        with open(self.file, "w") as f:
+        tmp = self.file + ".tmp"   # write + rename: a kill during the write leaves the previous metrics.json intact
+        with open(tmp, "w") as f:
             json.dump(self.data, f, indent=1)
+        os.replace(tmp, self.file)
 
     def stop(self):
         pass

@@ -6,9 +6,15 @@ Jumanji's published algorithm with UNPINNED dynamics (oracle/lbf.py and oracle/r
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from functools import cached_property
+from typing import Tuple
 
-from ..learner import CoordSumConfig, LbfConfig, RwareConfig
+import numpy as np
+import torch
+
+from .. import specs
+from ..learner import CoordSumConfig, LbfConfig, RwareConfig, make_env_batch, obs_row_stride
+from ..types import Observation, TimeStep
 
 COORDSUM_REGISTRY = {  # mava/coordsum/__init__.py:6-45
     "5x20-80-v0": dict(num_agents=5, num_actions=20, time_limit=100, maxval=80),
@@ -18,13 +24,42 @@ COORDSUM_REGISTRY = {  # mava/coordsum/__init__.py:6-45
 }
 
 
-@dataclass
-class MarlEnvSpec:
-    """What the system file reads from a MarlEnv (mava/types.py:45-123)."""
-    cfg: object   # CoordSumConfig | LbfConfig | RwareConfig
-    auto_reset: bool
-    add_agent_id: bool = True
+class EnvState:
+    """State of a batch of wrapped envs (the reference's vmapped State pytree: inner env state + RecordEpisodeMetricsState counters):
+    ``fields`` are the device tensors named by the env's ``state_fields`` (leading env axis).  ``MarlEnv.step`` updates them IN PLACE
+    and returns the same object -- the donated-buffer form of ``state -> new_state`` (the kernels own the env's auto-reset branch, so a
+    step is one launch over the whole batch)."""
 
+    def __init__(self, batch):
+        self.batch = batch
+
+    @property
+    def fields(self):
+        return {f: getattr(self.batch, f) for f in self.batch.state_fields}
+
+    def __getattr__(self, name):   # state.key, state.step_count ... like the reference's State dataclasses
+        batch = object.__getattribute__(self, "batch")
+        if name in batch.state_fields:
+            return getattr(batch, name)
+        raise AttributeError(name)
+
+
+class MarlEnv:
+    """The env API the system file, the learner set-up and the evaluator use (mava/types.py:45-123 ``MarlEnv``): ``num_agents`` /
+    ``time_limit`` / ``action_dim``, ``reset(key) -> (state, timestep)``, ``step(state, action) -> (state, timestep)``,
+    ``observation_spec`` / ``action_spec`` / ``reward_spec`` / ``discount_spec`` and ``unwrapped`` -- driving the HIP env kernels
+    (csrc/coordsum.hip, lbf.hip, rware.hip), which implement the whole wrapper stack of mava/utils/make_env.py:90-104
+    (env wrapper -> AgentIDWrapper -> AutoResetWrapper [train env] -> RecordEpisodeMetrics).
+
+    The batch axis is explicit: the reference calls ``jax.vmap(env.reset)(keys)`` / ``jax.vmap(env.step)(state, action)``; here
+    ``reset`` takes the ``[N, 2]`` key array itself (a single ``[2]`` key = one env) and ``step`` the ``[N, A]`` actions, one kernel
+    launch per call.  ``extras`` carries ``episode_metrics`` and (empty) ``env_metrics``; the auto-reset wrapper's ``real_next_obs``
+    entry is not produced (nothing on the MAGPO path reads it)."""
+
+    def __init__(self, cfg, auto_reset: bool, add_agent_id: bool = True, device=None):
+        self.cfg, self.auto_reset, self.add_agent_id, self.device = cfg, bool(auto_reset), bool(add_agent_id), device
+
+    # ---- attributes (mava/types.py:53-55)
     @property
     def num_agents(self) -> int:
         return self.cfg.num_agents
@@ -40,6 +75,86 @@ class MarlEnvSpec:
     @property
     def obs_dim(self) -> int:
         return self.cfg.obs_dim
+
+    @property
+    def unwrapped(self):
+        return self.cfg
+
+    # ---- specs (per env, no batch axis)
+    @cached_property
+    def observation_spec(self) -> specs.Spec:
+        A, K, F = self.num_agents, self.action_dim, self.obs_dim
+        return specs.Spec(Observation, "ObservationSpec",
+                          agents_view=specs.Array((A, F), np.float32, "agents_view"),
+                          action_mask=specs.BoundedArray((A, K), bool, False, True, "action_mask"),
+                          step_count=specs.BoundedArray((A,), np.int32, 0, self.time_limit, "step_count"))
+
+    @cached_property
+    def action_spec(self) -> specs.MultiDiscreteArray:
+        return specs.MultiDiscreteArray(num_values=np.full(self.num_agents, self.action_dim, np.int32), name="action")
+
+    @cached_property
+    def reward_spec(self) -> specs.Array:
+        return specs.Array((self.num_agents,), np.float32, "reward")
+
+    @cached_property
+    def discount_spec(self) -> specs.BoundedArray:
+        return specs.BoundedArray((self.num_agents,), np.float32, 0.0, 1.0, "discount")
+
+    # ---- dynamics
+    def _dev(self):
+        return self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def _timestep(self, st: EnvState, step_type, reward, discount, obs, obs_step, mask, m_ret, m_len, m_term) -> TimeStep:
+        N, A, K, F = obs.shape[0], self.num_agents, self.action_dim, self.obs_dim
+        if mask is None:   # CoordSum: every action legal (matrax.py:117-134)
+            if getattr(st, "_ones", None) is None or st._ones.shape[0] != N:
+                st._ones = torch.ones(N, A, K, dtype=torch.uint8, device=obs.device)
+            mask = st._ones
+        observation = Observation(obs[..., :F], mask, obs_step.view(N, 1).expand(N, A))
+        extras = {"episode_metrics": {"episode_return": m_ret, "episode_length": m_len, "is_terminal_step": m_term.bool()}, "env_metrics": {}}
+        return TimeStep(step_type, reward, discount, observation, extras)
+
+    def reset(self, key) -> Tuple[EnvState, TimeStep]:
+        """``key``: [N, 2] (or [2]) uint32 keys, numpy or device tensor -- what the reference passes to ``jax.vmap(env.reset)``
+        (rec_magpo.py:642-653, evaluator.py:128-130)."""
+        dev = self._dev()
+        if not torch.is_tensor(key):
+            key = torch.from_numpy(np.ascontiguousarray(key, dtype=np.uint32).reshape(-1, 2).view(np.int32).copy())
+        keys = key.reshape(-1, 2).to(dev).contiguous()
+        N, A = keys.shape[0], self.num_agents
+        batch = make_env_batch(self.cfg, N, dev)
+        st = EnvState(batch)
+        ld = obs_row_stride(self.cfg.obs_dim)
+        obs = torch.zeros(N, A, ld, device=dev)
+        obs_step = torch.zeros(N, dtype=torch.int32, device=dev)
+        mask = torch.zeros(N, A, self.action_dim, dtype=torch.uint8, device=dev) if self.cfg.has_mask else None
+        batch.reset(keys, obs, obs_step, mask)
+        z = lambda dt: torch.zeros(N, dtype=dt, device=dev)
+        ts = self._timestep(st, torch.zeros(N, dtype=torch.int8, device=dev), torch.zeros(N, A, device=dev), torch.ones(N, A, device=dev),
+                            obs, obs_step, mask, z(torch.float32), z(torch.int32), z(torch.uint8))
+        return st, ts
+
+    def step(self, state: EnvState, action: torch.Tensor) -> Tuple[EnvState, TimeStep]:
+        """One env step of the whole batch (``jax.vmap(env.step)(state, action)``): the env state is updated in place; the TimeStep's
+        tensors are fresh, so earlier timesteps stay valid."""
+        batch = state.batch
+        N, A = batch.N, self.num_agents
+        dev = action.device
+        action = action.to(torch.int32).reshape(N, A).contiguous()
+        ld = obs_row_stride(self.cfg.obs_dim)
+        obs = torch.zeros(N, A, ld, device=dev) if ld != self.cfg.obs_dim else torch.empty(N, A, ld, device=dev)
+        obs_step = torch.empty(N, dtype=torch.int32, device=dev)
+        mask = torch.empty(N, A, self.action_dim, dtype=torch.uint8, device=dev) if self.cfg.has_mask else None
+        reward, discount = torch.empty(N, A, device=dev), torch.empty(N, A, device=dev)
+        done = torch.empty(N, dtype=torch.uint8, device=dev)
+        m_ret, m_len, m_term = torch.empty(N, device=dev), torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.uint8, device=dev)
+        batch.step(action, reward, done, obs, obs_step, m_ret, m_len, m_term, auto_reset=self.auto_reset, mask=mask, discount=discount)
+        step_type = (done + 1).to(torch.int8)   # MID = 1, LAST = 2
+        return state, self._timestep(state, step_type, reward, discount, obs, obs_step, mask, m_ret, m_len, m_term)
+
+
+MarlEnvSpec = MarlEnv   # earlier name of this class
 
 
 def make_coordsum_env(config):
@@ -74,6 +189,10 @@ def make_lbf_env(config):
                     time_limit=int(kw.get("time_limit", 100)))
     if cfg.obs_dim > 32:
         raise NotImplementedError("LevelBasedForaging: num_agents + 3 (num_food + num_agents) <= 32 (the LBF kernel writes unpadded observation rows)")
+    G = cfg.grid_size
+    if (G - 2) ** 2 < 5 * (cfg.num_food - 1) + 1 or G * G - cfg.num_food < cfg.num_agents:
+        # a food blocks up to 5 interior cells for the later ones; jax.random.choice on an all-zero mask would silently return cell 0
+        raise ValueError(f"LevelBasedForaging: a {G}x{G} grid cannot be guaranteed to hold {cfg.num_food} food items and {cfg.num_agents} agents")
     return MarlEnvSpec(cfg, auto_reset=True), MarlEnvSpec(cfg, auto_reset=False)
 
 

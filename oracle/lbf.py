@@ -25,9 +25,12 @@ compute_action_mask, observer.py VectorObserver, generator.py RandomGenerator) f
   * action mask: a move is legal if the target cell is inside the grid and free; NOOP always; LOAD iff an uneaten food is adjacent
   * generator: food on non-border cells, no two foods in the same or in 4-adjacent cells; agents on free cells; agent levels
     uniform in [1, max_agent_level]; force_coop: every food level = sum of the (up to three) smallest agent levels
-What is NOT reproduced bit for bit is the generator's use of jax.random.choice: here a cell is drawn as "the (bits mod n)-th
-valid cell in row-major order" with 32 random bits from the same threefry stream (uniform over valid cells up to a 2^-32
-modulo bias), one split key per draw.  Levels use the exact jax.random.randint restatement (oracle/prng.py).
+The generator's cell draws follow jax.random.choice's published algorithm (oracle/prng.py:choice) with the call forms of
+Jumanji's RandomGenerator as recalled: every food cell is one `choice(key_f, G*G, shape=(), p=mask)` (replace=True: cumulative
+counts of the boolean mask, one uniform, searchsorted) with key_f = split(key_food, NF)[f] and the mask updated between the
+draws; the agents are ONE `choice(key_agents, G*G, shape=(A,), replace=False, p=mask)` (Gumbel top-k over the cells that hold
+no food).  Levels use the exact jax.random.randint restatement (oracle/prng.py).  A mask with no valid cell left yields cell 0
+(what choice returns for an all-zero p); make_lbf_env / magpo_lbf_* reject configurations where that can happen.
 """
 from __future__ import annotations
 
@@ -54,13 +57,6 @@ class LbfSpec:
         return 3 * (self.num_food + self.num_agents) + self.num_agents
 
 
-def _draw_cell(key: np.ndarray, valid: np.ndarray) -> int:
-    """The (bits mod n)-th valid cell in row-major order (see the module docstring)."""
-    idx = np.nonzero(valid.reshape(-1))[0]
-    b = int(prng.random_bits(key, 1)[0])
-    return int(idx[b % len(idx)])
-
-
 def _generate(spec: LbfSpec, key: np.ndarray) -> Dict[str, np.ndarray]:
     """RandomGenerator.__call__ for one key."""
     G, A, NF = spec.grid_size, spec.num_agents, spec.num_food
@@ -71,7 +67,7 @@ def _generate(spec: LbfSpec, key: np.ndarray) -> Dict[str, np.ndarray]:
     food_pos = np.zeros((NF, 2), np.int32)
     fkeys = prng.split(key_food, NF)
     for f in range(NF):
-        c = _draw_cell(fkeys[f], valid)
+        c = int(prng.choice(fkeys[f], G * G, 1, True, valid.reshape(-1))[0])   # take_positions: choice(key, flat_size, (), p=mask)
         r, q = divmod(c, G)
         food_pos[f] = (r, q)
         for dr, dc in ((0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)):
@@ -79,13 +75,8 @@ def _generate(spec: LbfSpec, key: np.ndarray) -> Dict[str, np.ndarray]:
                 valid[r + dr, q + dc] = False
     free = np.ones((G, G), bool)
     free[food_pos[:, 0], food_pos[:, 1]] = False
-    agent_pos = np.zeros((A, 2), np.int32)
-    akeys = prng.split(key_agents, A)
-    for a in range(A):
-        c = _draw_cell(akeys[a], free)
-        r, q = divmod(c, G)
-        agent_pos[a] = (r, q)
-        free[r, q] = False
+    cells = prng.choice(key_agents, G * G, A, False, free.reshape(-1))   # sample_agents: choice(key, G*G, (A,), replace=False, p=mask)
+    agent_pos = np.stack(np.divmod(cells, G), axis=1).astype(np.int32)
     agent_level = prng.randint(key_agent_level, A, 1, spec.max_agent_level + 1).astype(np.int32)
     max_food_level = int(np.sort(agent_level)[:3].sum())
     if spec.force_coop:

@@ -141,3 +141,49 @@ def permutation(key: np.ndarray, n: int) -> np.ndarray:
         order = np.argsort(sort_keys, kind="stable")
         x = x[order]
     return x
+
+
+def uniform(key: np.ndarray, n: int, minval: float = 0.0, maxval: float = 1.0) -> np.ndarray:
+    """jax.random.uniform(key, (n,), float32, minval, maxval) (shape () draws are n = 1)."""
+    return bits_to_uniform(random_bits(key, n), minval, maxval)
+
+
+def gumbel(key: np.ndarray, n: int) -> np.ndarray:
+    """jax.random.gumbel(key, (n,), float32)."""
+    return bits_to_gumbel(random_bits(key, n))
+
+
+def choice(key: np.ndarray, n: int, num: int = 1, replace: bool = True, p=None) -> np.ndarray:
+    """jax.random.choice(key, n, shape=(num,), replace=replace, p=p) for an integer ``a = n`` (jax/_src/random.py, `choice`;
+    jax 0.6.0): all four branches of the published algorithm.
+
+      p is None,  replace      randint(key, shape, 0, n)
+      p is None, ~replace      permutation(key, n)[:num]
+      p given,    replace      p_cuml = cumsum(p); r = p_cuml[-1] * (1 - uniform(key, shape)); searchsorted(p_cuml, r)   (side 'left')
+      p given,   ~replace      Gumbel top-k: g = gumbel(key, (n,)) + log(p); top_k(g, num) indices (descending; ties: lower index first)
+
+    ``p`` is promoted to float32 and NOT normalised by ``choice`` itself (callers that pass a boolean mask get the mask's own cumulative
+    counts, which is what makes the draw uniform over the set cells).  Restated from memory of the JAX source: PARITY UNPINNED like
+    the other derivations in this file; the float32 arithmetic (one multiply, one subtraction) is IEEE and order-free, the cumulative sum of a
+    0 / 1 mask is exact in any summation order, and the gumbel uses this file's correctly rounded double log (see bits_to_gumbel).
+    Returns int32 [num]."""
+    n, num = int(n), int(num)
+    if n <= 0:
+        raise ValueError("a must be non-empty")
+    if not replace and num > n:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    if p is None:
+        if replace:
+            return randint(key, num, 0, n)
+        return permutation(key, n)[:num].astype(np.int32)
+    p_arr = np.asarray(p).astype(np.float32)
+    if p_arr.shape != (n,):
+        raise ValueError("p must be None or match the shape of a")
+    if replace:
+        p_cuml = np.cumsum(p_arr, dtype=np.float32)
+        r = (p_cuml[-1] * (np.float32(1.0) - uniform(key, num))).astype(np.float32)
+        return np.searchsorted(p_cuml, r, side="left").astype(np.int32)
+    with np.errstate(divide="ignore"):
+        g = (gumbel(key, n) + np.log(p_arr.astype(np.float64)).astype(np.float32)).astype(np.float32)
+    order = np.argsort(-g.astype(np.float64), kind="stable")   # descending, equal values keep index order (lax.top_k)
+    return order[:num].astype(np.int32)

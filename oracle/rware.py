@@ -31,9 +31,11 @@ robot_warehouse: env.py, utils*.py, generator.py -- itself a JAX port of github.
   * observation per agent, sensor_range r: [row, col, carrying, one-hot direction (4), on highway] then, for every cell of the
     (2r + 1)^2 window in row-major order, [agent present, one-hot direction of that agent (4), shelf present, shelf requested];
     cells outside the grid read zeros; 8 + 7 (2r + 1)^2 features (71 at r = 1)
-What is NOT reproduced bit for bit is the generator's and the request queue's use of jax.random.choice: a draw here is "the
-(bits mod n)-th remaining candidate in index order" with 32 random bits of a split key (uniform up to a 2^-32 modulo bias);
-directions use the exact jax.random.randint restatement.
+The generator's and the request queue's draws follow jax.random.choice's published algorithm (oracle/prng.py:choice) with the
+call forms of Jumanji's code as recalled: agent cells = `choice(key_pos, H*W, (A,), replace=False)` (no p: the first A entries of
+permutation(key, H*W)), the initial queue = `choice(key_queue, NS, (Q,), replace=False)` (same form over the shelf ids), and the
+shelf that replaces a delivered request = `choice(sub, NS, (), replace=False, p=not_requested)` (p given, replace=False: Gumbel
+top-1 over the shelves that are not in the queue).  Directions use the exact jax.random.randint restatement.
 """
 from __future__ import annotations
 
@@ -73,31 +75,17 @@ class RwareSpec:
         return 8 + 7 * (2 * self.sensor_range + 1) ** 2 + self.num_agents
 
 
-def _draw(key: np.ndarray, candidates: np.ndarray) -> int:
-    """The (bits mod n)-th candidate (see the module docstring)."""
-    b = int(prng.random_bits(key, 1)[0])
-    return int(candidates[b % len(candidates)])
-
-
 def _generate(spec: RwareSpec, key: np.ndarray) -> Dict[str, np.ndarray]:
     H, W, A, NS, Q = spec.H, spec.W, spec.num_agents, spec.num_shelves, spec.request_queue_size
     ks = prng.split(key, 4)   # key_pos, key_dir, key_queue, key
     key_pos, key_dir, key_queue, key_state = ks
-    free = np.ones(H * W, bool)
-    pos = np.zeros((A, 2), np.int32)
-    pk = prng.split(key_pos, A)
-    for a in range(A):
-        c = _draw(pk[a], np.nonzero(free)[0])
-        free[c] = False
-        pos[a] = divmod(c, W)
+    cells = prng.choice(key_pos, H * W, A, False)             # choice(key, H*W, (A,), replace=False)
+    pos = np.stack(np.divmod(cells, W), axis=1).astype(np.int32)
     direction = prng.randint(key_dir, A, 0, 4).astype(np.int32)
+    picks = prng.choice(key_queue, NS, Q, False)              # choice(key, shelf_ids, (Q,), replace=False)
     requested = np.zeros(NS, bool)
-    queue = np.zeros(Q, np.int32)
-    qk = prng.split(key_queue, Q)
-    for i in range(Q):
-        s = _draw(qk[i], np.nonzero(~requested)[0])
-        requested[s] = True
-        queue[i] = s + 1
+    requested[picks] = True
+    queue = (picks + 1).astype(np.int32)
     grid_a = np.zeros((H, W), np.int32)
     for a in range(A):
         grid_a[pos[a, 0], pos[a, 1]] = a + 1
@@ -183,7 +171,7 @@ def _step_one(spec: RwareSpec, st, actions):
             reward = np.float32(reward + np.float32(1.0))
             ks = prng.split(key, 2)
             key, sub = ks[0], ks[1]
-            new = _draw(sub, np.nonzero(~st["shelf_req"])[0])
+            new = int(prng.choice(sub, spec.num_shelves, 1, False, ~st["shelf_req"])[0])   # not_in_queue mask still holds the delivered shelf as requested
             slot = int(np.nonzero(st["queue"] == sid)[0][0])
             st["queue"][slot] = new + 1
             st["shelf_req"][sid - 1] = False

@@ -30,6 +30,10 @@ def prng_fixture():
     np.savez_compressed(os.path.join(OUT, "prng.npz"), key=key, split6=ks, bits32=oprng.random_bits(ks[1], 32),
                         randint_0_60=oprng.randint(ks[2], 101, 0, 60), perm16=oprng.permutation(ks[3], 16),
                         perm1000=oprng.permutation(ks[4], 1000),
+                        # jax.random.choice, all four branches (oracle/prng.py:choice): p = a 0/1 mask over 64 cells
+                        choice_mask=(np.arange(64) % 3 != 1), choice_p_replace=np.concatenate([oprng.choice(k, 64, 1, True, np.arange(64) % 3 != 1) for k in oprng.split(ks[0], 16)]),
+                        choice_p_noreplace=oprng.choice(ks[1], 64, 5, False, np.arange(64) % 3 != 1),
+                        choice_noreplace=oprng.choice(ks[2], 110, 4, False), choice_replace=oprng.choice(ks[3], 64, 7, True),
                         cat_logits=np.linspace(-1, 1, 60, dtype=np.float32).reshape(3, 1, 20),
                         cat_sample=oprng.categorical(ks[5], np.linspace(-1, 1, 60, dtype=np.float32).reshape(3, 1, 20)))
 

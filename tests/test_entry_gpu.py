@@ -151,3 +151,34 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in roof, k
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+
+
+def test_lr_decay_uses_the_num_updates_check_total_timesteps_derives(tmp_path):
+    """linear_scedule (mava/utils/training.py:37-43) reads config.system.num_updates when the learner is traced, i.e. AFTER
+    check_total_timesteps rewrote it (rec_magpo.py:581 builds the optimiser before :717, but the closure holds the same config): with
+    total_timesteps set the rate decays over the DERIVED number of updates -- never below zero, ~0 after the last update."""
+    from magpo_amd.config import compose
+    from magpo_amd.learner import MagpoLearner
+    from magpo_amd.systems.gpo.anakin import rec_magpo
+    n_env, T, U, updates = 4, 8, 2, 6
+    cfg = compose("rec_magpo", ["env=coordsum", "env/scenario=3x10-30", f"arch.num_envs={n_env}", "arch.num_evaluation=2", "arch.num_eval_episodes=4",
+                                "arch.absolute_metric=False", f"system.total_timesteps={n_env * T * U * updates}", f"system.rollout_length={T}",
+                                "system.ppo_epochs=2", "system.decay_learning_rates=True", "env.kwargs.time_limit=5", f"logger.base_exp_path={tmp_path}/"])
+    assert int(cfg.system.num_updates) != updates        # the composed default (1000) is NOT what the schedule may use
+    lrs = []
+    orig = MagpoLearner.apply_grads
+
+    def spy(self, *a, **k):
+        out = orig(self, *a, **k)
+        lrs.append(self.last_lr)
+        return out
+    MagpoLearner.apply_grads = spy
+    try:
+        rec_magpo.run_experiment(cfg)
+    finally:
+        MagpoLearner.apply_grads = orig
+    per_update = 2 * int(cfg.system.num_minibatches)
+    assert len(lrs) == updates * per_update
+    base = float(cfg.system.actor_lr)
+    want = [base * (1.0 - (i // per_update) / updates) for i in range(len(lrs))]
+    assert np.allclose(lrs, want, rtol=1e-12, atol=0) and min(lrs) > 0 and abs(lrs[-1] - base / updates) < 1e-12

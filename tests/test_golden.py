@@ -21,6 +21,11 @@ def test_oracle_reproduces_prng_and_env_fixtures():
     assert np.array_equal(oprng.randint(ks[2], 101, 0, 60), f["randint_0_60"])
     assert np.array_equal(oprng.permutation(ks[3], 16), f["perm16"]) and np.array_equal(oprng.permutation(ks[4], 1000), f["perm1000"])
     assert np.array_equal(oprng.categorical(ks[5], f["cat_logits"]), f["cat_sample"])
+    m = f["choice_mask"]
+    assert np.array_equal(np.concatenate([oprng.choice(k, 64, 1, True, m) for k in oprng.split(ks[0], 16)]), f["choice_p_replace"])
+    assert m[f["choice_p_replace"]].all() and m[f["choice_p_noreplace"]].all() and len(set(f["choice_p_noreplace"].tolist())) == 5
+    assert np.array_equal(oprng.choice(ks[1], 64, 5, False, m), f["choice_p_noreplace"])
+    assert np.array_equal(oprng.choice(ks[2], 110, 4, False), f["choice_noreplace"]) and np.array_equal(oprng.choice(ks[3], 64, 7, True), f["choice_replace"])
     e = np.load(os.path.join(G, "coordsum.npz"))
     A, K, TL, mv = e["cfg"]
     spec = ocs.CoordSumSpec(A, K, TL, mv)

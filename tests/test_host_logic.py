@@ -73,9 +73,17 @@ def test_env_factory():
     c = compose("rec_magpo", ["env=coordsum", "+env.kwargs.num_agents=4", "+env.kwargs.num_actions=20", "+env.kwargs.maxval=60"])
     tr, _ = make_env.make(c)
     assert (tr.num_agents, tr.action_dim, tr.cfg.maxval) == (4, 20, 60)
-    # the default env of configs/default/rec_magpo.yaml is rware tiny-4ag: 71 vector features + 4 agent-id features
+    # the default env of configs/default/rec_magpo.yaml is rware with scenario tiny-2ag (mava/configs/env/rware.yaml:4): 71 vector
+    # features + 2 agent-id features
     tr, ev = make_env.make(compose("rec_magpo"))
-    assert (tr.num_agents, tr.action_dim, tr.time_limit, tr.obs_dim) == (4, 5, 500, 75) and tr.cfg.has_mask
+    assert (tr.num_agents, tr.action_dim, tr.time_limit, tr.obs_dim) == (2, 5, 500, 73) and tr.cfg.has_mask
+    tr4, _ = make_env.make(compose("rec_magpo", ["env/scenario=tiny-4ag"]))
+    assert (tr4.num_agents, tr4.obs_dim) == (4, 75)
+    # the MarlEnv surface (mava/types.py:45-123): attributes + specs without touching the GPU
+    assert tr.observation_spec.agents_view.shape == (2, 73) and tr.action_spec.shape == (2,) and int(tr.action_spec.num_values[0]) == 5
+    assert callable(tr.reset) and callable(tr.step) and tr.unwrapped is tr.cfg
+    with pytest.raises(ValueError):   # a 4x4 grid cannot be guaranteed to hold 3 non-adjacent interior food items
+        make_env.make(compose("rec_magpo", ["env=lbf", "env.scenario.task_config.grid_size=4", "env.scenario.task_config.num_food=3"]))
     tr, _ = make_env.make(compose("rec_magpo", ["env=lbf", "env/scenario=15x15-4p-5f"]))
     assert (tr.num_agents, tr.action_dim, tr.time_limit, tr.obs_dim, tr.cfg.fov) == (4, 6, 100, 31, 15)
     with pytest.raises(NotImplementedError):
@@ -148,6 +156,50 @@ def test_checkpointer_keeps_best(tmp_path):
     ck.save(300, mk(3), episode_return=7.0)
     files = sorted(f for f in os.listdir(os.path.join(tmp_path, "checkpoints", "rec_magpo", "u")) if f.endswith(".pt"))
     assert files == ["200.pt"]
-    st = torch.load(os.path.join(tmp_path, "checkpoints", "rec_magpo", "u", "200.pt"), weights_only=False)
+    st = torch.load(os.path.join(tmp_path, "checkpoints", "rec_magpo", "u", "200.pt"), weights_only=True)
     assert st["episode_return"] == 9.0 and float(st["learner_state"]["params"]["guider_params"]["w"][0]) == 2.0
     assert json.load(open(os.path.join(tmp_path, "checkpoints", "rec_magpo", "u", "metadata.json")))["checkpointer_version"] == 2.0
+
+
+def test_checkpoints_are_safe_atomic_rank_aware_and_resumable(tmp_path):
+    """(1) files load with torch.load(weights_only=True): tensors + plain containers, numpy keys round-trip; (2) written through a
+    temporary file (no ``.tmp`` left, a truncated newest file falls back to the one before it); (3) a relaunch seeds the retention from
+    the files on disk; (4) ranks > 0 write / read their own rollout state, a rank-count mismatch raises."""
+    from magpo_amd.types import GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
+    from magpo_amd.utils.checkpointing import Checkpointer, latest_valid_checkpoint, load_checkpoint, restore_learner_state
+
+    def mk(v, r=0):
+        hs = HiddenStates(SableHiddenStates(*[torch.full((1, 1, 1, 2, 4, 4), float(v + r))] * 3), torch.full((1, 6, 128), float(r)))
+        return GPOLearnerState(Params({"w": torch.full((3,), float(v))}, {"k": torch.zeros(2)}),
+                               OptStates(dict(count=7, mu=torch.zeros(3), nu=torch.zeros(3)), dict(count=7, mu=torch.zeros(2), nu=torch.zeros(2))),
+                               np.array([v, 100 + r], np.uint32), {"step_count": torch.full((1, 2), r, dtype=torch.int32)},
+                               {"agents_view": torch.full((1, 2, 3, 4), float(r))}, torch.zeros(1, 2, dtype=torch.uint8), hs)
+    d = os.path.join(tmp_path, "checkpoints", "rec_magpo", "u")
+    cks = [Checkpointer("rec_magpo", base_path=str(tmp_path), max_to_keep=2, keep_latest=True, checkpoint_uid="u", rank=r, world=2) for r in range(2)]
+    for t in (100, 200):
+        for r in (1, 0):
+            cks[r].save(t, mk(t, r), episode_return=float(t), extras=dict(eval_step=t // 100, key_e=np.array([5, 6], np.uint32), best_params=None))
+    assert sorted(os.listdir(d)) == ["100.pt", "100.rank1.pt", "200.pt", "200.rank1.pt", "metadata.json"]
+    raw = torch.load(os.path.join(d, "200.pt"), weights_only=True)          # (1) no pickled code objects
+    assert raw["world"] == 2 and raw["learner_state"]["opt_states"]["guider_opt_state"]["count"] == 7
+    s0, t0 = restore_learner_state(os.path.join(d, "200.pt"), "cpu", rank=0, world=2)
+    s1, _ = restore_learner_state(os.path.join(d, "200.pt"), "cpu", rank=1, world=2)
+    assert t0 == 200 and s0.key.dtype == np.uint32 and s0.key.tolist() == [200, 100] and s1.key.tolist() == [200, 101]
+    assert torch.equal(s0.params.guider_params["w"], s1.params.guider_params["w"])                 # replicated parts from rank 0's file
+    assert float(s1.env_state["step_count"][0, 0]) == 1 and float(s0.env_state["step_count"][0, 0]) == 0   # rollout state per rank
+    assert float(s1.hstates.policy_hidden_state.max()) == 1.0 and float(s1.timestep["agents_view"].max()) == 1.0
+    assert load_checkpoint(os.path.join(d, "200.pt"))["extras"]["key_e"].tolist() == [5, 6]
+    with pytest.raises(ValueError):
+        restore_learner_state(os.path.join(d, "200.pt"), "cpu", rank=0, world=4)
+    # (2) a kill while writing 300.pt: the truncated file is skipped, and so is a timestep whose rank file is missing
+    with open(os.path.join(d, "300.pt"), "wb") as f:
+        f.write(open(os.path.join(d, "200.pt"), "rb").read()[:200])
+    assert latest_valid_checkpoint(d, 0, 2).endswith("200.pt")
+    os.remove(os.path.join(d, "200.rank1.pt"))
+    assert latest_valid_checkpoint(d, 1, 2).endswith("100.pt")
+    # (3) relaunch: the truncated file is dropped, the old files are ranked, retention removes a timestep's files together
+    ck = Checkpointer("rec_magpo", base_path=str(tmp_path), max_to_keep=2, keep_latest=True, checkpoint_uid="u", rank=0, world=2)
+    assert [k[1] for k in ck.kept] == [100, 200] and not os.path.exists(os.path.join(d, "300.pt"))
+    ck.save(400, mk(400), episode_return=1.0)
+    assert sorted(os.listdir(d)) == ["200.pt", "400.pt", "metadata.json"]
+    assert not [f for f in os.listdir(d) if f.endswith(".tmp")]

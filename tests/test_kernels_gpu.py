@@ -564,6 +564,7 @@ class DevEnv:
         self.ep_ret, self.ep_len = torch.zeros(N, device=DEV), i32(N)
         self.obs, self.obs_step = torch.zeros(N, A, A + 1, device=DEV), i32(N)
         self.reward = torch.zeros(N, A, device=DEV)
+        self.discount = torch.full((N, A), -1.0, device=DEV)
         self.done = torch.zeros(N, dtype=torch.uint8, device=DEV)
         self.m_ret, self.m_len, self.m_term = torch.zeros(N, device=DEV), i32(N), torch.zeros(N, dtype=torch.uint8, device=DEV)
 
@@ -578,7 +579,7 @@ class DevEnv:
         self.L.call("magpo_coordsum_reset", *self._state(), *self._cfg(), dev(env_keys.view(np.int32)), self.obs, self.obs_step, self.st)
 
     def step(self, actions, auto_reset=1):
-        self.L.call("magpo_coordsum_step", *self._state(), *self._cfg(), actions, self.spec.num_agents, self.reward, self.done,
+        self.L.call("magpo_coordsum_step", *self._state(), *self._cfg(), actions, self.spec.num_agents, self.reward, self.discount, self.done,
                     self.obs, self.obs_step, self.m_ret, self.m_len, self.m_term, auto_reset, self.st)
 
 
@@ -607,6 +608,7 @@ def test_coordsum_env(L, stream, A, K, TL, maxval, auto):
         st, ts = ocs.step(spec, st, acts, auto_reset=bool(auto))
         env.step(dev(acts), auto)
         assert np.array_equal(env.reward.cpu().numpy(), ts["reward"]), f"reward step {i}"
+        assert np.array_equal(env.discount.cpu().numpy(), ts["discount"]), f"discount step {i}"
         assert np.array_equal(env.done.cpu().numpy().astype(bool), ts["step_type"] == ocs.STEP_LAST)
         assert np.array_equal(env.obs.cpu().numpy(), ts["observation"]["agents_view"].astype(np.float32)), f"obs step {i}"
         assert np.array_equal(env.obs_step.cpu().numpy(), ts["observation"]["step_count"][:, 0])

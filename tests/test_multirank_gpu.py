@@ -102,3 +102,65 @@ def test_rccl_all_reduce_on_the_gradient_buffer():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert ncalls == 2 * CFG["P"] * CFG["M"] and identity and same
+
+
+def _resume_worker(rank, world, port, tmp, q):
+    """Two ranks: learn, checkpoint (rank-aware), learn again; then a fresh job built from ANOTHER seed restores the checkpoint and
+    must continue exactly like the uninterrupted one -- with every rank on its OWN envs (a resume that hands rank 0's
+    rollout state to every rank shrinks the effective batch silently)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from magpo_amd import distributed as mdist
+    from magpo_amd.config import compose
+    from magpo_amd.learner import host_split, prng_key
+    from magpo_amd.systems.gpo.anakin import rec_magpo
+    from magpo_amd.utils import make_env as environments
+    from magpo_amd.utils.checkpointing import Checkpointer, latest_valid_checkpoint, restore_learner_state
+    from magpo_amd.utils.config import check_total_timesteps
+    mdist.init_from_env("gloo")
+
+    def setup(seed):
+        cfg = compose("rec_magpo", ["env=coordsum", "env/scenario=3x10-30", "arch.num_envs=6", "system.total_timesteps=~", "system.num_updates=4",
+                                    "system.rollout_length=8", "system.ppo_epochs=2", "env.kwargs.time_limit=5", f"system.seed={seed}",
+                                    f"logger.base_exp_path={tmp}/"])
+        env, _ = environments.make(cfg)
+        ks = host_split(prng_key(seed), 4)
+        learn, _, state = rec_magpo.learner_setup(env, (ks[0], ks[2], ks[3]), cfg, torch.device("cuda"), rank, world)
+        cfg = check_total_timesteps(cfg, world)
+        cfg.system.num_updates_per_eval = 1
+        return learn, state
+
+    learn, s0 = setup(42)
+    s1 = learn(s0).learner_state
+    ck = Checkpointer("rec_magpo", base_path=tmp, checkpoint_uid="mr", rank=rank, world=world)
+    ck.save(1, s1, episode_return=0.0)
+    dist.barrier()
+    s2 = learn(s1).learner_state
+    act_ref = learn.learner.traj["action"].cpu().numpy().copy()
+    learn2, _ = setup(7)
+    path = latest_valid_checkpoint(os.path.join(tmp, "checkpoints", "rec_magpo", "mr"), rank, world)
+    restored, _ = restore_learner_state(path, "cuda", rank, world)
+    r2 = learn2(restored).learner_state
+    act_res = learn2.learner.traj["action"].cpu().numpy().copy()
+    same = all(torch.equal(a, b) for a, b in zip(r2.params.guider_params.values(), s2.params.guider_params.values())) \
+        and torch.equal(r2.env_state["target"], s2.env_state["target"]) and np.array_equal(r2.key, s2.key)
+    q.put((rank, act_ref, act_res, bool(same)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_resume_keeps_every_ranks_own_rollout_state(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + os.getpid() % 90
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=400) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert np.array_equal(res[r][1], res[r][2]), f"rank {r}: resumed rollout differs from the uninterrupted one"
+        assert res[r][3], f"rank {r}: resumed state differs"
+    assert not np.array_equal(res[0][2], res[1][2]), "after the resume both ranks act on the same envs"

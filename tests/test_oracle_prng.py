@@ -48,3 +48,39 @@ def test_categorical_matches_manual_gumbel_argmax():
     a = prng.categorical(k, logits)
     g = prng.bits_to_gumbel(prng.random_bits(k, logits.size)).reshape(logits.shape)
     assert np.array_equal(a, np.argmax(g + logits, -1))
+
+
+def test_choice_hand_worked_vector_and_branches():
+    """jax.random.choice restated (oracle/prng.py:choice), the four branches of the published algorithm.
+
+    Hand-worked p / replace=True case, key = PRNGKey(7): random_bits(key, 1) = 2895194379 = 0xAC9129CB, so
+    uniform = bitcast((bits >> 9) | 0x3F800000) - 1 = 0.6740899; mask = [0,1,1,0,1,0,0,1] has cumulative counts [0,1,2,2,3,3,3,4];
+    r = 4 * (1 - 0.6740899) = 1.3036404; searchsorted(left) = first index whose count >= r = index 2."""
+    k = prng.prng_key(7)
+    assert int(prng.random_bits(k, 1)[0]) == 2895194379
+    u = prng.uniform(k, 1)[0]
+    assert abs(float(u) - 0.6740899) < 1e-7
+    mask = np.array([0, 1, 1, 0, 1, 0, 0, 1], bool)
+    assert prng.choice(k, 8, 1, True, mask).tolist() == [2]
+    # the draw is "the ceil(r)-th set cell": exhaustively over keys, always a set cell and all of them reachable
+    seen = set()
+    for s in range(200):
+        kk = prng.prng_key(1000 + s)
+        c = int(prng.choice(kk, 8, 1, True, mask)[0])
+        r = 4 * (1.0 - float(prng.uniform(kk, 1)[0]))
+        assert mask[c] and c == np.nonzero(mask)[0][int(np.ceil(r)) - 1]
+        seen.add(c)
+    assert seen == {1, 2, 4, 7}
+    assert prng.choice(k, 8, 1, True, np.zeros(8, bool)).tolist() == [0]          # all-zero p: searchsorted of 0 in zeros
+    # p, replace=False: Gumbel top-k = the k largest of gumbel + log p in descending order, masked cells never before set ones
+    g = prng.gumbel(k, 8)
+    want = [i for i in np.argsort(-g, kind="stable") if mask[i]][:3]
+    assert prng.choice(k, 8, 3, False, mask).tolist() == want
+    full = prng.choice(k, 8, 8, False, mask).tolist()
+    assert full[:4] == [i for i in np.argsort(-g, kind="stable") if mask[i]] and full[4:] == [0, 3, 5, 6]
+    # no p: randint / permutation prefix
+    assert np.array_equal(prng.choice(k, 8, 5, True), prng.randint(k, 5, 0, 8))
+    assert np.array_equal(prng.choice(k, 110, 4, False), prng.permutation(k, 110)[:4])
+    import pytest
+    with pytest.raises(ValueError):
+        prng.choice(k, 3, 4, False)

@@ -142,7 +142,7 @@ def test_rware_evaluator_and_entry_point(tmp_path):
     want = oeval.evaluate(orw.RwareSpec(8, 1, 3, 2, 1, 2, 15), ap, key, 6, 12, env=orw)
     assert np.array_equal(got["episode_length"], want["episode_length"])
     assert np.array_equal(got["episode_return"], want["episode_return"])
-    # the reference's DEFAULT experiment (configs/default/rec_magpo.yaml: env rware tiny-4ag) end to end, shortened
+    # the reference's DEFAULT experiment (configs/default/rec_magpo.yaml: env rware, scenario tiny-2ag) end to end, shortened
     cfg = compose("rec_magpo", ["arch.num_envs=8", "arch.num_evaluation=2", "arch.num_eval_episodes=8", "arch.num_absolute_metric_eval_episodes=16",
                                 "system.total_timesteps=~", "system.num_updates=4", "system.rollout_length=16", "system.ppo_epochs=2",
                                 "env.kwargs.time_limit=20", f"logger.base_exp_path={tmp_path}/"])
