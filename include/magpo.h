@@ -183,13 +183,19 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
                                  magpo_stream_t stream);
 
 /* ---- K2 fused acting step: SableNetwork.get_actions (sable_network.py:443-482; decode.py:111-153) in ONE launch ----
- * dims_host[12] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F), envs per wave (0 = by size, or 4 / 8 / 16)};
- * kappa_host[4] (per head);
+ * dims_host[14] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F), envs per wave (0 = by size, or 4 / 8 / 16),
+ *   pending, flush}; kappa_host[4] (per head);
  * keys_host [A][2] sampling keys by value, or NULL with ptrs[3] = device key table (static arguments for graph replay);
- * ptrs_host[48]: obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
+ * Decoder states are read once and written once per step: the update S <- kappa S + sum_a k_a^T v_a of a step is DEFERRED to the next launch
+ *   (the step's k | v rows stay in the scratch rows qkvg1 / kvg2, which therefore must persist between the launches of a rollout).
+ *   pending = 1: the previous launch left such rows (apply them first); flush = 1: also apply this launch's rows before returning (with
+ *   value_only: the pending ones), so that S_d1 / S_d2 hold the carried states again.  A stand-alone step is {pending 0, flush 1}; a rollout is
+ *   {0, 0}, {1, 0} ... and ends with a launch that has flush = 1 (e.g. the bootstrap-value launch {value_only 1, pending 1, flush 1}).
+ * ptrs_host[49]: obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
  *   pe | S_enc S_d1 S_d2 ([n_block][n_head][N][64][64], updated in place) | scratch xn ([N*A] rows), done [N] u8 or NULL (envs whose
  *   episode just ended: their carried states read as zero, rec_magpo.py:164-169), scratch qkvg u y rep reppe hv ([N*A] rows) |
- *   xa kin1 y1 c cpe y2 xo xope hp hn logits ([N] rows) | u1 u2 ([N*A] rows) | prev [N][A] i32 | action [N][A] i32, logp, value [N][A];
+ *   xa kin1 y1 c cpe y2 xo xope hp hn logits ([N] rows) | u1 u2 ([N*A] rows) | prev [N][A] i32 | action [N][A] i32, logp, value [N][A] |
+ *   ptab [N][K + 2][64] scratch (n_head = 1: block-0 self-retention candidate table);
  * blk_ptrs_host[21 * n_block]: qkvg_t wo_t ln1 ln2 gn_g gn_b | qkvg1_t wo1_t dln1 gn1_g gn1_b | q2_t kvg2_t wo2_t dln2 dln3 gn2_g gn2_b |
  *   scratch qkvg1 [N*A][256], q2 [N*A][64], kvg2 [N*A][256] (rows [k | v | - | q2 (kappa S)]).   (*_t = transposed weights as produced by magpo_transpose_pad) */
 int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs_host,

@@ -15,6 +15,21 @@
 //     the state layout through a small per-wave LDS tile; GroupNorm + swish gate are fused behind it;
 //   * sampling: the logits never leave registers; gumbel noise from the JAX threefry stream (rl.hip: k_sample).
 // Only what later agents / the training pass need goes to (L2-resident) scratch: this step's k, v rows, obs_rep, q2.
+//
+// HBM traffic = the retention states, so every state is read ONCE and written ONCE per env step:
+//   * encoder state: one pass (all A tokens are known up front);
+//   * decoder states: the update S <- kappa S + sum_a k_a^T v_a of step t needs all A decoded tokens, the outputs of step t need
+//     kappa S while the tokens are still being decoded.  The update is therefore DEFERRED to the next launch: memory holds the state
+//     that ENTERED the last step plus that step's k | v rows (the scratch rows blk[].qkvg1 / blk[].kvg2 persist between launches);
+//     the next launch's pre-pass loads the state once, adds the pending rows, applies the episode-end zeroing, writes it back and
+//     computes from registers everything the decoder needs from kappa S:
+//       - cross-retention: q2_a (kappa S) for all agents (the query is the encoder's, known before the decoder starts);
+//       - self-retention, block 0, one head: q_c (kappa S) for EVERY candidate previous action c (the block-0 query is a function of
+//         (previous action, step count) only: q = x_c W_q + pe W_q) -- a (K + 2) x 64 x 64 product per env on the otherwise idle
+//         16x16x4 fp32 MFMA with the state registers as B operand, instead of re-reading the state once per agent;
+//     the decoder iterations then only add the intra-step rank-1 terms in registers (cross_ret).  `flush` (the last launch of a
+//     rollout, or a stand-alone step) adds the rows of the current launch so that memory holds the true carried states again.
+//     Blocks > 0 and n_head > 1 keep the per-agent state pass (ret_pass mode 1) for the self-retention.
 #include "fm_rows.hpp"
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +51,11 @@ struct ActBlk {
 };
 struct ActArgs {
   int N, A, K, F, nb, nh, hs, gs, npos, value_only, ldo;   // ldo = floats between observation rows (>= F: wide observations are padded)
+  // Deferred decoder-state updates (see the header comment): pending = the k | v rows the PREVIOUS launch left in the scratch rows
+  // (blk[].qkvg1 / blk[].kvg2) have not been added to S_d1 / S_d2 yet; flush = add this launch's (or, for a value-only launch, the
+  // pending) rows before returning, so that the states in memory are the true carried states again.
+  int pending, flush;
+  float* ptab;              // [N][K + 2][64] block-0 self-retention: q_c (kappa S) for every candidate previous action c, row K + 1 = the positional part
   const float* obs; const int* pos; const unsigned char* mask; const uint32_t* keys_dev; uint32_t keys[16][2];
   const float *s_obs, *W_obs, *s_encln, *W_act, *s_decln;
   const float *vh0_t, *vh0_b, *vh_s, *vh_w, *vh_b1;
@@ -69,16 +89,21 @@ template <int MODE, int NA, int NBUF, int NH>
 __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* __restrict__ S0 /* head 0 of this block */, long NS,
                                          const ActArgs& a, int env0, int nvalid, int i, const float* __restrict__ hist, long ldh,
                                          int hcol, float* __restrict__ uout, long ldu, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, int write_state, unsigned long long dmask) {
+                                         const float* __restrict__ beta, int write_state, unsigned long long dmask,
+                                         const float* __restrict__ qsrc = nullptr, long ldq = 0, int apply_pending = 0) {
   const int lane = threadIdx.x, c4 = 4 * (lane & 15), rg = lane >> 4;
   const int A = a.A, nh = NH ? NH : a.nh, hs = NH ? AE / NH : a.hs, gs = NH ? AE / (NH * NH) : a.gs;   // NH = 0: run-time head count
   // MODE 0 (encoder): all A tokens staged as [q|k|v|g] rows, state update + write, gated output -> global uout
   // MODE 1 (decoder self-retention, agent i): tokens a < i staged (k|v), token i from TQ, output u_i -> LDS U, state written at the last agent
   // MODE 2 (cross-retention pre-pass): q rows of all A agents staged, RAW q_a (kappa S) -> global uout, state untouched
-  // MODE 3 (cross-retention, after the last agent): k|v rows of all A agents staged, state update + write, no output
+  // MODE 3 (flush): k|v rows of all A agents staged, state update + write, no output
+  // MODE 4 (decoder pre-pass with queries): s = kappa s (+ the pending k|v rows of the previous launch); zero where the episode just
+  //         ended; WRITE (the state that enters this step); then raw q_a (kappa s) -> global uout for the A staged query rows (qsrc)
+  // MODE 5 (decoder pre-pass, no outputs): the same without queries
   constexpr bool ENC = MODE == 0;
-  constexpr bool DO_UPD = MODE != 2, DO_OUT = MODE != 3;
-  const int ntok = MODE == 1 ? i + 1 : A, ret_from = MODE == 1 ? i : 0, nstage = MODE == 1 ? i : A;
+  constexpr bool PRE = MODE == 4 || MODE == 5;
+  constexpr bool DO_UPD = MODE != 2, DO_OUT = MODE != 3 && MODE != 5;
+  const int ntok = MODE == 1 ? i + 1 : (PRE && !apply_pending ? 0 : A), ret_from = MODE == 1 ? i : 0, nstage = MODE == 1 ? i : A;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool colin = c4 < hs, rowin = 16 * rg < hs;
   const float inv_gs = 1.0f / (float)gs;
@@ -105,6 +130,10 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
       if (t < nstage) {
         if (ENC) tok[t] = ld4g(hist + (row0 + t) * ldh + 4 * lane);
         else if (MODE == 2) { if (lane < 16) tok[t] = ld4g(hist + (row0 + t) * ldh + 4 * lane); }
+        else if (MODE == 4) {   // lanes 0-15: this step's query row; lanes 16-47: the pending k | v row of the previous launch
+          if (lane < 16) tok[t] = ld4g(qsrc + (row0 + t) * ldq + 4 * lane);
+          else if (lane < 48) tok[t] = ld4g(hist + (row0 + t) * ldh + hcol + 4 * (lane - 16));
+        }
         else if (lane < 32) tok[t] = ld4g(hist + (row0 + t) * ldh + hcol + 4 * lane);
       }
     }
@@ -130,13 +159,15 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
         if (t < nstage) {
           if (ENC) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[j][t];
           else if (MODE == 2) { if (lane < 16) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[j][t]; }
+          else if (MODE == 4) { if (lane < 48) *reinterpret_cast<float4*>(HK + t * QP + 4 * lane) = hreg[j][t]; }   // q at 0, k | v at 64
           else if (lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[j][t];
         }
       }
       lsync();   // LDS only: a workgroup-scope fence here would drain the prefetches (vmcnt(0))
       RT(1);
       // episode ended on the previous step: the carried state is zero (rec_magpo.py:164-169)
-      const float decay = ((dmask >> e) & 1ull) ? 0.f : a.kappa[h];
+      // (pre-pass: the state in memory already carries the zeroing of ITS step; this step's zeroing follows the pending update)
+      const float decay = (!PRE && ((dmask >> e) & 1ull)) ? 0.f : a.kappa[h];
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r].x *= decay; s[r].y *= decay; s[r].z *= decay; s[r].w *= decay; }
 #pragma unroll
@@ -157,14 +188,24 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
         }
       }
       RT(2);
+      if (PRE) {   // episode ended on the previous step: the state that enters this step is zero (rec_magpo.py:164-169)
+        const float keep = ((dmask >> e) & 1ull) ? 0.f : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r].x *= keep; s[r].y *= keep; s[r].z *= keep; s[r].w *= keep; }
+      }
       if (write_state && live) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st4nt(Se + (16 * rg + r) * 64 + c4, s[r]);
       }
+      if (MODE == 4) {   // the outputs see kappa S
+        const float kp = a.kappa[h];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r].x *= kp; s[r].y *= kp; s[r].z *= kp; s[r].w *= kp; }
+      }
       RT(3);
 #pragma unroll
       for (int t = 0; t < NA; ++t) {
-        if (!DO_OUT || t < ret_from || t >= ntok) continue;
+        if (!DO_OUT || t < ret_from || t >= (MODE == 4 ? A : ntok)) continue;
         const float* tk = (MODE != 1 || t < i) ? HK + t * QP : TQ + e * QP;
         float4 p = z4;
 #pragma unroll
@@ -182,7 +223,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
         s1 = gsum(s1, gs >> 2); s2 = gsum(s2, gs >> 2);
         const float mu = s1 * inv_gs, m2 = s2 * inv_gs;
         const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
-        if (MODE == 2) {   // raw q (kappa S): the intra-step terms, GroupNorm and gate follow in registers (cross_ret)
+        if (MODE == 2 || MODE == 4) {   // raw q (kappa S): the intra-step terms, GroupNorm and gate follow in registers (cross_ret)
           if (colin && rg == 0 && live) st4g(uout + (row0 + t) * ldu + o + c4, p);
           continue;
         }
@@ -203,6 +244,105 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
   RT_FLUSH();
 }
 
+// ---- decoder self-retention pre-pass, block 0, one head: the candidate table ---------------------------------------------------
+// For every env of the wave: S <- kappa S (+ pending k_a^T v_a of the previous launch), zero where the episode just ended, WRITE;
+// then P[c] = q_c (kappa S) for the K + 1 candidate previous actions c (q_c = x_c W_q, x_c = rms(gelu(W_act[c])) s) and
+// P[K + 1] = (pe W_q) (kappa S), the positional part of the query -- the block-0 query of agent i is q = x_prev W_q + pe W_q, so the
+// decoder reads rows `prev` and K + 1 of its env's table instead of the state (ptab [N][K + 2][64]).
+// The product runs on v_mfma_f32_16x16x4_f32: A = candidate rows (tile row m = l & 15 -> candidate 16 mt + m, features in the Row
+// layout), B = the state registers.  For that the lane (col group n = l & 15, kq = l >> 4) holds state rows rho(j) = 16 (j >> 2) +
+// 4 kq + (j & 3), j < 16 -- the Row feature order -- of columns 4 n .. 4 n + 3; k-step j multiplies feature rho(j) on both sides.
+// Output tile (mt, nt): lane holds candidates 16 mt + 4 kq + i (i < 4) of column 4 n + nt, i.e. one float4 of row c per lane.
+template <int NA, int MT>
+__device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* __restrict__ S0, const ActArgs& a, int env0, int nvalid,
+                                                  const float* __restrict__ pend, const Row (&xq)[MT], unsigned long long dmask) {
+  const int lane = threadIdx.x, n16 = lane & 15, c4 = 4 * n16, kq = lane >> 4, A = a.A;
+  const float kappa = a.kappa[0];
+  const int pe_row = a.K + 1, pe_mt = pe_row >> 4, pe_m = pe_row & 15;
+  float4 buf[2][16], hreg[2][NA];
+  auto prefetch = [&](float4 (&dst)[16], float4 (&tok)[NA], int e) {
+    e = min(e, nvalid - 1);
+    const float* Se = S0 + (long)(env0 + e) * 4096;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j] = ld4nt(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4);
+    const long row0 = (long)(env0 + e) * A;
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+      if (t < A && lane < 32) tok[t] = ld4g(pend + (row0 + t) * 256 + 64 + 4 * lane);   // k | v of the previous launch (qkvg1 rows)
+  };
+  prefetch(buf[0], hreg[0], 0);
+  for (int base = 0; base < nvalid; base += 2) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const int e = min(base + jb, nvalid - 1);
+      const bool live = base + jb < nvalid;
+      float4 (&s)[16] = buf[jb];
+      prefetch(buf[jb ^ 1], hreg[jb ^ 1], base + jb + 1);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < NA; ++t)
+        if (t < A && lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[jb][t];
+      lsync();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { s[j].x *= kappa; s[j].y *= kappa; s[j].z *= kappa; s[j].w *= kappa; }
+      if (a.pending) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+          if (t < A) {
+            const float4 vv = *reinterpret_cast<const float4*>(HK + t * QP + 128 + c4);
+            float kk[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 k4 = *reinterpret_cast<const float4*>(HK + t * QP + 64 + 16 * g + 4 * kq);
+              kk[4 * g] = k4.x; kk[4 * g + 1] = k4.y; kk[4 * g + 2] = k4.z; kk[4 * g + 3] = k4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { s[j].x += kk[j] * vv.x; s[j].y += kk[j] * vv.y; s[j].z += kk[j] * vv.z; s[j].w += kk[j] * vv.w; }
+          }
+        }
+      }
+      const float keep = ((dmask >> e) & 1ull) ? 0.f : 1.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { s[j].x *= keep; s[j].y *= keep; s[j].z *= keep; s[j].w *= keep; }
+      if (live) {
+        float* Se = S0 + (long)(env0 + e) * 4096;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st4nt(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4, s[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { s[j].x *= kappa; s[j].y *= kappa; s[j].z *= kappa; s[j].w *= kappa; }
+      // positional query row of this env (features in the Row order of this lane's kq)
+      float qp[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 t4 = *reinterpret_cast<const float4*>(PEQ + e * 64 + 16 * g + 4 * kq);
+        qp[4 * g] = t4.x; qp[4 * g + 1] = t4.y; qp[4 * g + 2] = t4.z; qp[4 * g + 3] = t4.w;
+      }
+      float* prow = a.ptab + (long)(env0 + e) * (a.K + 2) * 64;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool pe_lane = mt == pe_mt && n16 == pe_m;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float av = pe_lane ? qp[j] : xq[mt].v[j];
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[j].x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[j].y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[j].z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[j].w, acc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = 16 * mt + 4 * kq + i;
+          if (live && c <= pe_row) st4g(prow + (long)c * 64 + c4, make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]));
+        }
+      }
+    }
+  }
+}
+
 // ---- cross-retention of agent i in registers (feature-major rows, all envs of the wave at once) --------------------------
 //   r = P2_i + sum_{a <= i} (q_i . k_a)_head v_a ,  u = swish(g_i) * GroupNorm(r)
 // P2_i = q_i (kappa S) comes from the pre-pass (the cross-retention query is the encoder's, so it is known for every agent
@@ -211,12 +351,11 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
 // hist (NA > 4 only): the k | v history rows of this env (token t at hist + t * 256, v at + 64) are then streamed through two row
 // pairs (one in use, one in flight) instead of being held for all NA - 1 earlier agents at once: 14 rows = 224 VGPRs for 8-agent
 // teams, which the register file does not have beside the state buffers (249 values went to scratch).
-template <int NH, int NA>
+template <int NH, int NA, bool STREAM = (NA > 4)>
 __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const Row& kc, const Row& vc, const Row& gc, const Row& p2,
                                          const Row (&hk)[NA - 1], const Row (&hv)[NA - 1], int i, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, int kq, const float* __restrict__ hist = nullptr) {
   const int nh = NH ? NH : a.nh, hs = AE / nh;
-  constexpr bool STREAM = NA > 4;
   Row r = p2;
   Row nk, nv;   // STREAM: rows of token t, requested while token t - 1 is being used
   if (STREAM && i > 0) { nk = row_load(hist, kq); nv = row_load(hist + 64, kq); }
@@ -299,12 +438,13 @@ __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const R
 constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
 
 template <int EPW, int NA, int NH>
-__global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
+__global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* TQ = smem;                  // [EPW][QP]  this iteration's [q|k|v|g] rows, one per env
   float* HK = TQ + EPW * QP;         // [A][QP]    staged token rows of the env being processed
   float* U = HK + a.A * QP;          // [EPW][UP]  gated retention output, one row per env
   float* XS = U + EPW * UP;          // [EPW][UP]  block input x parked across the self-retention (register relief)
+  float* PEQ = XS + EPW * UP;        // [EPW][64]  pe W_q of every env (candidate pre-pass)
 #ifdef MAGPO_ACT_PROF
   unsigned long long t_last = wall_clock64();
 #endif
@@ -385,13 +525,50 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
     PROF(0);
   }
   PROF(3);
-  if (a.value_only) return;   // uniform: bootstrap value only (rec_magpo.py:202-208)
+  constexpr int NBF = EPW == 16 ? ACT_NBUF16 : 2;
+  // candidate path of the block-0 self-retention: one head (the state tile is the whole 64 x 64 matrix)
+  const bool cand = nh_ == 1;
+  // flush: S <- kappa S + sum_a k_a^T v_a with the rows in the scratch (this launch's, or the pending ones of the previous launch)
+  auto flush_states = [&]() {
+    wsync();
+    for (int b = 0; b < nb; ++b) {
+      const ActBlk& B = a.blk[b];
+      ret_pass<3, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 1, 0ull);
+      ret_pass<3, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, nullptr, 0, B.gn2_g, B.gn2_b, 1, 0ull);
+    }
+  };
+  if (a.value_only) {   // uniform: bootstrap value only (rec_magpo.py:202-208); the last launch of a rollout also settles the decoder states
+    if (a.flush && a.pending) flush_states();
+    return;
+  }
 
-  // cross-retention pre-pass: q2_a (kappa S_d2) for every agent, one state read per env and block
+  // decoder pre-pass: every decoder state is loaded once, brought up to date (pending rows of the previous launch, episode-end
+  // zeroing), written back, and gives from registers what the decoder needs from kappa S
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
-    ret_pass<2, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.q2, AE, 0, B.kvg2 + 192, 256, B.gn2_g,
-                                            B.gn2_b, 0, dmask);
+    ret_pass<4, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
+                             B.q2, AE, a.pending);
+    if (b == 0 && cand) {
+      // candidate query rows q_c = x_c W_q (tile row = candidate) and the positional query rows pe W_q of this wave's envs
+      const Row qpe = dense64(pe, B.qkvg1_t, nullptr, m, kq);
+      row_store(PEQ + env * 64, kq, qpe);
+      lsync();
+      const int ntile = (a.K + 2 + 15) >> 4;
+#define CAND_ROWS(MT_)                                                                                                        \
+      {                                                                                                                        \
+        Row xq[MT_];                                                                                                           \
+        _Pragma("unroll") for (int mt = 0; mt < MT_; ++mt) {                                                                   \
+          const int c = min(16 * mt + env, a.K);                                                                               \
+          xq[mt] = dense64(row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq), B.qkvg1_t, nullptr, m, kq); \
+        }                                                                                                                      \
+        self_prepass_cand<NA, MT_>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask);                                      \
+      }
+      if (ntile == 1) CAND_ROWS(1) else if (ntile == 2) CAND_ROWS(2) else CAND_ROWS(3)
+#undef CAND_ROWS
+    } else {
+      ret_pass<5, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 1, dmask,
+                               nullptr, 0, a.pending);
+    }
   }
   wsync();
   PROF(1);
@@ -399,7 +576,6 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
   // ---------------- autoregressive decoder (decode.py:111-153): token i of every env
   int prev = 0;   // 0 = start token, action + 1 afterwards
   for (int i = 0; i < A; ++i) {
-    const int last = i == A - 1;
     const long row = ge * A + i;
     Row xo;
     for (int b = 0; b < nb; ++b) {
@@ -407,25 +583,48 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
       Row xin;
       if (b == 0) xin = row_rms(row_gelu(row_load(a.W_act + (long)prev * AE, kq)), a.s_decln, kq);   // action embedding (:258-267)
       else xin = xo;
-      if (valid) row_store(XS + env * UP, kq, xin);
-      {
+      Row cpe;
+      if (b == 0 && cand) {
+        // self-retention from the candidate table: r = P[prev] + P[pe] + sum_{a <= i} (q . k_a) v_a, everything in registers
+        const float* pt = a.ptab + ge * (long)(a.K + 2) * 64;
+        const Row pc = row_load(pt + (long)prev * 64, kq), pp = row_load(pt + (long)(a.K + 1) * 64, kq);
+        Row hk1[NA - 1], hv1[NA - 1];   // (unused: the history rows of the earlier agents are streamed, two row pairs at a time)
         const Row kin = row_add(xin, pe);
+        Row q1, k1, v1, g1;
         float* hrow = B.qkvg1 + row * 256;
         wgemm<16>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
-          const float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
-          if (valid) {
-            *reinterpret_cast<float4*>(TQ + env * QP + 16 * g + 4 * kq) = v4;
-            if (g >= 4 && g < 12) st4g(hrow + 16 * g + 4 * kq, v4);   // k, v of this token: history for the later agents
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (g < 4) q1.v[4 * g + c] = acc[c];
+            else if (g < 8) k1.v[4 * (g - 4) + c] = acc[c];
+            else if (g < 12) v1.v[4 * (g - 8) + c] = acc[c];
+            else g1.v[4 * (g - 12) + c] = acc[c];
           }
+          if (valid && g >= 4 && g < 12) st4g(hrow + 16 * g + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));   // k, v: history / pending rows
         });
-      }
-      wsync();
-      PROF(0);
-      ret_pass<1, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, last, dmask);
-      wsync();
-      PROF(1);
-      Row cpe;
-      {
+        const Row u1 = cross_ret<NH, NA, true>(a, q1, k1, v1, g1, row_add(pc, pp), hk1, hv1, i, B.gn1_g, B.gn1_b, kq, B.qkvg1 + ge * A * 256 + 64);
+        PROF(0);
+        const Row y1 = dense64(u1, B.wo1_t, nullptr, m, kq);
+        cpe = row_add(row_rms(row_add(xin, y1), B.dln1, kq), pe);
+      } else {
+        if (valid) row_store(XS + env * UP, kq, xin);
+        {
+          const Row kin = row_add(xin, pe);
+          float* hrow = B.qkvg1 + row * 256;
+          wgemm<16>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
+            const float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (valid) {
+              *reinterpret_cast<float4*>(TQ + env * QP + 16 * g + 4 * kq) = v4;
+              if (g >= 4 && g < 12) st4g(hrow + 16 * g + 4 * kq, v4);   // k, v of this token: history for the later agents
+            }
+          });
+        }
+        wsync();
+        PROF(0);
+        // the state in memory is the one that entered this step (pre-pass): no zeroing, never written here
+        ret_pass<1, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 0, 0ull);
+        wsync();
+        PROF(1);
         const Row y1 = dense64(row_load(U + le * UP, kq), B.wo1_t, nullptr, m, kq);
         cpe = row_add(row_rms(row_add(row_load(XS + le * UP, kq), y1), B.dln1, kq), pe);
       }
@@ -454,12 +653,6 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
         });
         const Row u2 = cross_ret<NH, NA>(a, q2, k2, v2, g2, p2, hk2, hv2, i, B.gn2_g, B.gn2_b, kq, B.kvg2 + ge * A * 256);
         PROF(0);
-        if (last) {   // all A tokens are known: S <- kappa S + sum_a k_a^T v_a  (one read + one write per env)
-          wsync();
-          ret_pass<3, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, nullptr, 0, B.gn2_g,
-                                                  B.gn2_b, 1, dmask);
-          PROF(1);
-        }
         const Row y2 = dense64(u2, B.wo2_t, nullptr, m, kq);
         const Row repi = row_load(a.rep + row * AE, kq);
         xo = row_rms(row_rms(row_add(repi, y2), B.dln2, kq), B.dln3, kq);
@@ -518,6 +711,7 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
     prev = arg + 1;
     PROF(2);
   }
+  if (a.flush) flush_states();   // stand-alone step (or last step of a rollout without a value launch): settle the decoder states now
 }
 
 }  // namespace magpo
@@ -525,7 +719,7 @@ __global__ __launch_bounds__(64, EPW == 8 ? 2 : 1) void k_sable_act(ActArgs a) {
 using namespace magpo;
 
 template <int EPW> static void launch_act(const ActArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)((EPW + a.A) * QP + 2 * EPW * UP) * sizeof(float);
+  const size_t lds = (size_t)((EPW + a.A) * QP + 2 * EPW * UP + EPW * 64) * sizeof(float);
   const dim3 grid((a.N + EPW - 1) / EPW), blk(64);
   if (a.A <= 4 && a.nh == 1) hipLaunchKernelGGL((k_sable_act<EPW, 4, 1>), grid, blk, lds, st, a);   // the benchmark shape: everything static
   else if (a.A <= 4) hipLaunchKernelGGL((k_sable_act<EPW, 4, 0>), grid, blk, lds, st, a);
@@ -533,21 +727,22 @@ template <int EPW> static void launch_act(const ActArgs& a, hipStream_t st) {
 }
 
 // Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
-//   dims_host[11] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride}; kappa_host[4]; keys_host [A][2] or NULL (then
-//   ptrs[3] = device key table);  ptrs_host[48] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
+//   dims_host[14] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride, envs per wave, pending, flush}; kappa_host[4];
+//   keys_host [A][2] or NULL (then ptrs[3] = device key table);  ptrs_host[49] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
 extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs,
                                int nptrs, const void* const* blk_ptrs, int nblk_ptrs, hipStream_t st) {
   ActArgs a;
   memset(&a, 0, sizeof(a));
   a.N = dims_host[0]; a.A = dims_host[1]; a.K = dims_host[2]; a.F = dims_host[3]; a.nb = dims_host[4]; a.nh = dims_host[5];
   a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9]; a.ldo = dims_host[10];
+  a.pending = dims_host[12] != 0; a.flush = dims_host[13] != 0;
   if (a.N <= 0) return MAGPO_OK;
   if (a.A < 1 || a.A > MAXA || a.nb < 1 || a.nb > MAXB || a.nh < 1 || a.nh > 4 || a.K < 1 || a.K > 64 || a.F < 1 || a.hs * a.nh != AE ||
       a.gs < 4 || a.gs > a.hs || (a.gs & (a.gs - 1)) || a.npos < 1 || a.ldo < a.F) {
     set_error("magpo_sable_act: unsupported shape (1 <= A <= 8, n_block <= 4, n_head in {1,2,4}, K <= 64)");
     return MAGPO_EINVAL;
   }
-  if (nptrs != 48 || nblk_ptrs != 21 * a.nb) { set_error("magpo_sable_act: pointer table size mismatch"); return MAGPO_EINVAL; }
+  if (nptrs != 49 || nblk_ptrs != 21 * a.nb) { set_error("magpo_sable_act: pointer table size mismatch"); return MAGPO_EINVAL; }
   for (int i = 0; i < 4; ++i) a.kappa[i] = kappa_host[i];
   if (keys_host) for (int i = 0; i < a.A; ++i) { a.keys[i][0] = keys_host[2 * i]; a.keys[i][1] = keys_host[2 * i + 1]; }
   int p = 0;
@@ -561,8 +756,9 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   P(float*, xn) P(const unsigned char*, done) P(float*, qkvg) P(float*, u) P(float*, y) P(float*, rep) P(float*, reppe) P(float*, hv)
   P(float*, xa) P(float*, kin1) P(float*, y1) P(float*, c) P(float*, cpe) P(float*, y2) P(float*, xo) P(float*, xope) P(float*, hp)
   P(float*, hn) P(float*, logits) P(float*, u1) P(float*, u2) P(int*, prev)
-  P(int*, action) P(float*, logp) P(float*, value)
+  P(int*, action) P(float*, logp) P(float*, value) P(float*, ptab)
 #undef P
+  if (!a.value_only && a.nh == 1 && !a.ptab) { set_error("magpo_sable_act: the candidate table (ptrs[48]) is required for n_head = 1"); return MAGPO_EINVAL; }
   if (!keys_host && !a.keys_dev && !a.value_only) { set_error("magpo_sable_act: no sampling keys"); return MAGPO_EINVAL; }
   for (int b = 0; b < a.nb; ++b) {
     const void* const* q = blk_ptrs + 21 * b;
@@ -578,7 +774,7 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   // envs per wave: N = 1024 -> 204 / 311 / 335 us, 2048 -> 237 / 331 / 348, 4096 -> 327 / 396 / 361, 8192 -> 606 / 553 / 434, 16384 -> 1360 / 922 / 698;
   // A = 8, two blocks (before the one-wave bound of the 4-env waves): N = 1024 -> 1114 / 1363 / 1882, 4096 -> 1691 / 1679 / 2088, 16384 -> 5212 / 4905 / 2340): few envs per wave while the
   // waves fit the chip's 1024 SIMDs (a rollout step is a latency chain per wave), full MFMA tiles and less weight traffic once they do not.
-  // 4- and 16-env waves run at one wave per SIMD (512 registers, no scratch), 8-env waves at two.
+  // All variants run at one wave per SIMD (512 registers, no scratch).
   int epw;
   if (a.A <= 4) epw = a.N > 4096 ? 16 : 4;
   else epw = a.N >= 16384 ? 16 : (a.N >= 4096 ? 8 : 4);

@@ -462,14 +462,16 @@ class MagpoLearner:
                     self.actor.step(obs, h_in, done_prev, h_out)
                 g.cur = 1 - g.cur
             mk = None if tr["mask"] is None else tr["mask"][t]
-            if fused:   # states of envs whose episode just ended read as zero inside the kernel (rec_magpo.py:164-169)
-                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], done=done_prev, mask=mk)
+            if fused:   # states of envs whose episode just ended read as zero inside the kernel (rec_magpo.py:164-169); the decoder-state
+                # update of a step is deferred to the next launch (each state read + written once per step, csrc/act_fused.hip)
+                act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], done=done_prev, mask=mk,
+                    pending=t > 0, flush=False)
             else:
                 act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], mask=mk)
             g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
                        g.metrics["episode_return"][t], g.metrics["episode_length"][t], g.metrics["is_terminal_step"][t],
                        mask=None if tr["mask"] is None else tr["mask"][t + 1])
-            if not fused or t == T - 1:
+            if not fused:
                 zero_done(tr["done"][t + 1])
         if side is not None:
             main.wait_stream(side)
@@ -485,7 +487,11 @@ class MagpoLearner:
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])
             g.cur = 0
-        act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
+        if fused:   # bootstrap value (encoder states of just-ended episodes read as zero) + the last step's pending decoder-state update
+            act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True, done=tr["done"][T], pending=True, flush=True)
+            zero_done(tr["done"][T])
+        else:
+            act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
         L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], g.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
                self.sys.gamma, self.sys.gae_lambda, st)
 

@@ -306,15 +306,20 @@ class SableGuider:
             L.call("magpo_sample_categorical", logits, E, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
                    k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
 
-    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag=""):
-        """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a wave carries 8 envs
+    def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag="",
+                  pending=False, flush=True):
+        """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a wave carries 4 - 16 envs
         through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64].  ``done`` [N] u8
         (optional): envs whose episode ended on the previous step -- their carried states are read as zero
-        (rec_magpo.py:164-169), which replaces a separate zeroing pass between steps."""
+        (rec_magpo.py:164-169), which replaces a separate zeroing pass between steps.
+        ``pending`` / ``flush``: the kernel defers a step's decoder-state update to the next launch so that every state is read and
+        written once per step (include/magpo.h).  The defaults {False, True} are a stand-alone step (states settled on return); a
+        rollout passes pending = (t > 0), flush = False and ends with a launch that has flush = True (the bootstrap-value launch).
+        The scratch rows that carry the pending k | v rows belong to ``tag``."""
         A, K, F, nb, nh = self.A, self.K, self.F, self.nb, self.nh
         if A > 8 and self.wide:
             raise NotImplementedError("wide observations (obs_dim > 32) with more than 8 agents")
-        if A > 8:   # token staging registers of the fused kernel: larger teams take the kernel-by-kernel path
+        if A > 8:   # token staging registers of the fused kernel: larger teams take the kernel-by-kernel path (states settled on return)
             if done is not None:
                 for k in range(nb):
                     for h in range(nh):
@@ -325,7 +330,7 @@ class SableGuider:
         v, b = self.v, self.b
         s_enc, s_d1, s_d2 = states   # value_only (bootstrap value, rec_magpo.py:202-208): the kernel writes no state
         kdev = sample_keys if torch.is_tensor(sample_keys) else None
-        cache_key = (N, bool(value_only), self.tuning.act_envs_per_wave, obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
+        cache_key = (N, bool(value_only), bool(pending), bool(flush), self.tuning.act_envs_per_wave, obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
                      None if kdev is None else kdev.data_ptr(), s_enc.data_ptr(), s_d1.data_ptr(), s_d2.data_ptr(),
                      None if action_out is None else action_out.data_ptr(), None if logp_out is None else logp_out.data_ptr(),
                      value_out.data_ptr(), None if done is None else done.data_ptr())
@@ -341,7 +346,8 @@ class SableGuider:
                     g("xn"), done, g("qkvg", 4 * E), g("u"), g("y"), g("rep"), g("reppe"), g("hv"),
                     g("xa", E, N), g("kin1", E, N), g("y1", E, N), g("c", E, N), g("cpe", E, N), g("y2", E, N), g("xo", E, N),
                     g("xope", E, N), g("hp", E, N), g("hn", E, N), g("logits", E, N), g("u1"), g("u2"),
-                    b.get(f"f{tag}_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out]
+                    b.get(f"f{tag}_prev", (N, A), torch.int32, zero=True), action_out, logp_out, value_out,
+                    b.get(f"f{tag}_ptab", (N, (K + 2) * E)) if nh == 1 else None]
             blk = []
             for k in range(nb):
                 e, d = f"enc.block{k}.", f"dec.block{k}."
@@ -350,7 +356,8 @@ class SableGuider:
                         self.wt[f"q2{k}"], self.wt[f"kvg2{k}"], self.wt[f"wo2{k}"], v[d + "ln2.scale"], v[d + "ln3.scale"],
                         v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
                         g(f"qkvg1_{k}", 4 * E), g(f"q2_{k}"), g(f"kvg2_{k}", 4 * E)]   # kvg2 rows: [k | v | - | P2] (ld 256)
-            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld, self.tuning.act_envs_per_wave], dtype=np.int32),
+            tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld, self.tuning.act_envs_per_wave,
+                              1 if pending else 0, 1 if flush else 0], dtype=np.int32),
                     np.array((self.kappas + [0.0] * 4)[:4], dtype=np.float32),
                     np.array([ptr(t) for t in glob], dtype=np.uint64), np.array([ptr(t) for t in blk], dtype=np.uint64))
             if len(self._act_tabs) > 4096:
