@@ -118,38 +118,39 @@ int magpo_transpose_pad(const float* W, float* Wt, int K, int N, int Npad, magpo
 int magpo_small_linear(const float* X, int ldx, int F, const float* W, const float* b, float* Y, int ldy, int N,
                        long R, int relu, magpo_stream_t stream);
 
-/* ---- token-local Sable rows (sable_network.py:62-71,93-137,188-217,255-319; retention.py:289-294) ---- */
+/* ---- token-local Sable rows (sable_network.py:62-71,93-137,188-217,255-319; retention.py:289-294) ----
+ * E = row width = embed_dim of the device network: 64 (16 lanes x float4 per row) or 128 (32 lanes); slabs are [grid][E]. */
 int magpo_row_grid(long R);
 int magpo_pe_table(float* pe, int npos, int E, magpo_stream_t stream);
 /* embed: z (forward) and z / dz (backward) are nullable -- the backward then recomputes the pre-activation from obs / idx (pass W) */
 int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const float* s_obs, const float* W,
                     const int* idx, int idx_stride, const float* s_ln, const float* pe, const int* pos,
                     int pos_stride, int npos, float* z, int ldz, float* xn, int ldxn, float* kin, int ldkin,
-                    long R, magpo_stream_t stream);
+                    long R, int E, magpo_stream_t stream);
 int magpo_embed_bwd(int mode, const float* z, int ldz, const float* d0, int ldd0, const float* d1, int ldd1,
                     const float* d2, int ldd2, const float* s_ln, float* dz, int lddz, float* slab_sln,
                     float* slab_w, int nrows, const float* obs, int ldo, int F, const float* s_obs, const float* W,
-                    float* slab_sobs, const int* idx, int idx_stride, long R, magpo_stream_t stream);
+                    float* slab_sobs, const int* idx, int idx_stride, long R, int E, magpo_stream_t stream);
 int magpo_small_relu_wgrad(const float* X, int ldx, int F, const float* Yact, const float* dY, float* slab_w, long R,
                            magpo_stream_t stream);
 int magpo_small_operand(int mode, const float* obs, int ldo, int F, const float* s_obs, const int* idx,
                         int idx_stride, float* out, long R, magpo_stream_t stream);
 int magpo_retpost_fwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
-                      float* u, int ldu, long R, int hs, int gs, magpo_stream_t stream);
+                      float* u, int ldu, long R, int hs, int gs, int E, magpo_stream_t stream);
 int magpo_retpost_bwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
                       const float* du, int lddu, float* dr, int lddr, float* dgp, int lddg, float* slab_gamma,
-                      float* slab_beta, long R, int hs, int gs, magpo_stream_t stream);
+                      float* slab_beta, long R, int hs, int gs, int E, magpo_stream_t stream);
 int magpo_resnorm_fwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
                       const float* pe, const int* pos, int pos_stride, int npos, float* out, int ldout,
-                      float* outpe, int ldoutpe, long R, magpo_stream_t stream);
+                      float* outpe, int ldoutpe, long R, int E, magpo_stream_t stream);
 int magpo_resnorm_bwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
                       const float* d0, int ldd0, const float* d1, int ldd1, const float* d2, int ldd2,
-                      float* dsum, int lddsum, float* slab_s1, float* slab_s2, long R, magpo_stream_t stream);
+                      float* dsum, int lddsum, float* slab_s1, float* slab_s2, long R, int E, magpo_stream_t stream);
 int magpo_headmid_fwd(const float* hpre, int ldh, const float* s, float* hn, int ldhn, const float* w,
-                      const float* b, float* value, int value_stride, long R, magpo_stream_t stream);
+                      const float* b, float* value, int value_stride, long R, int E, magpo_stream_t stream);
 int magpo_headmid_bwd(const float* hpre, int ldh, const float* s, const float* dhn, int lddhn, const float* w,
                       const float* dvalue, int dvalue_stride, float* dhpre, int lddh, float* slab_s,
-                      float* slab_w, float* slab_b, long R, magpo_stream_t stream);
+                      float* slab_w, float* slab_b, long R, int E, magpo_stream_t stream);
 /* wide observations (obs_dim > 32: rows padded to 128 columns, first layers on the MFMA dense kernels; csrc/wideobs.hip):
  * on = RMSNorm_F(obs) * s_obs (sable_network.py:93-95), its s_obs gradient as [magpo_obsnorm_grid(R)][128] slabs, and x + pe[pos] */
 int magpo_obsnorm_grid(long R);

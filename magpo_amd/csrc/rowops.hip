@@ -22,42 +22,53 @@ __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float
 __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// mean over aligned groups of gs channels (gs = 4, 8, 16, 32 or 64) of a 64-wide row held as float4 by 16 lanes
+// Row geometry: a W-wide row (W = embed_dim = 64 or 128) is held as float4 by LPR = W / 4 consecutive lanes, RPW = 64 / LPR rows per
+// wave, RPB = 4 RPW rows per 256-thread block.  Grids come from row_grid (sized for 16 rows per block; the kernels are grid-stride).
+template <int W> struct RowGeo { static constexpr int LPR = W / 4, RPW = 64 / LPR, RPB = 4 * RPW; };
+
+// mean over aligned groups of gs channels (gs = 4 ... W, a power of two) of a row
 __device__ __forceinline__ float groupmean(float4 v, int gs) {
   float s = f4sum(v);
   for (int o = gs >> 3; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   return s / (float)gs;
 }
-// mean over a 64-wide row held as float4 by 16 consecutive lanes
-__device__ __forceinline__ float rowmean64(float4 v) { return sum16(f4sum(v)) * (1.0f / 64.0f); }
+// all-reduce over the lanes of one row
+template <int W> __device__ __forceinline__ float rowsum(float v) {
+  v = sum16(v);
+  if (W == 128) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+template <int W> __device__ __forceinline__ float rowmean(float4 v) { return rowsum<W>(f4sum(v)) * (1.0f / (float)W); }
 
 struct RmsFwd { float4 y; float4 xhat; float rstd; };
-__device__ __forceinline__ RmsFwd rms_fwd(float4 x, float4 s) {
+template <int W> __device__ __forceinline__ RmsFwd rms_fwd(float4 x, float4 s) {
   RmsFwd o;
-  o.rstd = rsqrtf(rowmean64(f4mul(x, x)) + NORM_EPS);
+  o.rstd = rsqrtf(rowmean<W>(f4mul(x, x)) + NORM_EPS);
   o.xhat = f4scale(x, o.rstd);
   o.y = f4mul(o.xhat, s);
   return o;
 }
 // returns dx; accumulates ds
-__device__ __forceinline__ float4 rms_bwd(float4 dy, const RmsFwd& f, float4 s, float4& ds) {
+template <int W> __device__ __forceinline__ float4 rms_bwd(float4 dy, const RmsFwd& f, float4 s, float4& ds) {
   float4 g = f4mul(dy, s);
-  float dot = rowmean64(f4mul(g, f.xhat));
+  float dot = rowmean<W>(f4mul(g, f.xhat));
   ds = f4add(ds, f4mul(dy, f.xhat));
   return f4scale(make_float4(g.x - f.xhat.x * dot, g.y - f.xhat.y * dot, g.z - f.xhat.z * dot, g.w - f.xhat.w * dot), f.rstd);
 }
 
-// Sum a per-lane float4 accumulator over all rows handled by the workgroup and store 64 floats.
-__device__ __forceinline__ void block_store_colsum(float4 acc, float* __restrict__ out64, float* lds /*[4][64]*/) {
-  acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
-  acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+// Sum a per-lane float4 accumulator over all rows handled by the workgroup and store W floats.
+template <int W> __device__ __forceinline__ void block_store_colsum(float4 acc, float* __restrict__ outw, float* lds /*[4][W]*/) {
+  if (W == 64) {
+    acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+    acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+  }
   acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
   acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
-  if (lane < 16) st4(&lds[wave * 64 + 4 * lane], acc);
+  if (lane < W / 4) st4(&lds[wave * W + 4 * lane], acc);
   __syncthreads();
-  if (threadIdx.x < 64) out64[threadIdx.x] = (lds[threadIdx.x] + lds[64 + threadIdx.x]) + (lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
+  if (threadIdx.x < W) outw[threadIdx.x] = (lds[threadIdx.x] + lds[W + threadIdx.x]) + (lds[2 * W + threadIdx.x] + lds[3 * W + threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -107,12 +118,12 @@ __device__ __forceinline__ EmbedIn embed_fetch(const EmbedArgs& a, int mode, lon
   return in;
 }
 
-__global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+template <int W> __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 sln = ld4(a.s_ln + c4);
-  const long stride = (long)gridDim.x * ROWS_PER_BLOCK;
-  const long lrow = wave * 4 + (lane >> 4);
-  long base = (long)blockIdx.x * ROWS_PER_BLOCK;
+  const long stride = (long)gridDim.x * RowGeo<W>::RPB;
+  const long lrow = wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
+  long base = (long)blockIdx.x * RowGeo<W>::RPB;
   if (base >= a.R) return;
   EmbedIn nx = embed_fetch(a, mode, base + lrow);
   for (; base < a.R; base += stride) {
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
       for (int f = 0; f < 8; ++f) {
         if (f < a.F) {
           const float on = in.of[f] * rstd * a.s_obs[f];
-          const float4 w = ld4(a.W + f * 64 + c4);
+          const float4 w = ld4(a.W + f * W + c4);
           z.x += on * w.x; z.y += on * w.y; z.z += on * w.z; z.w += on * w.w;
         }
       }
@@ -142,18 +153,18 @@ __global__ __launch_bounds__(256) void k_embed_fwd(EmbedArgs a, int mode) {
         const float rstd = rsqrtf(ms / (float)a.F + NORM_EPS);
         for (int f = 0; f < a.F; ++f) {
           const float of = o[f] * rstd * a.s_obs[f];
-          const float4 w = ld4(a.W + f * 64 + c4);
+          const float4 w = ld4(a.W + f * W + c4);
           z.x += of * w.x; z.y += of * w.y; z.z += of * w.z; z.w += of * w.w;
         }
       }
     } else {
-      z = ld4(a.W + (long)in.idx * 64 + c4);
+      z = ld4(a.W + (long)in.idx * W + c4);
     }
     float4 x0 = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
-    RmsFwd n = rms_fwd(x0, sln);
+    RmsFwd n = rms_fwd<W>(x0, sln);
     int p = in.p;
     p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
-    const float4 pe = ld4(a.pe + (long)p * 64 + c4);
+    const float4 pe = ld4(a.pe + (long)p * W + c4);
     if (ok) {
       if (a.z) st4(a.z + row * a.ldz + c4, z);
       st4(a.xn + row * a.ldxn + c4, n.y);
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256) void k_embed_fwd_tile(EmbedArgs a) {
         z = ld4(a.W + (long)is[it][lrow] * 64 + c4);
       }
       const float4 g0 = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
-      const RmsFwd n = rms_fwd(g0, sln);
+      const RmsFwd n = rms_fwd<64>(g0, sln);
       int p = ps[it][lrow];
       p = p < 0 ? 0 : (p >= a.npos ? a.npos - 1 : p);
       const float4 pe = ld4(a.pe + (long)p * 64 + c4);
@@ -266,11 +277,11 @@ struct EmbedBwdArgs {
   long R;
 };
 
-template <int MODE, int NR>  // NR = compile-time bound on the rows of the small weight (register accumulators)
+template <int MODE, int NR, int W>  // NR = compile-time bound on the rows of the small weight (register accumulators)
 __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
-  __shared__ float lds[4 * 64];
+  __shared__ float lds[4 * W];
   __shared__ float sobs_acc[4][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 sln = ld4(a.s_ln + c4);
   float4 dsln = f4zero();
   float4 wacc[NR];
@@ -286,11 +297,11 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
     for (int f = 0; f < NR; ++f) {
       dsobs[f] = 0.f;
       sob[f] = f < a.F ? a.s_obs[f] : 0.f;
-      wob[f] = f < a.F ? ld4(a.W + f * 64 + c4) : f4zero();
+      wob[f] = f < a.F ? ld4(a.W + f * W + c4) : f4zero();
     }
   }
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < a.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  for (long base = (long)blockIdx.x * RowGeo<W>::RPB; base < a.R; base += (long)gridDim.x * RowGeo<W>::RPB) {
+    const long row = base + wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
     const bool ok = row < a.R;
     float4 z = f4zero(), d = f4zero();
     float of[MODE == 0 ? NR : 1];   // MODE 0: normalised observation features of this row (all loads issued together)
@@ -311,14 +322,14 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
           const float on = of[f] * sob[f];
           z.x += on * wob[f].x; z.y += on * wob[f].y; z.z += on * wob[f].z; z.w += on * wob[f].w;
         }
-      } else z = ld4(a.W + (long)a.idx[row * a.idx_stride] * 64 + c4);   // ... or gather it from the embedding table
+      } else z = ld4(a.W + (long)a.idx[row * a.idx_stride] * W + c4);   // ... or gather it from the embedding table
       d = ld4(a.d0 + row * a.ldd0 + c4);
       if (a.d1) d = f4add(d, ld4(a.d1 + row * a.ldd1 + c4));
       if (a.d2) d = f4add(d, ld4(a.d2 + row * a.ldd2 + c4));
     }
     float4 x0 = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
-    RmsFwd n = rms_fwd(x0, sln);
-    float4 dx0 = rms_bwd(d, n, sln, dsln);
+    RmsFwd n = rms_fwd<W>(x0, sln);
+    float4 dx0 = rms_bwd<W>(d, n, sln, dsln);
     float4 dz = make_float4(dx0.x * gelu_tanh_grad(z.x), dx0.y * gelu_tanh_grad(z.y), dx0.z * gelu_tanh_grad(z.z),
                             dx0.w * gelu_tanh_grad(z.w));
     if (!ok) dz = f4zero();
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
       for (int f = 0; f < NR; ++f) {
         const float on = of[f] * sob[f];
         wacc[f].x += on * dz.x; wacc[f].y += on * dz.y; wacc[f].z += on * dz.z; wacc[f].w += on * dz.w;
-        const float dof = sum16(f4sum(f4mul(dz, wob[f])));
+        const float dof = rowsum<W>(f4sum(f4mul(dz, wob[f])));
         dsobs[f] += dof * of[f];     // every lane of the row keeps the same partial; lane 0 of the row group publishes it
       }
     } else {
@@ -340,18 +351,18 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
       }
     }
   }
-  block_store_colsum(dsln, a.slab_sln + (long)blockIdx.x * 64, lds);
+  block_store_colsum<W>(dsln, a.slab_sln + (long)blockIdx.x * W, lds);
 #pragma unroll
   for (int f = 0; f < NR; ++f)
-    if (f < a.nrows) block_store_colsum(wacc[f], a.slab_w + ((long)blockIdx.x * 32 + f) * 64, lds);
+    if (f < a.nrows) block_store_colsum<W>(wacc[f], a.slab_w + ((long)blockIdx.x * 32 + f) * W, lds);
   if (MODE == 0) {
     if (threadIdx.x < 32) sobs_acc[0][threadIdx.x] = sobs_acc[1][threadIdx.x] = sobs_acc[2][threadIdx.x] = sobs_acc[3][threadIdx.x] = 0.f;
     __syncthreads();
-    // lanes 0,16,32,48 of each wave hold partial sums
+    // the first lane of every row of the wave holds the row's partial sum (lanes 0,16,32,48 for W = 64; 0,32 for W = 128)
 #pragma unroll
     for (int f = 0; f < NR; ++f) {
       float v = dsobs[f];
-      v += __shfl_xor(v, 16, 64);
+      if (W == 64) v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       if (lane == 0) sobs_acc[wave][f] = v;
     }
@@ -426,14 +437,14 @@ __global__ void k_small_operand(const float* __restrict__ obs, int ldo, int F, c
 // ------------------------------------------------------------------------------------------------
 // Retention epilogue: rn = GroupNorm(r) (per-row over the 64 head channels, fast variance),
 // u = swish(gpre) * rn                                                  (retention.py:289-294)
-__global__ __launch_bounds__(256) void k_retpost_fwd(const float* __restrict__ r, int ldr, const float* __restrict__ gp, int ldg,
+template <int W> __global__ __launch_bounds__(256) void k_retpost_fwd(const float* __restrict__ r, int ldr, const float* __restrict__ gp, int ldg,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ u, int ldu, long R, int hs, int gs) {
   // flax GroupNorm(num_groups = n_head) on (token*head, hs) rows: groups of gs = hs / n_head channels; scale/bias [hs]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 ga = ld4(gamma + (c4 % hs)), be = ld4(beta + (c4 % hs));
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  for (long base = (long)blockIdx.x * RowGeo<W>::RPB; base < R; base += (long)gridDim.x * RowGeo<W>::RPB) {
+    const long row = base + wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
     const bool ok = row < R;
     float4 x = f4zero(), g = f4zero();
     if (ok) { x = ld4(r + row * ldr + c4); g = ld4(gp + row * ldg + c4); }
@@ -447,17 +458,17 @@ __global__ __launch_bounds__(256) void k_retpost_fwd(const float* __restrict__ r
   }
 }
 
-__global__ __launch_bounds__(256) void k_retpost_bwd(const float* __restrict__ r, int ldr, const float* __restrict__ gp, int ldg,
+template <int W> __global__ __launch_bounds__(256) void k_retpost_bwd(const float* __restrict__ r, int ldr, const float* __restrict__ gp, int ldg,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ du, int lddu,
                                                      float* __restrict__ dr, int lddr, float* __restrict__ dgp, int lddg,
                                                      float* __restrict__ slab_gamma, float* __restrict__ slab_beta, long R, int hs, int gs) {
-  __shared__ float lds[4 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  __shared__ float lds[4 * W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 ga = ld4(gamma + (c4 % hs)), be = ld4(beta + (c4 % hs));
   float4 dga = f4zero(), dbe = f4zero();
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  for (long base = (long)blockIdx.x * RowGeo<W>::RPB; base < R; base += (long)gridDim.x * RowGeo<W>::RPB) {
+    const long row = base + wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
     const bool ok = row < R;
     float4 x = f4zero(), g = f4zero(), d = f4zero();
     if (ok) { x = ld4(r + row * ldr + c4); g = ld4(gp + row * ldg + c4); d = ld4(du + row * lddu + c4); }
@@ -479,8 +490,8 @@ __global__ __launch_bounds__(256) void k_retpost_bwd(const float* __restrict__ r
                             (gg.z - mg - xh.z * mgx) * rstd, (gg.w - mg - xh.w * mgx) * rstd);
     if (ok) { st4(dr + row * lddr + c4, dx); st4(dgp + row * lddg + c4, dg); }
   }
-  block_store_colsum(dga, slab_gamma + (long)blockIdx.x * 64, lds);
-  block_store_colsum(dbe, slab_beta + (long)blockIdx.x * 64, lds);
+  block_store_colsum<W>(dga, slab_gamma + (long)blockIdx.x * W, lds);
+  block_store_colsum<W>(dbe, slab_beta + (long)blockIdx.x * W, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,26 +505,26 @@ struct ResNormArgs {
   float* out; float* outpe; int ldout, ldoutpe;
   long R;
 };
-__global__ __launch_bounds__(256) void k_resnorm_fwd(ResNormArgs p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+template <int W> __global__ __launch_bounds__(256) void k_resnorm_fwd(ResNormArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 s1 = ld4(p.s1 + c4);
   const float4 s2 = p.s2 ? ld4(p.s2 + c4) : f4zero();
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < p.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  for (long base = (long)blockIdx.x * RowGeo<W>::RPB; base < p.R; base += (long)gridDim.x * RowGeo<W>::RPB) {
+    const long row = base + wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
     const bool ok = row < p.R;
     float4 x = f4zero();
     if (ok) {
       x = ld4(p.a + row * p.lda + c4);
       if (p.y) x = f4add(x, ld4(p.y + row * p.ldy + c4));
     }
-    float4 o = rms_fwd(x, s1).y;
-    if (p.s2) o = rms_fwd(o, s2).y;
+    float4 o = rms_fwd<W>(x, s1).y;
+    if (p.s2) o = rms_fwd<W>(o, s2).y;
     if (ok) {
       if (p.out) st4(p.out + row * p.ldout + c4, o);
       if (p.outpe) {
         int ps = p.pos[row * p.pos_stride];
         ps = ps < 0 ? 0 : (ps >= p.npos ? p.npos - 1 : ps);
-        st4(p.outpe + row * p.ldoutpe + c4, f4add(o, ld4(p.pe + (long)ps * 64 + c4)));
+        st4(p.outpe + row * p.ldoutpe + c4, f4add(o, ld4(p.pe + (long)ps * W + c4)));
       }
     }
   }
@@ -527,14 +538,14 @@ struct ResNormBwdArgs {
   float* slab_s1; float* slab_s2;   // [grid][64]
   long R;
 };
-__global__ __launch_bounds__(256) void k_resnorm_bwd(ResNormBwdArgs p) {
-  __shared__ float lds[4 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+template <int W> __global__ __launch_bounds__(256) void k_resnorm_bwd(ResNormBwdArgs p) {
+  __shared__ float lds[4 * W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 s1 = ld4(p.s1 + c4);
   const float4 s2 = p.s2 ? ld4(p.s2 + c4) : f4zero();
   float4 ds1 = f4zero(), ds2 = f4zero();
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < p.R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  for (long base = (long)blockIdx.x * RowGeo<W>::RPB; base < p.R; base += (long)gridDim.x * RowGeo<W>::RPB) {
+    const long row = base + wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
     const bool ok = row < p.R;
     float4 x = f4zero(), d = f4zero();
     if (ok) {
@@ -544,79 +555,79 @@ __global__ __launch_bounds__(256) void k_resnorm_bwd(ResNormBwdArgs p) {
       if (p.d1) d = f4add(d, ld4(p.d1 + row * p.ldd1 + c4));
       if (p.d2) d = f4add(d, ld4(p.d2 + row * p.ldd2 + c4));
     }
-    RmsFwd n1 = rms_fwd(x, s1);
+    RmsFwd n1 = rms_fwd<W>(x, s1);
     if (p.s2) {
-      RmsFwd n2 = rms_fwd(n1.y, s2);
-      d = rms_bwd(d, n2, s2, ds2);
+      RmsFwd n2 = rms_fwd<W>(n1.y, s2);
+      d = rms_bwd<W>(d, n2, s2, ds2);
     }
-    float4 dx = rms_bwd(d, n1, s1, ds1);
+    float4 dx = rms_bwd<W>(d, n1, s1, ds1);
     if (ok) st4(p.dsum + row * p.lddsum + c4, dx);
   }
-  block_store_colsum(ds1, p.slab_s1 + (long)blockIdx.x * 64, lds);
-  if (p.s2) block_store_colsum(ds2, p.slab_s2 + (long)blockIdx.x * 64, lds);
+  block_store_colsum<W>(ds1, p.slab_s1 + (long)blockIdx.x * W, lds);
+  if (p.s2) block_store_colsum<W>(ds2, p.slab_s2 + (long)blockIdx.x * W, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Head middle: h = gelu(hpre) ; hn = rmsnorm(h) * s ; mode 0 -> out hn ; mode 1 -> value = hn . w + b
 // (sable_network.py:102-109 value head, :277-284 logit head)
-__global__ __launch_bounds__(256) void k_headmid_fwd(const float* __restrict__ hpre, int ldh, const float* __restrict__ s,
+template <int W> __global__ __launch_bounds__(256) void k_headmid_fwd(const float* __restrict__ hpre, int ldh, const float* __restrict__ s,
                                                      float* __restrict__ hn, int ldhn,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float* __restrict__ value, int value_stride, long R) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 sc = ld4(s + c4);
   const float4 wv = w ? ld4(w + c4) : f4zero();
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  for (long base = (long)blockIdx.x * RowGeo<W>::RPB; base < R; base += (long)gridDim.x * RowGeo<W>::RPB) {
+    const long row = base + wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
     const bool ok = row < R;
     float4 z = ok ? ld4(hpre + row * ldh + c4) : f4zero();
     float4 h = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
-    float4 o = rms_fwd(h, sc).y;
+    float4 o = rms_fwd<W>(h, sc).y;
     if (hn && ok) st4(hn + row * ldhn + c4, o);
     if (w) {
-      float v = sum16(f4sum(f4mul(o, wv))) + b[0];
-      if (ok && (lane & 15) == 0) value[row * value_stride] = v;
+      float v = rowsum<W>(f4sum(f4mul(o, wv))) + b[0];
+      if (ok && (lane & (RowGeo<W>::LPR - 1)) == 0) value[row * value_stride] = v;
     }
   }
 }
 
 // Backward: incoming either dhn [R,64] (mode 0) or dvalue [R] (mode 1, dhn = dvalue * w).
 // Outputs dhpre; slabs ds[64]; mode 1 also dw[64] (slab) and db (slab_b[grid]).
-__global__ __launch_bounds__(256) void k_headmid_bwd(const float* __restrict__ hpre, int ldh, const float* __restrict__ s,
+template <int W> __global__ __launch_bounds__(256) void k_headmid_bwd(const float* __restrict__ hpre, int ldh, const float* __restrict__ s,
                                                      const float* __restrict__ dhn, int lddhn,
                                                      const float* __restrict__ w, const float* __restrict__ dvalue, int dvalue_stride,
                                                      float* __restrict__ dhpre, int lddh,
                                                      float* __restrict__ slab_s, float* __restrict__ slab_w, float* __restrict__ slab_b,
                                                      long R) {
-  __shared__ float lds[4 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & 15);
+  __shared__ float lds[4 * W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = 4 * (lane & (RowGeo<W>::LPR - 1));
   const float4 sc = ld4(s + c4);
   const float4 wv = w ? ld4(w + c4) : f4zero();
   float4 ds = f4zero(), dw = f4zero();
   float db = 0.f;
-  for (long base = (long)blockIdx.x * ROWS_PER_BLOCK; base < R; base += (long)gridDim.x * ROWS_PER_BLOCK) {
-    const long row = base + wave * 4 + (lane >> 4);
+  for (long base = (long)blockIdx.x * RowGeo<W>::RPB; base < R; base += (long)gridDim.x * RowGeo<W>::RPB) {
+    const long row = base + wave * RowGeo<W>::RPW + lane / RowGeo<W>::LPR;
     const bool ok = row < R;
     float4 z = ok ? ld4(hpre + row * ldh + c4) : f4zero();
     float4 h = make_float4(gelu_tanh(z.x), gelu_tanh(z.y), gelu_tanh(z.z), gelu_tanh(z.w));
-    RmsFwd n = rms_fwd(h, sc);
+    RmsFwd n = rms_fwd<W>(h, sc);
     float4 d;
     if (w) {
       const float dv = ok ? dvalue[row * dvalue_stride] : 0.f;
       d = f4scale(wv, dv);
       dw = f4add(dw, f4scale(n.y, dv));
-      if ((lane & 15) == 0) db += dv;
+      if ((lane & (RowGeo<W>::LPR - 1)) == 0) db += dv;
     } else {
       d = ok ? ld4(dhn + row * lddhn + c4) : f4zero();
     }
-    float4 dh = rms_bwd(d, n, sc, ds);
+    float4 dh = rms_bwd<W>(d, n, sc, ds);
     float4 dz = make_float4(dh.x * gelu_tanh_grad(z.x), dh.y * gelu_tanh_grad(z.y), dh.z * gelu_tanh_grad(z.z),
                             dh.w * gelu_tanh_grad(z.w));
     if (ok) st4(dhpre + row * lddh + c4, dz);
   }
-  block_store_colsum(ds, slab_s + (long)blockIdx.x * 64, lds);
+  block_store_colsum<W>(ds, slab_s + (long)blockIdx.x * W, lds);
   if (w) {
-    block_store_colsum(dw, slab_w + (long)blockIdx.x * 64, lds);
+    block_store_colsum<W>(dw, slab_w + (long)blockIdx.x * W, lds);
     float v = wave_sum(db);
     __syncthreads();
     if (lane == 0) lds[wave] = v;
@@ -645,6 +656,11 @@ __global__ void k_relu_bwd(const float* __restrict__ act, const float* __restric
 
 using namespace magpo;
 
+static int check_width(int E) {
+  if (E != 64 && E != 128) { set_error("row kernels: the row width (embed_dim of the device network) must be 64 or 128"); return MAGPO_EINVAL; }
+  return MAGPO_OK;
+}
+
 static inline int row_grid(long R) {
   long b = (R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -661,9 +677,14 @@ extern "C" int magpo_pe_table(float* pe, int npos, int E, hipStream_t st) {
 extern "C" int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const float* s_obs, const float* W,
                                const int* idx, int idx_stride, const float* s_ln, const float* pe, const int* pos,
                                int pos_stride, int npos, float* z, int ldz, float* xn, int ldxn, float* kin, int ldkin,
-                               long R, hipStream_t st) {
+                               long R, int E, hipStream_t st) {
   if (mode == 0 && F > 1024) { set_error("magpo_embed_fwd: F too large"); return MAGPO_EINVAL; }
+  if (int e = check_width(E)) return e;
   EmbedArgs a{obs, ldo, F, s_obs, W, idx, idx_stride, s_ln, pe, pos, pos_stride, npos, z, xn, kin, ldz, ldxn, ldkin, R};
+  if (E == 128) {
+    hipLaunchKernelGGL(k_embed_fwd<128>, dim3(row_grid(R)), dim3(256), 0, st, a, mode);
+    return check_launch("magpo_embed_fwd");
+  }
   if (mode == 1 || F <= 8) {
     const long nb = (R + EMB_ROWS - 1) / EMB_ROWS;
     static const unsigned cap0 = resident_grid(k_embed_fwd_tile<0>, 256, 1L << 30), cap1 = resident_grid(k_embed_fwd_tile<1>, 256, 1L << 30);
@@ -673,7 +694,7 @@ extern "C" int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const
     else hipLaunchKernelGGL(k_embed_fwd_tile<1>, grid, dim3(256), 0, st, a);
     return check_launch("magpo_embed_fwd");
   }
-  hipLaunchKernelGGL(k_embed_fwd, dim3(row_grid(R)), dim3(256), 0, st, a, mode);
+  hipLaunchKernelGGL(k_embed_fwd<64>, dim3(row_grid(R)), dim3(256), 0, st, a, mode);
   return check_launch("magpo_embed_fwd");
 }
 
@@ -682,12 +703,17 @@ extern "C" int magpo_embed_fwd(int mode, const float* obs, int ldo, int F, const
 extern "C" int magpo_embed_bwd(int mode, const float* z, int ldz, const float* d0, int ldd0, const float* d1, int ldd1,
                                const float* d2, int ldd2, const float* s_ln, float* dz, int lddz, float* slab_sln,
                                float* slab_w, int nrows, const float* obs, int ldo, int F, const float* s_obs, const float* W,
-                               float* slab_sobs, const int* idx, int idx_stride, long R, hipStream_t st) {
+                               float* slab_sobs, const int* idx, int idx_stride, long R, int E, hipStream_t st) {
   if (nrows < 1 || nrows > 32 || (mode == 0 && F != nrows)) { set_error("magpo_embed_bwd: 1 <= nrows <= 32 (F or K+1)"); return MAGPO_EINVAL; }
+  if (int e = check_width(E)) return e;
   EmbedBwdArgs a{z, ldz, d0, d1, d2, ldd0, ldd1, ldd2, s_ln, dz, lddz, slab_sln, slab_w, nrows, obs, ldo, F, s_obs, W, slab_sobs, idx, idx_stride, R};
-#define EB(M_, N_) hipLaunchKernelGGL((k_embed_bwd<M_, N_>), dim3(row_grid(R)), dim3(256), 0, st, a)
-  if (mode == 0) { if (nrows <= 8) EB(0, 8); else if (nrows <= 16) EB(0, 16); else EB(0, 32); }
-  else { if (nrows <= 8) EB(1, 8); else if (nrows <= 16) EB(1, 16); else if (nrows <= 24) EB(1, 24); else EB(1, 32); }
+#define EB(M_, N_)                                                                                              \
+  {                                                                                                             \
+    if (E == 64) hipLaunchKernelGGL((k_embed_bwd<M_, N_, 64>), dim3(row_grid(R)), dim3(256), 0, st, a);          \
+    else hipLaunchKernelGGL((k_embed_bwd<M_, N_, 128>), dim3(row_grid(R)), dim3(256), 0, st, a);                 \
+  }
+  if (mode == 0) { if (nrows <= 8) EB(0, 8) else if (nrows <= 16) EB(0, 16) else EB(0, 32) }
+  else { if (nrows <= 8) EB(1, 8) else if (nrows <= 16) EB(1, 16) else if (nrows <= 24) EB(1, 24) else EB(1, 32) }
 #undef EB
   return check_launch("magpo_embed_bwd");
 }
@@ -710,57 +736,65 @@ extern "C" int magpo_small_operand(int mode, const float* obs, int ldo, int F, c
   return check_launch("magpo_small_operand");
 }
 
-static int check_groups(int hs, int gs) {
-  if (hs < 4 || hs > 64 || (64 % hs) || gs < 4 || gs > hs || (gs & (gs - 1))) {
-    set_error("retpost: head width must divide 64 and the group size must be a power of two in [4, hs]");
+static int check_groups(int hs, int gs, int E) {
+  if (int e = check_width(E)) return e;
+  if (hs < 4 || hs > E || (E % hs) || gs < 4 || gs > hs || (gs & (gs - 1))) {
+    set_error("retpost: head width must divide the row width and the group size must be a power of two in [4, hs]");
     return MAGPO_EINVAL;
   }
   return MAGPO_OK;
 }
+#define ROW_LAUNCH(K_, ...)                                                                           \
+  {                                                                                                   \
+    if (E == 64) hipLaunchKernelGGL(K_<64>, dim3(row_grid(R)), dim3(256), 0, st, __VA_ARGS__);         \
+    else hipLaunchKernelGGL(K_<128>, dim3(row_grid(R)), dim3(256), 0, st, __VA_ARGS__);                \
+  }
 
 extern "C" int magpo_retpost_fwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
-                                 float* u, int ldu, long R, int hs, int gs, hipStream_t st) {
-  if (int e = check_groups(hs, gs)) return e;
-  hipLaunchKernelGGL(k_retpost_fwd, dim3(row_grid(R)), dim3(256), 0, st, r, ldr, gp, ldg, gamma, beta, u, ldu, R, hs, gs);
+                                 float* u, int ldu, long R, int hs, int gs, int E, hipStream_t st) {
+  if (int e = check_groups(hs, gs, E)) return e;
+  ROW_LAUNCH(k_retpost_fwd, r, ldr, gp, ldg, gamma, beta, u, ldu, R, hs, gs)
   return check_launch("magpo_retpost_fwd");
 }
 
 extern "C" int magpo_retpost_bwd(const float* r, int ldr, const float* gp, int ldg, const float* gamma, const float* beta,
                                  const float* du, int lddu, float* dr, int lddr, float* dgp, int lddg, float* slab_gamma,
-                                 float* slab_beta, long R, int hs, int gs, hipStream_t st) {
-  if (int e = check_groups(hs, gs)) return e;
-  hipLaunchKernelGGL(k_retpost_bwd, dim3(row_grid(R)), dim3(256), 0, st, r, ldr, gp, ldg, gamma, beta, du, lddu, dr, lddr,
-                     dgp, lddg, slab_gamma, slab_beta, R, hs, gs);
+                                 float* slab_beta, long R, int hs, int gs, int E, hipStream_t st) {
+  if (int e = check_groups(hs, gs, E)) return e;
+  ROW_LAUNCH(k_retpost_bwd, r, ldr, gp, ldg, gamma, beta, du, lddu, dr, lddr, dgp, lddg, slab_gamma, slab_beta, R, hs, gs)
   return check_launch("magpo_retpost_bwd");
 }
 
 extern "C" int magpo_resnorm_fwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
                                  const float* pe, const int* pos, int pos_stride, int npos, float* out, int ldout,
-                                 float* outpe, int ldoutpe, long R, hipStream_t st) {
+                                 float* outpe, int ldoutpe, long R, int E, hipStream_t st) {
+  if (int e = check_width(E)) return e;
   ResNormArgs p{a, y, lda, ldy, s1, s2, pe, pos, pos_stride, npos, out, outpe, ldout, ldoutpe, R};
-  hipLaunchKernelGGL(k_resnorm_fwd, dim3(row_grid(R)), dim3(256), 0, st, p);
+  ROW_LAUNCH(k_resnorm_fwd, p)
   return check_launch("magpo_resnorm_fwd");
 }
 
 extern "C" int magpo_resnorm_bwd(const float* a, int lda, const float* y, int ldy, const float* s1, const float* s2,
                                  const float* d0, int ldd0, const float* d1, int ldd1, const float* d2, int ldd2,
-                                 float* dsum, int lddsum, float* slab_s1, float* slab_s2, long R, hipStream_t st) {
+                                 float* dsum, int lddsum, float* slab_s1, float* slab_s2, long R, int E, hipStream_t st) {
+  if (int e = check_width(E)) return e;
   ResNormBwdArgs p{a, y, lda, ldy, s1, s2, d0, d1, d2, ldd0, ldd1, ldd2, dsum, lddsum, slab_s1, slab_s2, R};
-  hipLaunchKernelGGL(k_resnorm_bwd, dim3(row_grid(R)), dim3(256), 0, st, p);
+  ROW_LAUNCH(k_resnorm_bwd, p)
   return check_launch("magpo_resnorm_bwd");
 }
 
 extern "C" int magpo_headmid_fwd(const float* hpre, int ldh, const float* s, float* hn, int ldhn, const float* w,
-                                 const float* b, float* value, int value_stride, long R, hipStream_t st) {
-  hipLaunchKernelGGL(k_headmid_fwd, dim3(row_grid(R)), dim3(256), 0, st, hpre, ldh, s, hn, ldhn, w, b, value, value_stride, R);
+                                 const float* b, float* value, int value_stride, long R, int E, hipStream_t st) {
+  if (int e = check_width(E)) return e;
+  ROW_LAUNCH(k_headmid_fwd, hpre, ldh, s, hn, ldhn, w, b, value, value_stride, R)
   return check_launch("magpo_headmid_fwd");
 }
 
 extern "C" int magpo_headmid_bwd(const float* hpre, int ldh, const float* s, const float* dhn, int lddhn, const float* w,
                                  const float* dvalue, int dvalue_stride, float* dhpre, int lddh, float* slab_s,
-                                 float* slab_w, float* slab_b, long R, hipStream_t st) {
-  hipLaunchKernelGGL(k_headmid_bwd, dim3(row_grid(R)), dim3(256), 0, st, hpre, ldh, s, dhn, lddhn, w, dvalue, dvalue_stride,
-                     dhpre, lddh, slab_s, slab_w, slab_b, R);
+                                 float* slab_w, float* slab_b, long R, int E, hipStream_t st) {
+  if (int e = check_width(E)) return e;
+  ROW_LAUNCH(k_headmid_bwd, hpre, ldh, s, dhn, lddhn, w, dvalue, dvalue_stride, dhpre, lddh, slab_s, slab_w, slab_b, R)
   return check_launch("magpo_headmid_bwd");
 }
 

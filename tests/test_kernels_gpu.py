@@ -183,9 +183,9 @@ def test_small_linear(L, stream, F, R, relu):
     assert (Y[R] == -7.0).all()            # nothing written past the last row
 
 
-def _pe_table(L, st, npos=101):
-    pe = torch.empty(npos, 64, device=DEV)
-    L.call("magpo_pe_table", pe, npos, 64, st)
+def _pe_table(L, st, E=64, npos=101):
+    pe = torch.empty(npos, E, device=DEV)
+    L.call("magpo_pe_table", pe, npos, E, st)
     return pe
 
 
@@ -199,20 +199,22 @@ def _slabsum(slab):
     return slab.double().sum(0)
 
 
+@pytest.mark.parametrize("E", [64, 128])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_embed_fwd_bwd(L, stream, mode):
+def test_embed_fwd_bwd(L, stream, mode, E):
+    """E = row width (embed_dim of the device network): 16 or 32 lanes per row (csrc/rowops.hip)."""
     g = torch.Generator().manual_seed(3)
     R, F, K = 333, 5, 20
-    pe = _pe_table(L, stream)
+    pe = _pe_table(L, stream, E)
     pos = torch.randint(0, 101, (R,), generator=g, dtype=torch.int32)
-    s_ln = 1 + 0.1 * torch.randn(64, generator=g)
+    s_ln = 1 + 0.1 * torch.randn(E, generator=g)
     obs = torch.randint(0, 60, (R, F), generator=g).float()
     s_obs = 1 + 0.1 * torch.randn(F, generator=g)
-    W = torch.randn(F if mode == 0 else K + 1, 64, generator=g) * 0.5
+    W = torch.randn(F if mode == 0 else K + 1, E, generator=g) * 0.5
     idx = torch.randint(0, K + 1, (R,), generator=g, dtype=torch.int32)
-    z = torch.empty(R, 64, device=DEV); xn = torch.empty_like(z); kin = torch.empty_like(z)
+    z = torch.empty(R, E, device=DEV); xn = torch.empty_like(z); kin = torch.empty_like(z)
     L.call("magpo_embed_fwd", mode, dev(obs), F, F, dev(s_obs), dev(W), dev(idx), 1, dev(s_ln), pe, dev(pos), 1, 101,
-           z, 64, xn, 64, kin, 64, R, stream)
+           z, E, xn, E, kin, E, R, E, stream)
     # reference (fp64 autograd)
     Wd = W.double().requires_grad_(True); sl = s_ln.double().requires_grad_(True); so = s_obs.double().requires_grad_(True)
     if mode == 0:
@@ -222,18 +224,18 @@ def test_embed_fwd_bwd(L, stream, mode):
     xnr = onets.rmsnorm(onets.gelu(zr), sl)
     kinr = xnr + pe.cpu().double()[pos.long()]
     close(z, zr, what="z"); close(xn, xnr, what="xn"); close(kin, kinr, what="kin")
-    d0 = torch.randn(R, 64, generator=g); d1 = torch.randn(R, 64, generator=g)
+    d0 = torch.randn(R, E, generator=g); d1 = torch.randn(R, E, generator=g)
     (xnr * d0.double() + kinr * d1.double()).sum().backward()
     grid = L.call("magpo_row_grid", R)
-    dz = torch.empty(R, 64, device=DEV)
-    slab_sln = torch.zeros(grid, 64, device=DEV); slab_sobs = torch.zeros(grid, 32, device=DEV)
-    slab_w = torch.zeros(grid, 32 * 64, device=DEV)
+    dz = torch.empty(R, E, device=DEV)
+    slab_sln = torch.zeros(grid, E, device=DEV); slab_sobs = torch.zeros(grid, 32, device=DEV)
+    slab_w = torch.zeros(grid, 32 * E, device=DEV)
     rows = F if mode == 0 else K + 1
-    L.call("magpo_embed_bwd", mode, z, 64, dev(d0), 64, dev(d1), 64, None, 0, dev(s_ln), dz, 64, slab_sln, slab_w, rows,
-           dev(obs), F, F, dev(s_obs), dev(W), slab_sobs, dev(idx), 1, R, stream)
+    L.call("magpo_embed_bwd", mode, z, E, dev(d0), E, dev(d1), E, None, 0, dev(s_ln), dz, E, slab_sln, slab_w, rows,
+           dev(obs), F, F, dev(s_obs), dev(W), slab_sobs, dev(idx), 1, R, E, stream)
     close(_slabsum(slab_sln), sl.grad, 1e-4, 1e-5, "ds_ln")
-    dW = torch.zeros(rows, 64, device=DEV)
-    L.call("magpo_reduce_slabs", slab_w, dW, grid, rows * 64, 32 * 64, 1.0, 0, stream)
+    dW = torch.zeros(rows, E, device=DEV)
+    L.call("magpo_reduce_slabs", slab_w, dW, grid, rows * E, 32 * E, 1.0, 0, stream)
     close(dW, Wd.grad, 1e-4, 1e-5, "dW")
     if mode == 0:
         close(_slabsum(slab_sobs)[:F], so.grad, 1e-4, 1e-5, "ds_obs")
@@ -253,41 +255,42 @@ def test_embed_fwd_grid_stride(L, stream, mode):
     idx = torch.randint(0, K + 1, (R,), generator=g, dtype=torch.int32)
     xn = torch.empty(R + 1, 64, device=DEV).fill_(-7.0); kin = torch.empty(R + 1, 64, device=DEV).fill_(-7.0)
     L.call("magpo_embed_fwd", mode, dev(obs), F, F, dev(s_obs), dev(W), dev(idx), 1, dev(s_ln), pe, dev(pos), 1, 101,
-           None, 64, xn, 64, kin, 64, R, stream)
+           None, 64, xn, 64, kin, 64, R, 64, stream)
     zr = onets.rmsnorm(obs.double(), s_obs.double()) @ W.double() if mode == 0 else W.double()[idx.long()]
     xnr = onets.rmsnorm(onets.gelu(zr), s_ln.double())
     close(xn[:R], xnr, what="xn"); close(kin[:R], xnr + pe.cpu().double()[pos.long()], what="kin")
     assert (xn[R] == -7.0).all() and (kin[R] == -7.0).all()
 
 
-def test_retpost_resnorm_headmid(L, stream):
+@pytest.mark.parametrize("E,hs,nh", [(64, 64, 1), (128, 128, 1), (128, 64, 2), (128, 32, 4)])
+def test_retpost_resnorm_headmid(L, stream, E, hs, nh):
     g = torch.Generator().manual_seed(4)
     R = 300
-    pe = _pe_table(L, stream)
+    pe = _pe_table(L, stream, E)
     pos = torch.randint(0, 101, (R,), generator=g, dtype=torch.int32)
     grid = L.call("magpo_row_grid", R)
     rn = lambda *s: torch.randn(*s, generator=g)
     # retpost
-    r, gp, du = rn(R, 64), rn(R, 64), rn(R, 64)
-    ga, be = 1 + 0.1 * rn(64), 0.1 * rn(64)
-    u = torch.empty(R, 64, device=DEV)
-    L.call("magpo_retpost_fwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), u, 64, R, 64, 64, stream)
+    r, gp, du = rn(R, E), rn(R, E), rn(R, E)
+    ga, be = 1 + 0.1 * rn(hs), 0.1 * rn(hs)
+    u = torch.empty(R, E, device=DEV)
+    L.call("magpo_retpost_fwd", dev(r), E, dev(gp), E, dev(ga), dev(be), u, E, R, hs, hs // nh, E, stream)
     rd, gpd, gad, bed = (t.double().requires_grad_(True) for t in (r, gp, ga, be))
-    ur = onets.swish(gpd) * onets.groupnorm_rows(rd, gad, bed, 1)
+    ur = onets.swish(gpd) * onets.groupnorm_rows(rd.reshape(R * (E // hs), hs), gad, bed, nh).reshape(R, E)
     close(u, ur, what="u")
     (ur * du.double()).sum().backward()
-    dr = torch.empty(R, 64, device=DEV); dgp = torch.empty(R, 64, device=DEV)
-    sg = torch.zeros(grid, 64, device=DEV); sb = torch.zeros(grid, 64, device=DEV)
-    L.call("magpo_retpost_bwd", dev(r), 64, dev(gp), 64, dev(ga), dev(be), dev(du), 64, dr, 64, dgp, 64, sg, sb, R, 64, 64, stream)
+    dr = torch.empty(R, E, device=DEV); dgp = torch.empty(R, E, device=DEV)
+    sg = torch.zeros(grid, E, device=DEV); sb = torch.zeros(grid, E, device=DEV)
+    L.call("magpo_retpost_bwd", dev(r), E, dev(gp), E, dev(ga), dev(be), dev(du), E, dr, E, dgp, E, sg, sb, R, hs, hs // nh, E, stream)
     close(dr, rd.grad, 1e-4, 1e-5, "dr"); close(dgp, gpd.grad, 1e-4, 1e-5, "dgp")
-    close(_slabsum(sg), gad.grad, 1e-4, 1e-5, "dgamma"); close(_slabsum(sb), bed.grad, 1e-4, 1e-5, "dbeta")
+    close(_slabsum(sg).reshape(E // hs, hs).sum(0), gad.grad, 1e-4, 1e-5, "dgamma"); close(_slabsum(sb).reshape(E // hs, hs).sum(0), bed.grad, 1e-4, 1e-5, "dbeta")
     # resnorm (two norms + pe) and (one norm)
     for two in (True, False):
-        a, y, d0, d1 = rn(R, 64), rn(R, 64), rn(R, 64), rn(R, 64)
-        s1, s2 = 1 + 0.1 * rn(64), 1 + 0.1 * rn(64)
-        out = torch.empty(R, 64, device=DEV); outpe = torch.empty(R, 64, device=DEV)
-        L.call("magpo_resnorm_fwd", dev(a), 64, dev(y), 64, dev(s1), dev(s2) if two else None, pe, dev(pos), 1, 101,
-               out, 64, outpe, 64, R, stream)
+        a, y, d0, d1 = rn(R, E), rn(R, E), rn(R, E), rn(R, E)
+        s1, s2 = 1 + 0.1 * rn(E), 1 + 0.1 * rn(E)
+        out = torch.empty(R, E, device=DEV); outpe = torch.empty(R, E, device=DEV)
+        L.call("magpo_resnorm_fwd", dev(a), E, dev(y), E, dev(s1), dev(s2) if two else None, pe, dev(pos), 1, 101,
+               out, E, outpe, E, R, E, stream)
         ad, yd, s1d, s2d = (t.double().requires_grad_(True) for t in (a, y, s1, s2))
         o = onets.rmsnorm(ad + yd, s1d)
         if two:
@@ -295,33 +298,33 @@ def test_retpost_resnorm_headmid(L, stream):
         ope = o + pe.cpu().double()[pos.long()]
         close(out, o, what="resnorm out"); close(outpe, ope, what="resnorm outpe")
         (o * d0.double() + ope * d1.double()).sum().backward()
-        dsum = torch.empty(R, 64, device=DEV)
-        sl1 = torch.zeros(grid, 64, device=DEV); sl2 = torch.zeros(grid, 64, device=DEV)
-        L.call("magpo_resnorm_bwd", dev(a), 64, dev(y), 64, dev(s1), dev(s2) if two else None, dev(d0), 64, dev(d1), 64,
-               None, 0, dsum, 64, sl1, sl2, R, stream)
+        dsum = torch.empty(R, E, device=DEV)
+        sl1 = torch.zeros(grid, E, device=DEV); sl2 = torch.zeros(grid, E, device=DEV)
+        L.call("magpo_resnorm_bwd", dev(a), E, dev(y), E, dev(s1), dev(s2) if two else None, dev(d0), E, dev(d1), E,
+               None, 0, dsum, E, sl1, sl2, R, E, stream)
         close(dsum, ad.grad, 1e-4, 1e-5, "dsum"); close(_slabsum(sl1), s1d.grad, 1e-4, 1e-5, "ds1")
         if two:
             close(_slabsum(sl2), s2d.grad, 1e-4, 1e-5, "ds2")
     # headmid: logits mode and value mode
-    hpre, dhn = rn(R, 64), rn(R, 64)
-    s, w, b, dv = 1 + 0.1 * rn(64), rn(64), rn(1), rn(R)
-    hn = torch.empty(R, 64, device=DEV)
-    L.call("magpo_headmid_fwd", dev(hpre), 64, dev(s), hn, 64, None, None, None, 0, R, stream)
+    hpre, dhn = rn(R, E), rn(R, E)
+    s, w, b, dv = 1 + 0.1 * rn(E), rn(E), rn(1), rn(R)
+    hn = torch.empty(R, E, device=DEV)
+    L.call("magpo_headmid_fwd", dev(hpre), E, dev(s), hn, E, None, None, None, 0, R, E, stream)
     hd, sd, wd, bd = (t.double().requires_grad_(True) for t in (hpre, s, w, b))
     hnr = onets.rmsnorm(onets.gelu(hd), sd)
     close(hn, hnr, what="hn")
     (hnr * dhn.double()).sum().backward()
-    dh = torch.empty(R, 64, device=DEV); ss = torch.zeros(grid, 64, device=DEV)
-    L.call("magpo_headmid_bwd", dev(hpre), 64, dev(s), dev(dhn), 64, None, None, 0, dh, 64, ss, None, None, R, stream)
+    dh = torch.empty(R, E, device=DEV); ss = torch.zeros(grid, E, device=DEV)
+    L.call("magpo_headmid_bwd", dev(hpre), E, dev(s), dev(dhn), E, None, None, 0, dh, E, ss, None, None, R, E, stream)
     close(dh, hd.grad, 1e-4, 1e-5, "dhpre"); close(_slabsum(ss), sd.grad, 1e-4, 1e-5, "ds")
     hd.grad = None; sd.grad = None
     val = torch.empty(R, device=DEV)
-    L.call("magpo_headmid_fwd", dev(hpre), 64, dev(s), None, 0, dev(w), dev(b), val, 1, R, stream)
+    L.call("magpo_headmid_fwd", dev(hpre), E, dev(s), None, 0, dev(w), dev(b), val, 1, R, E, stream)
     vr = onets.rmsnorm(onets.gelu(hd), sd) @ wd + bd
     close(val, vr, what="value")
     (vr * dv.double()).sum().backward()
-    sw = torch.zeros(grid, 64, device=DEV); sbb = torch.zeros(grid, device=DEV)
-    L.call("magpo_headmid_bwd", dev(hpre), 64, dev(s), None, 0, dev(w), dev(dv), 1, dh, 64, ss, sw, sbb, R, stream)
+    sw = torch.zeros(grid, E, device=DEV); sbb = torch.zeros(grid, device=DEV)
+    L.call("magpo_headmid_bwd", dev(hpre), E, dev(s), None, 0, dev(w), dev(dv), 1, dh, E, ss, sw, sbb, R, E, stream)
     close(dh, hd.grad, 1e-4, 1e-5, "dhpre(v)"); close(_slabsum(ss), sd.grad, 1e-4, 1e-5, "ds(v)")
     close(_slabsum(sw), wd.grad, 1e-4, 1e-5, "dw"); close(sbb.double().sum(), bd.grad[0], 1e-4, 1e-5, "db")
 
