@@ -160,6 +160,8 @@ int magpo_add_pe(const float* x, long ldx, const float* pe, const int* pos, long
                  long ldout, long R, magpo_stream_t stream);
 int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, magpo_stream_t stream);
 int magpo_add_inplace(float* dst, const float* src, long n, magpo_stream_t stream);
+/* dst[r][0..W) += src[r][0..W) over R rows (row strides ldd / lds): the partial sums of the blockwise 128-wide retention head */
+int magpo_add_rows(float* dst, long ldd, const float* src, long lds, long R, int W, magpo_stream_t stream);
 
 /* ---- K2/K7 retention (retention.py:66-115 chunkwise + recurrent, :117-213 decay matrix / xi) ---- */
 /* qkv_rows (nullable): q | k | v are row tables (block-0 projections exist once per distinct input row, csrc/classtab.hip) and token row r

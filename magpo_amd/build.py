@@ -19,16 +19,19 @@ def _newer(src, dst):
     return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(BUILD, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, out: str = OUT, extra_flags=(), build_dir: str = BUILD) -> str:
+    """``out`` / ``extra_flags`` / ``build_dir``: experiment builds (debug timers, A/B macros) next to the product library, e.g.
+    ``python -m magpo_amd.build --out exp_libs/prof.so --flags=-DMAGPO_ACT_PROF`` (scripts pick them up through MAGPO_LIB)."""
+    os.makedirs(build_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.hpp"))
     objs, jobs = [], []
     for s in srcs:
-        o = os.path.join(BUILD, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(build_dir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, *extra_flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -39,10 +42,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(OUT):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
-    return OUT
+    if jobs or not os.path.exists(out):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--out", default=OUT)
+    ap.add_argument("--flags", default="")
+    a = ap.parse_args()
+    bd = BUILD if a.out == OUT else os.path.join(BUILD, "exp_" + os.path.basename(a.out).replace(".so", ""))
+    print(build(force=a.force, verbose=True, out=a.out, extra_flags=a.flags.split(), build_dir=bd))

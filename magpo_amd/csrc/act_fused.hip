@@ -85,12 +85,26 @@ __device__ unsigned long long g_act_prof[16];
 // ENC: ntok = A, all tokens staged from the global [q|k|v|g] rows `hist`; u rows -> global uout[(env*A + a)*64].
 // DEC: ntok = i + 1, tokens a < i staged from the global k|v history (hist rows, columns hcol..hcol+127), token i read
 //      from the wave's TQ tile; u -> LDS tile U[env].
-template <int MODE, int NA, int NBUF, int NH>
+// The first state of a pass can be PRIMED: its loads are issued by the caller before the dense phase that precedes the pass
+// (prime_state), so that the memory system also has work while the wave runs MFMA / VALU code (one wave per SIMD: nothing else hides it).
+__device__ __forceinline__ void prime_state(float4 (&dst)[16], const float* __restrict__ Se, int lane) {
+  const int c4 = 4 * (lane & 15), rg = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[r] = ld4nt(Se + (16 * rg + r) * 64 + c4);
+}
+__device__ __forceinline__ void prime_state_perm(float4 (&dst)[16], const float* __restrict__ Se, int lane) {   // row order of self_prepass_cand
+  const int c4 = 4 * (lane & 15), kq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dst[j] = ld4nt(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4);
+}
+
+template <int MODE, int NA, int NBUF, int NH, bool PRIMED = false>
 __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* __restrict__ S0 /* head 0 of this block */, long NS,
                                          const ActArgs& a, int env0, int nvalid, int i, const float* __restrict__ hist, long ldh,
                                          int hcol, float* __restrict__ uout, long ldu, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, int write_state, unsigned long long dmask,
-                                         const float* __restrict__ qsrc = nullptr, long ldq = 0, int apply_pending = 0) {
+                                         const float* __restrict__ qsrc = nullptr, long ldq = 0, int apply_pending = 0,
+                                         const float4* __restrict__ primed = nullptr) {
   const int lane = threadIdx.x, c4 = 4 * (lane & 15), rg = lane >> 4;
   const int A = a.A, nh = NH ? NH : a.nh, hs = NH ? AE / NH : a.hs, gs = NH ? AE / (NH * NH) : a.gs;   // NH = 0: run-time head count
   // MODE 0 (encoder): all A tokens staged as [q|k|v|g] rows, state update + write, gated output -> global uout
@@ -118,12 +132,14 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
   float4 buf[NBUF][16], hreg[NBUF][NA];
   RT_DECL();
   const int npairs = nvalid * nh;
-  auto prefetch = [&](float4 (&dst)[16], float4 (&tok)[NA], int pair) {
+  auto prefetch = [&](float4 (&dst)[16], float4 (&tok)[NA], int pair, bool with_state = true) {
     pair = min(pair, npairs - 1);
     const int e = pair / nh, h = pair - e * nh;
     const float* Se = S0 + (long)h * NS + (long)(env0 + e) * 4096;
+    if (with_state) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[r] = ld4nt(Se + (16 * rg + r) * 64 + c4);
+      for (int r = 0; r < 16; ++r) dst[r] = ld4nt(Se + (16 * rg + r) * 64 + c4);
+    }
     const long row0 = (long)(env0 + e) * A;
 #pragma unroll
     for (int t = 0; t < NA; ++t) {
@@ -139,7 +155,15 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
     }
   };
 #pragma unroll
-  for (int j = 0; j < NBUF - 1; ++j) prefetch(buf[j], hreg[j], j);
+  for (int j = 0; j < NBUF - 1; ++j) {
+    if (PRIMED && j == 0) {   // pair 0's state was requested by the caller (prime_state); only its token rows are loaded here
+#pragma unroll
+      for (int r = 0; r < 16; ++r) buf[0][r] = primed[r];
+      prefetch(buf[0], hreg[0], 0, false);
+    } else {
+      prefetch(buf[j], hreg[j], j);
+    }
+  }
   for (int base = 0; base < npairs; base += NBUF) {
 #pragma unroll
     for (int j = 0; j < NBUF; ++j) {
@@ -255,22 +279,27 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
 // Output tile (mt, nt): lane holds candidates 16 mt + 4 kq + i (i < 4) of column 4 n + nt, i.e. one float4 of row c per lane.
 template <int NA, int MT>
 __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* __restrict__ S0, const ActArgs& a, int env0, int nvalid,
-                                                  const float* __restrict__ pend, const Row (&xq)[MT], unsigned long long dmask) {
+                                                  const float* __restrict__ pend, const Row (&xq)[MT], unsigned long long dmask,
+                                                  const float4* __restrict__ primed) {
   const int lane = threadIdx.x, n16 = lane & 15, c4 = 4 * n16, kq = lane >> 4, A = a.A;
   const float kappa = a.kappa[0];
   const int pe_row = a.K + 1, pe_mt = pe_row >> 4, pe_m = pe_row & 15;
   float4 buf[2][16], hreg[2][NA];
-  auto prefetch = [&](float4 (&dst)[16], float4 (&tok)[NA], int e) {
+  auto prefetch = [&](float4 (&dst)[16], float4 (&tok)[NA], int e, bool with_state = true) {
     e = min(e, nvalid - 1);
     const float* Se = S0 + (long)(env0 + e) * 4096;
+    if (with_state) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dst[j] = ld4nt(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4);
+      for (int j = 0; j < 16; ++j) dst[j] = ld4nt(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4);
+    }
     const long row0 = (long)(env0 + e) * A;
 #pragma unroll
     for (int t = 0; t < NA; ++t)
       if (t < A && lane < 32) tok[t] = ld4g(pend + (row0 + t) * 256 + 64 + 4 * lane);   // k | v of the previous launch (qkvg1 rows)
   };
-  prefetch(buf[0], hreg[0], 0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) buf[0][j] = primed[j];   // env 0's state: requested by the caller (prime_state_perm)
+  prefetch(buf[0], hreg[0], 0, false);
   for (int base = 0; base < nvalid; base += 2) {
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
@@ -462,6 +491,10 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
   // envs whose episode ended on the previous step (bit e): one flag load per kernel, kept out of the retention pipeline
   const unsigned long long dmask = a.done ? __ballot(valid && kq == 0 && a.done[ge] != 0) : 0ull;
 
+  // first state of the block-0 encoder pass: in flight while the token rows are computed
+  float4 pS[16];
+  prime_state(pS, a.S_enc + (long)env0 * 4096, lane);
+
   // ---------------- encoder over the A tokens of the step (act_encoder_fn, encode.py:58-84)
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
@@ -495,7 +528,10 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
     }
     wsync();
     PROF(0);
-    ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
+    if (b == 0) ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH, true>(TQ, HK, U, a.S_enc, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask, nullptr, 0, 0, pS);
+    else ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
+    // the first cross-retention state of the decoder pre-pass rides along with the encoder's post-retention dense phase
+    if (b == nb - 1 && !a.value_only) prime_state(pS, a.S_d2 + (long)env0 * 4096, lane);
     wsync();
     PROF(1);
     for (int t = 0; t < A; ++t) {
@@ -546,8 +582,11 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
   // zeroing), written back, and gives from registers what the decoder needs from kappa S
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
-    ret_pass<4, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
-                             B.q2, AE, a.pending);
+    float4 pS1[16];   // block 0, one head: the first self-retention state of the candidate pass
+    if (b == 0) ret_pass<4, NA, NBF, NH, true>(TQ, HK, U, a.S_d2, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
+                                               B.q2, AE, a.pending, pS);
+    else ret_pass<4, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
+                                  B.q2, AE, a.pending);
     if (b == 0 && cand) {
       // candidate query rows q_c = x_c W_q (tile row = candidate) and the positional query rows pe W_q of this wave's envs
       const Row qpe = dense64(pe, B.qkvg1_t, nullptr, m, kq);
@@ -556,12 +595,13 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
       const int ntile = (a.K + 2 + 15) >> 4;
 #define CAND_ROWS(MT_)                                                                                                        \
       {                                                                                                                        \
+        prime_state_perm(pS1, a.S_d1 + (long)env0 * 4096, lane);                                                               \
         Row xq[MT_];                                                                                                           \
         _Pragma("unroll") for (int mt = 0; mt < MT_; ++mt) {                                                                   \
           const int c = min(16 * mt + env, a.K);                                                                               \
           xq[mt] = dense64(row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq), B.qkvg1_t, nullptr, m, kq); \
         }                                                                                                                      \
-        self_prepass_cand<NA, MT_>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask);                                      \
+        self_prepass_cand<NA, MT_>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask, pS1);                                 \
       }
       if (ntile == 1) CAND_ROWS(1) else if (ntile == 2) CAND_ROWS(2) else CAND_ROWS(3)
 #undef CAND_ROWS
@@ -776,7 +816,7 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   // waves fit the chip's 1024 SIMDs (a rollout step is a latency chain per wave), full MFMA tiles and less weight traffic once they do not.
   // All variants run at one wave per SIMD (512 registers, no scratch).
   int epw;
-  if (a.A <= 4) epw = a.N > 4096 ? 16 : 4;
+  if (a.A <= 4) epw = a.N > 4096 ? 16 : (a.N >= 4096 ? 8 : 4);   // (4096 envs, round 3 kernel: 290 / 270 / 328 us for 4 / 8 / 16)
   else epw = a.N >= 16384 ? 16 : (a.N >= 4096 ? 8 : 4);
   if (dims_host[11]) {   // envs per wave forced by the caller (A/B measurements); 0 = by size as above
     if (dims_host[11] != 4 && dims_host[11] != 8 && dims_host[11] != 16) { set_error("magpo_sable_act: envs per wave must be 0, 4, 8 or 16"); return MAGPO_EINVAL; }

@@ -644,6 +644,14 @@ __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__
   float4 a = ld4(dst + i), b = ld4(src + i);
   st4(dst + i, f4add(a, b));
 }
+// dst[r][0..W) += src[r][0..W) for R rows with row strides ldd / lds (W, strides multiples of 4)
+__global__ void k_add_rows(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds, long R, int W4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * W4) return;
+  const long r = i / W4;
+  const int c = 4 * (int)(i - r * W4);
+  st4(dst + r * ldd + c, f4add(ld4(dst + r * ldd + c), ld4(src + r * lds + c)));
+}
 // y = relu'(act) * dy  (act is the post-relu activation), in place allowed
 __global__ void k_relu_bwd(const float* __restrict__ act, const float* __restrict__ dy, float* __restrict__ dx, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -802,6 +810,14 @@ extern "C" int magpo_add_inplace(float* dst, const float* src, long n, hipStream
   if (n & 3) { set_error("magpo_add_inplace: n must be a multiple of 4"); return MAGPO_EINVAL; }
   hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dst, src, n);
   return check_launch("magpo_add_inplace");
+}
+
+extern "C" int magpo_add_rows(float* dst, long ldd, const float* src, long lds, long R, int W, hipStream_t st) {
+  if ((W & 3) || (ldd & 3) || (lds & 3) || W < 4) { set_error("magpo_add_rows: W and the row strides must be multiples of 4"); return MAGPO_EINVAL; }
+  if (R <= 0) return MAGPO_OK;
+  const long n = R * (W / 4);
+  hipLaunchKernelGGL(k_add_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, ldd, src, lds, R, W / 4);
+  return check_launch("magpo_add_rows");
 }
 
 extern "C" int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, hipStream_t st) {

@@ -232,7 +232,7 @@ class EnvGroup:
     reference's (device, update-batch) replica (rec_magpo.py:519, :648-653); all groups of a process share
     the parameters and the training workspaces."""
 
-    def __init__(self, env_cfg, N: int, T: int, device, n_block: int = 1, n_head: int = 1):
+    def __init__(self, env_cfg, N: int, T: int, device, n_block: int = 1, n_tile: int = 1):
         A, F = env_cfg.num_agents, obs_row_stride(env_cfg.obs_dim)
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
@@ -243,9 +243,10 @@ class EnvGroup:
         # action masks (Observation.action_mask) only for envs that have illegal actions; None = every action legal
         self.traj["mask"] = u8(T + 1, N, A, env_cfg.num_actions) if env_cfg.has_mask else None
         self.metrics = dict(episode_return=f32(T, N), episode_length=i32(T, N), is_terminal_step=u8(T, N))
-        # (encoder, decoder self, decoder cross) retention states; head states are padded to 64 x 64 on the device
-        self.sable_hs = tuple(f32(n_block, n_head, N, 64, 64) for _ in range(3))
-        self.prev_sable_hs = tuple(f32(n_block, n_head, N, 64, 64) for _ in range(3))
+        # (encoder, decoder self, decoder cross) retention states as 64 x 64 tiles: one (zero-padded) tile per head, or the four blocks of
+        # the one 128-wide head (SableGuider.ntile)
+        self.sable_hs = tuple(f32(n_block, n_tile, N, 64, 64) for _ in range(3))
+        self.prev_sable_hs = tuple(f32(n_block, n_tile, N, 64, 64) for _ in range(3))
         self.policy_h = [f32(N * A, 128), f32(N * A, 128)]
         self.policy_h0 = f32(N * A, 128)
         self.last_val = f32(N, A)
@@ -285,11 +286,12 @@ class MagpoLearner:
         self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
                               grads=self.grad_all[gn:gn + an], tuning=self.tuning)
         self.loss_out = self.grad_all[gn + an:gn + an + 9]
-        self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb, self.nh) for _ in range(num_groups)]
+        self.nt = self.guider.ntile
+        self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb, self.nt) for _ in range(num_groups)]
         # rollout-start states of all groups in ONE tensor each (group g = envs g*N .. g*N + N - 1), so that the minibatches of all
         # local groups train as one batch of sequences (update(): the groups differ only in their advantage statistics)
         U_, N_ = num_groups, num_envs
-        self._prev_hs = tuple(torch.zeros(self.nb, self.nh, U_ * N_, 64, 64, device=device) for _ in range(3))
+        self._prev_hs = tuple(torch.zeros(self.nb, self.nt, U_ * N_, 64, 64, device=device) for _ in range(3))
         self._policy_h0 = torch.zeros(U_ * N_ * A, 128, device=device)
         for gi, g in enumerate(self.groups):
             g.prev_sable_hs = tuple(t[:, :, gi * N_:(gi + 1) * N_] for t in self._prev_hs)
@@ -307,7 +309,8 @@ class MagpoLearner:
         # First-layer class tables (csrc/classtab.hip): a wrapped CoordSum token is one of A*maxval*npos distinct inputs, so the
         # layers in front of the GRU / of the first retention run on the distinct rows only.  MAGPO_CLASS_TABLES=0 = dense path.
         import os
-        self.class_tables = env_cfg.class_tables and os.environ.get("MAGPO_CLASS_TABLES", "1") != "0"
+        # (the tables are read in place by the 64-wide fused kernels: a 128-wide net takes the dense first layers)
+        self.class_tables = env_cfg.class_tables and os.environ.get("MAGPO_CLASS_TABLES", "1") != "0" and int(embed_dim) <= 64
         self._cls = None
         # the actor's forward / backward run on a second HIP stream next to the guider's (independent until the loss)
         self.overlap_actor = False  # opt-in (bench.py --overlap): ~3 %, but per-kernel timings then include contention
@@ -446,7 +449,7 @@ class MagpoLearner:
 
         def zero_done(done):
             for k in range(self.nb):
-                for h in range(self.nh):
+                for h in range(self.nt):
                     L.call("magpo_zero_states_where_done", g.sable_hs[0][k][h], g.sable_hs[1][k][h], g.sable_hs[2][k][h], done, N, st)
 
         for t in range(T):

@@ -43,7 +43,7 @@ class FlatParams:
 
 
 def guider_layout(E: int, F: int, K: int, nb: int = 1, nh: int = 1) -> "OrderedDict[str, Tuple[int, ...]]":
-    assert E in (16, 32, 64) and E % nh == 0, "embed_dim must be 16, 32 or 64 (narrower nets run embedded in the 64-wide kernels)"
+    assert E in (16, 32, 64, 128) and E % nh == 0, "embed_dim must be 16, 32, 64 or 128 (nets narrower than 64 run embedded in the 64-wide kernels)"
     hs = E // nh  # GroupNorm scale / bias are per head channel (retention.py:247)
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     s["enc.ln.scale"] = (E,)

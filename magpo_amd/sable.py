@@ -4,9 +4,16 @@ Host-side composition of the C-ABI kernels (include/magpo.h); mirrors ``SableNet
 (mava/networks/sable_network.py:443-482) and ``SableNetwork.__call__`` (:412-441).  The backward pass
 is hand-derived (no autograd): it walks the forward graph in reverse, one kernel per node.
 
-Supported configuration (asserted): embed_dim 64, n_head 1, n_block 1, discrete actions, one chunk
+Supported configuration (asserted): embed_dim 16 / 32 / 64 / 128, n_head 1 / 2 / 4, any n_block, discrete actions, one chunk
 per rollout, SwiGLU weights at their zero init (then the FFN branch and its gradients are exactly 0,
 SURVEY B5 -- verified on the host at construction / load time).
+
+Widths.  ``EL`` = the reference's embed_dim; ``E`` = width of the device network: 64 (EL <= 64: narrower nets run embedded, see
+params.WidthEmbedding) or 128.  The fused kernels (csrc/seg_fused.hip, csrc/act_fused.hip, first-layer class tables read in place)
+exist for E = 64; an E = 128 network is composed kernel by kernel: dense layers on k_linear_lds<128 | 256 | 384,*>, row kernels at 32
+lanes per row (csrc/rowops.hip), retention on the 64-wide tile kernels -- n_head 2 / 4 have 64- / 32-wide heads (real tiles); the
+one 128-wide head of n_head = 1 is evaluated blockwise, r[:, J] = sum_I ret(q[:, I], k[:, I], v[:, J]) over the 64-column halves
+I, J with the 128 x 128 state kept as four 64 x 64 tiles S[I][J] (exact: retention is bilinear in (q.k) and v).
 """
 from __future__ import annotations
 
@@ -20,7 +27,9 @@ from ._lib import lib
 from .params import FlatParams, WidthEmbedding, guider_layout, guider_named_views, init_guider
 from .tuning import Tuning
 
-E = 64
+E = 64      # width of the fused (64-wide) kernel family, of a retention state tile and of a logit row
+TILE = 64   # retention states live in 64 x 64 tiles on the device
+LW = 64     # logit rows (K <= 31 valid columns)
 
 
 def decay_kappas(n_head: int, scaling: float):
@@ -48,13 +57,17 @@ class SableGuider:
                  wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None,
                  tuning: Optional[Tuning] = None):
         self.tuning = tuning if tuning is not None else Tuning.from_env()   # per-call kernel knobs (tuning.py); the library keeps none
-        if embed_dim not in (16, 32, 64) or n_head not in (1, 2, 4) or n_block < 1 or embed_dim % n_head or 64 // n_head // n_head < 4:
-            raise NotImplementedError("gfx950 Sable kernels: embed_dim in {16, 32, 64} (narrower nets run embedded in the 64-wide "
+        if embed_dim not in (16, 32, 64, 128) or n_head not in (1, 2, 4) or n_block < 1 or embed_dim % n_head or 64 // n_head // n_head < 4:
+            raise NotImplementedError("gfx950 Sable kernels: embed_dim in {16, 32, 64, 128} (nets narrower than 64 run embedded in the 64-wide "
                                       "kernels, params.WidthEmbedding) and n_head in {1, 2, 4} (SURVEY 8f rank 3)")
         self.nb, self.nh = int(n_block), int(n_head)
         self.EL = int(embed_dim)        # logical embed_dim (what the optimiser, checkpoints and the reference see)
-        self.hs = E // self.nh          # head width of the 64-wide device network
+        self.E = E = 128 if self.EL == 128 else 64   # width of the device network
+        self.hs = E // self.nh          # head width of the device network
         self.gs = self.hs // self.nh    # flax GroupNorm(num_groups=n_head) on (token*head, hs) rows: hs / n_head channels per group
+        # retention state tiles [n_block, ntile, N, 64, 64]: one per head, or the four 64 x 64 blocks (I, J) of the one 128-wide head
+        self.blockwise = self.hs > TILE
+        self.ntile = 4 if self.blockwise else self.nh
         if obs_dim > 128 or action_dim > 31:
             raise NotImplementedError("obs_dim <= 128 and action_dim <= 31 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
@@ -97,7 +110,7 @@ class SableGuider:
         self.b = _Bufs(device)
         self._act_tabs: Dict[tuple, tuple] = {}
         self._seg_tabs: Dict[tuple, tuple] = {}
-        self.fused_segments = self.nh == 1   # token-local parts between retention ops as single launches (csrc/seg_fused.hip)
+        self.fused_segments = self.nh == 1 and E == 64   # token-local parts between retention ops as single launches (csrc/seg_fused.hip)
         # weight-gradient GEMMs run on a side stream: they are off the critical path of the backward chain
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.overlap_wgrad = False  # opt-in (bench.py --overlap): ~0.5 %, but per-kernel timings then include contention
@@ -134,7 +147,7 @@ class SableGuider:
         """Rebuild the device parameters (embed_dim < 64) and the transposed (forward-GEMM) weight copies after a parameter update."""
         if self.emb is not None:
             self.emb.expand(self.P.flat, self.PD.flat)
-        v = self.v
+        v, E = self.v, self.E
         if self.wide:   # W_obs [F, 64] as [64][128] (forward) and [128][64] (dOn = dz W_obs^T), zero beyond F
             for name, shape in (("wobs", (E, 128)), ("wobs_nat_pad", (128, E))):
                 if name not in self.wt:
@@ -149,8 +162,17 @@ class SableGuider:
                               (f"wo1{b}", d + "retn1.w_o"), (f"q2{b}", d + "retn2.w_q"), (f"kvg2{b}", d + "retn2.w_kvg"),
                               (f"wo2{b}", d + "retn2.w_o")]:
                 self._tp(key, v[name])
-        h1t = self._tp("h1", v["dec.head.dense1.kernel"], 64)        # [64 (K padded)][64]
-        self._tp("h1_nat_pad", h1t, E)                                # [64][64]: natural W padded to 64 columns
+        h1t = self._tp("h1", v["dec.head.dense1.kernel"], LW)        # [64 (K padded)][E]
+        self._tp("h1_nat_pad", h1t, E)                                # [E][64]: natural W padded to 64 columns
+        if E > 64:   # dX = dY W^T with KIN = 4 E = 512 runs as two K-halves (k_linear_lds<256,*>): contiguous copies of the row halves
+            for bk in range(self.nb):
+                for name in (f"enc.block{bk}.retn.w_qkvg", f"dec.block{bk}.retn1.w_qkvg"):
+                    W = v[name]
+                    for half in (0, 1):
+                        key = f"{name}.nat{half}"
+                        if key not in self.wt:
+                            self.wt[key] = torch.empty(E, 2 * E, device=self.dev)
+                        self.wt[key].copy_(W[:, half * 2 * E:(half + 1) * 2 * E])
 
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self.tuning.linear_variant, self._st())
@@ -171,8 +193,19 @@ class SableGuider:
         with torch.cuda.stream(side):
             self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self.tuning.wgrad_variant, self._st())
 
-    def reduce(self, slab, out, P=64, stride=None, accumulate=False):
-        self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P, stride or slab.shape[1], 1.0, 1 if accumulate else 0, self._st())
+    def reduce(self, slab, out, P=None, stride=None, accumulate=False):
+        self.L.call("magpo_reduce_slabs", slab, out, slab.shape[0], P or slab.shape[1], stride or slab.shape[1], 1.0, 1 if accumulate else 0, self._st())
+
+    def lin_dx_qkvg(self, dY, name, dX, R):
+        """dX [R, E] = dY [R, 4E] W^T for a fused q|k|v|g projection ``name`` ([E, 4E]): one launch up to KIN = 256, two K-halves + add for E = 128."""
+        E = self.E
+        if E == 64:
+            self.lin(dY, 4 * E, self.v[name], None, dX, E, R, 4 * E, E)
+            return
+        tmp = self.b.get("g_dx_half", (R, E))
+        self.lin(dY, 4 * E, self.wt[name + ".nat0"], None, dX, E, R, 2 * E, E)
+        self.lin(dY[:, 2 * E:], 4 * E, self.wt[name + ".nat1"], None, tmp, E, R, 2 * E, E)
+        self.add_(dX, tmp)
 
     def add_(self, dst, src):
         self.L.call("magpo_add_inplace", dst, src, dst.numel(), self._st())
@@ -180,47 +213,116 @@ class SableGuider:
     # ------------------------------------------------------------------ acting (recurrent form)
     def _pro(self, pro, a, lda, y, ldy_in, s1, s2, use_pe, pos, pos_stride, W, idx, idx_stride, out, ldout, outpe, ldoutpe,
              Wt, bias, Y, ldy, R, NOUT):
-        """Dense layer with the preceding row-wise op fused into its prologue (csrc/linear.hip: k_linear_pro)."""
-        self.L.call("magpo_linear_pro", pro, a, lda, y, ldy_in, s1, s2, self.pe, pos, pos_stride, self.npos, 1 if use_pe else 0,
-                    W, idx, idx_stride, self.v["enc.obs.norm.scale"], self.F, out, ldout, outpe, ldoutpe, Wt, bias, Y, ldy, R, NOUT,
-                    self._st())
+        """Dense layer behind a row-wise op: pro 1 embed-action, 2 embed-observation, 3 residual + norm(s), 4 gelu + norm; the dense input is
+        the row (+ pe when ``use_pe``); ``out`` / ``outpe`` (optional) receive the row / the row + pe.  E = 64: one launch with the row op in
+        the prologue of the GEMM (csrc/linear.hip: k_linear_pro); E = 128: row kernel + k_linear_lds<128,*>."""
+        E = self.E
+        if E == 64:
+            self.L.call("magpo_linear_pro", pro, a, lda, y, ldy_in, s1, s2, self.pe, pos, pos_stride, self.npos, 1 if use_pe else 0,
+                        W, idx, idx_stride, self.v["enc.obs.norm.scale"], self.F, out, ldout, outpe, ldoutpe, Wt, bias, Y, ldy, R, NOUT,
+                        self._st())
+            return
+        L, st, b = self.L, self._st(), self.b
+        if out is None:
+            out, ldout = b.get("p_row", (R, E)), E
+        need_pe = use_pe or outpe is not None or pro in (1, 2)
+        if need_pe and outpe is None:
+            outpe, ldoutpe = b.get("p_rowpe", (R, E)), E
+        if pro == 1:
+            L.call("magpo_embed_fwd", 1, None, 0, 0, None, W, idx, idx_stride, s1, self.pe, pos, pos_stride, self.npos, None, 0, out, ldout,
+                   outpe, ldoutpe, R, E, st)
+        elif pro == 2:
+            L.call("magpo_embed_fwd", 0, a, lda, self.F, self.v["enc.obs.norm.scale"], W, None, 0, s1, self.pe, pos, pos_stride, self.npos, None, 0,
+                   out, ldout, outpe, ldoutpe, R, E, st)
+        elif pro == 3:
+            L.call("magpo_resnorm_fwd", a, lda, y, ldy_in, s1, s2, self.pe, pos, pos_stride, self.npos, out, ldout, outpe if need_pe else None,
+                   ldoutpe if need_pe else 0, R, E, st)
+        else:
+            L.call("magpo_headmid_fwd", a, lda, s1, out, ldout, None, None, None, 0, R, E, st)
+        if use_pe:
+            self.lin(outpe, ldoutpe, Wt, bias, Y, ldy, R, E, NOUT)
+        else:
+            self.lin(out, ldout, Wt, bias, Y, ldy, R, E, NOUT)
 
-    # ------------------------------------------------------------------ per-head retention helpers
+    # ------------------------------------------------------------------ retention helpers (per state tile)
+    def _tiles(self):
+        """State tiles of one retention layer as (tile, q / k column offset, v / r column offset, width, kappa): one per head, or -- one
+        128-wide head -- the four 64 x 64 blocks S[I][J] (q, k columns of half I meet v, r columns of half J; outputs add over I)."""
+        if self.blockwise:
+            return [(2 * i + j, TILE * i, TILE * j, TILE, self.kappas[0]) for i in (0, 1) for j in (0, 1)]
+        return [(h, h * self.hs, h * self.hs, self.hs, self.kappas[h]) for h in range(self.nh)]
+
+    def add_rows(self, dst, ldd, src, lds, R, W):
+        self.L.call("magpo_add_rows", dst, ldd, src, lds, R, W, self._st())
+
     def _ret_rec(self, S, q, ldq, k, ldk, v, ldv, env_rows, u, ldu, N, ntok, ret_from, write, gp, ldg, gamma, beta):
-        """Recurrent retention + fused GroupNorm/gate for every head; S [n_head, N, 64, 64] (padded head states)."""
-        hs = self.hs
-        for h in range(self.nh):
-            o = h * hs
-            self.L.call("magpo_retention_recurrent", S[h], q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, env_rows, u[:, o:], ldu, N, ntok,
-                        ret_from, self.kappas[h], write, gp[:, o:], ldg, gamma, beta, hs, self.gs, self._st())
+        """Recurrent retention + GroupNorm / gate for every state tile; S [ntile, N, 64, 64].  Rows: token a of env e at e * env_rows + a."""
+        E = self.E
+        if not self.blockwise:   # the kernel's fused epilogue covers a whole head
+            for ti, oq, ov, w, kap in self._tiles():
+                self.L.call("magpo_retention_recurrent", S[ti], q[:, oq:], ldq, k[:, oq:], ldk, v[:, ov:], ldv, env_rows, u[:, ov:], ldu, N, ntok,
+                            ret_from, kap, write, gp[:, ov:], ldg, gamma, beta, w, self.gs, self._st())
+            return
+        R = u.shape[0]
+        raw, tmp = self.b.get("rr_raw", (R, E)), self.b.get("rr_tmp", (R, TILE))
+        for ti, oq, ov, w, kap in self._tiles():
+            first = oq == 0
+            out, ldo = (raw[:, ov:], E) if first else (tmp, TILE)
+            self.L.call("magpo_retention_recurrent", S[ti], q[:, oq:], ldq, k[:, oq:], ldk, v[:, ov:], ldv, env_rows, out, ldo, N, ntok,
+                        ret_from, kap, write, None, 0, None, None, w, w, self._st())
+            if not first:
+                self.add_rows(raw[:, ov:], E, tmp, TILE, R, TILE)   # (rows outside [ret_from, ntok) hold stale values: never read)
+        for a in range(ret_from, ntok):   # GroupNorm + swish gate on the 128-wide rows of token a of every env
+            self.L.call("magpo_retpost_fwd", raw[a:], env_rows * E, gp[a:], env_rows * ldg, gamma, beta, u[a:], env_rows * ldu, N, self.hs, self.gs,
+                        E, self._st())
 
     def _ret_fwd(self, q, ldq, k, ldk, v, ldv, r, s0, seq_env, dones, name, nseq, T, masked, rows=None):
         """``rows`` (i32 [R], optional): q | k | v are row tables and token row r reads table row rows[r] (csrc/classtab.hip)."""
-        nch = self.L.call("magpo_retention_num_chunks", T, self.A, self.tuning.ret_chunk_tokens)
-        hs = self.hs
-        for h in range(self.nh):
-            o = h * hs
-            stt = self.b.get(f"t_{name}_{h}", (nseq, nch, E, E))
-            self.L.call("magpo_retention_chunk_fwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, r[:, o:], E, s0[h], seq_env, dones, stt,
-                        None, nseq, T, self.A, masked, self.kappas[h], hs, rows, self.tuning.ret_chunk_tokens, self._st())
+        ct = self.tuning.ret_chunk_tokens
+        nch = self.L.call("magpo_retention_num_chunks", T, self.A, ct)
+        E, R = self.E, nseq * T * self.A
+        for ti, oq, ov, w, kap in self._tiles():
+            stt = self.b.get(f"t_{name}_{ti}", (nseq, nch, TILE, TILE))
+            out, ldo = (r[:, ov:], E) if (not self.blockwise or oq == 0) else (self.b.get("rf_tmp", (R, TILE)), TILE)
+            self.L.call("magpo_retention_chunk_fwd", q[:, oq:], ldq, k[:, oq:], ldk, v[:, ov:], ldv, out, ldo, s0[ti], seq_env, dones, stt,
+                        None, nseq, T, self.A, masked, kap, w, rows, ct, self._st())
+            if out is not r and ldo == TILE:
+                self.add_rows(r[:, ov:], E, out, TILE, R, TILE)
 
     def _ret_bwd(self, q, ldq, k, ldk, v, ldv, dr, dq, lddq, dk, lddk, dv, lddv, dones, name, nseq, T, masked, rows=None):
-        hs = self.hs
-        for h in range(self.nh):
-            o = h * hs
-            self.L.call("magpo_retention_chunk_bwd", q[:, o:], ldq, k[:, o:], ldk, v[:, o:], ldv, dr[:, o:], E, dq[:, o:], lddq, dk[:, o:],
-                        lddk, dv[:, o:], lddv, dones, self.b.t[f"t_{name}_{h}"], nseq, T, self.A, masked, self.kappas[h], hs, rows, self.tuning.ret_chunk_tokens, self._st())
+        ct = self.tuning.ret_chunk_tokens
+        E, R = self.E, nseq * T * self.A
+        for ti, oq, ov, w, kap in self._tiles():
+            stt = self.b.t[f"t_{name}_{ti}"]
+            if not self.blockwise:
+                self.L.call("magpo_retention_chunk_bwd", q[:, oq:], ldq, k[:, oq:], ldk, v[:, ov:], ldv, dr[:, ov:], E, dq[:, oq:], lddq, dk[:, oq:],
+                            lddk, dv[:, ov:], lddv, dones, stt, nseq, T, self.A, masked, kap, w, rows, ct, self._st())
+                continue
+            # block (I, J) of the 128-wide head: dq_I, dk_I add over J; dv_J adds over I
+            tq, tk, tv = (self.b.get(f"rb_t{c}", (R, TILE)) for c in "qkv")
+            qk_first, v_first = ov == 0, oq == 0
+            oq_, ldq_ = (dq[:, oq:], lddq) if qk_first else (tq, TILE)
+            ok_, ldk_ = (dk[:, oq:], lddk) if qk_first else (tk, TILE)
+            ov_, ldv_ = (dv[:, ov:], lddv) if v_first else (tv, TILE)
+            self.L.call("magpo_retention_chunk_bwd", q[:, oq:], ldq, k[:, oq:], ldk, v[:, ov:], ldv, dr[:, ov:], E, oq_, ldq_, ok_, ldk_,
+                        ov_, ldv_, dones, stt, nseq, T, self.A, masked, kap, w, rows, ct, self._st())
+            if not qk_first:
+                self.add_rows(dq[:, oq:], lddq, tq, TILE, R, TILE)
+                self.add_rows(dk[:, oq:], lddk, tk, TILE, R, TILE)
+            if not v_first:
+                self.add_rows(dv[:, ov:], lddv, tv, TILE, R, TILE)
 
     def _retpost_fwd(self, r, gp, ldg, gamma, beta, u, R):
-        self.L.call("magpo_retpost_fwd", r, E, gp, ldg, gamma, beta, u, E, R, self.hs, self.gs, self._st())
+        E = self.E
+        self.L.call("magpo_retpost_fwd", r, E, gp, ldg, gamma, beta, u, E, R, self.hs, self.gs, E, self._st())
 
     def _retpost_bwd(self, r, gp, ldg, pfx, du, dr, dgp, lddg, R, sa, sb):
-        v, gv = self.v, self.gv
+        v, gv, E = self.v, self.gv, self.E
         self.L.call("magpo_retpost_bwd", r, E, gp, ldg, v[pfx + "gn.scale"], v[pfx + "gn.bias"], du, E, dr, E, dgp, lddg, sa, sb, R,
-                    self.hs, self.gs, self._st())
+                    self.hs, self.gs, E, self._st())
         for h in range(self.nh):   # scale / bias [hs] are shared by the heads: fold the per-column slabs
-            self.reduce(sa[:, h * self.hs:], gv[pfx + "gn.scale"], P=self.hs, stride=64, accumulate=h > 0)
-            self.reduce(sb[:, h * self.hs:], gv[pfx + "gn.bias"], P=self.hs, stride=64, accumulate=h > 0)
+            self.reduce(sa[:, h * self.hs:], gv[pfx + "gn.scale"], P=self.hs, stride=E, accumulate=h > 0)
+            self.reduce(sb[:, h * self.hs:], gv[pfx + "gn.bias"], P=self.hs, stride=E, accumulate=h > 0)
 
     def act(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False):
         """One env step for N envs (SableNetwork.get_actions, sable_network.py:443-482).  obs [N,A,F] f32, pos [N] i32
@@ -228,7 +330,7 @@ class SableGuider:
         uint32 (host array: keys by value; device tensor: static arguments for graph replay).
         Writes action [N,A] i32, logp [N,A], value [N,A].  Row-wise ops are fused into the prologue of the dense layer
         that follows them and the GroupNorm + swish gate into the recurrent retention kernel."""
-        L, st, A, K, F, nb = self.L, self._st(), self.A, self.K, self.F, self.nb
+        L, st, A, K, F, nb, E = self.L, self._st(), self.A, self.K, self.F, self.nb, self.E
         N = obs.shape[0]
         R = N * A
         v, b = self.v, self.b
@@ -243,7 +345,7 @@ class SableGuider:
         for blk in range(nb):
             e = f"enc.block{blk}."
             if blk == 0:
-                self._pro(2, obs, F, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, v["enc.obs.dense.kernel"], None, 0, xn, E, None, 0,
+                self._pro(2, obs, self.Fld, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, v["enc.obs.dense.kernel"], None, 0, xn, E, None, 0,
                           self.wt["qkvg0"], None, qkvg, 4 * E, R, 4 * E)
             else:  # x = ln(rep of the previous block) (shared self.ln, sable_network.py:150)
                 self._pro(3, rep, E, None, 0, v["enc.ln.scale"], None, True, pos_tok, 1, None, None, 0, xn, E, None, 0,
@@ -255,9 +357,9 @@ class SableGuider:
                 self._pro(3, xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], False, pos_tok, 1, None, None, 0, rep, E, reppe, E,
                           self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E)
             else:
-                L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], None, None, 0, 0, rep, E, None, 0, R, st)
+                L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], None, None, 0, 0, rep, E, None, 0, R, E, st)
         L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"],
-               v["enc.head.dense1.bias"], value_out, 1, R, st)
+               v["enc.head.dense1.bias"], value_out, 1, R, E, st)
         if value_only:
             return
         # autoregressive decoder (decode.py:111-153): one token per env per iteration.  Per-agent projections stay
@@ -265,7 +367,7 @@ class SableGuider:
         prev = b.get("a_prev", (N, A), torch.int32, zero=True)
         xa = b.get("d_xa", (N, E)); y1 = b.get("d_y1", (N, E)); y2 = b.get("d_y2", (N, E)); xo = b.get("d_xo", (N, E))
         xope = b.get("d_xope", (N, E))
-        hp = b.get("d_hp", (N, E)); logits = b.get("d_logits", (N, E), zero=True)
+        hp = b.get("d_hp", (N, E)); logits = b.get("d_logits", (N, LW), zero=True)
         qkvg1 = [b.get(f"d_qkvg1_{k}", (R, 4 * E)) for k in range(nb)]
         q2 = [b.get(f"d_q2_{k}", (R, E)) for k in range(nb)]
         kvg2 = [b.get(f"d_kvg2_{k}", (R, 3 * E)) for k in range(nb)]
@@ -296,14 +398,14 @@ class SableGuider:
                               None, 0, None, 0, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, N, E)
                 else:
                     L.call("magpo_resnorm_fwd", rep[i:], A * E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], self.pe, pos, 1, self.npos,
-                           xo, E, xope, E, N, st)
+                           xo, E, xope, E, N, E, st)
             self._pro(4, hp, E, None, 0, v["dec.head.norm.scale"], None, False, pos, 1, None, None, 0, None, 0, None, 0,
-                      self.wt["h1"], v["dec.head.dense1.bias"], logits, E, N, K)
+                      self.wt["h1"], v["dec.head.dense1.bias"], logits, LW, N, K)
             if torch.is_tensor(sample_keys):   # device key table [A, 2] (static arguments: HIP-graph replay)
                 k0, k1, kdev = 0, 0, sample_keys[i]
             else:
                 k0, k1, kdev = int(sample_keys[i][0]), int(sample_keys[i][1]), None
-            L.call("magpo_sample_categorical", logits, E, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
+            L.call("magpo_sample_categorical", logits, LW, None if mask is None else mask[:, i], (A * K if mask is not None else 0),
                    k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
 
     def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag="",
@@ -319,10 +421,10 @@ class SableGuider:
         A, K, F, nb, nh = self.A, self.K, self.F, self.nb, self.nh
         if A > 8 and self.wide:
             raise NotImplementedError("wide observations (obs_dim > 32) with more than 8 agents")
-        if A > 8:   # token staging registers of the fused kernel: larger teams take the kernel-by-kernel path (states settled on return)
+        if A > 8 or self.E != 64:   # token staging registers / 64-wide register rows of the fused kernel: larger teams take the kernel-by-kernel path (states settled on return)
             if done is not None:
                 for k in range(nb):
-                    for h in range(nh):
+                    for h in range(self.ntile):
                         self.L.call("magpo_zero_states_where_done", states[0][k][h], states[1][k][h], states[2][k][h], done, obs.shape[0], self._st())
             return self.act(obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=mask, value_only=value_only)
         N = obs.shape[0]
@@ -413,22 +515,20 @@ class SableGuider:
         enc=(cls, order, offsets), dec=(cls, order, offsets)): the embeddings and the first q|k|v|g projections of encoder
         and decoder are then evaluated on the distinct input rows only and gathered by class.
         Returns (logits [R,64] raw with K valid columns, value [R])."""
-        L, st, A, K, F, v, b, nb = self.L, self._st(), self.A, self.K, self.F, self.v, self.b, self.nb
+        L, st, A, K, F, v, b, nb, E = self.L, self._st(), self.A, self.K, self.F, self.v, self.b, self.nb, self.E
         R = nseq * T * A
-        nch = L.call("magpo_retention_num_chunks", T, A, self.tuning.ret_chunk_tokens)
         g = lambda n, w=E: b.get("t_" + n, (R, w))
-        stt = lambda n: b.get("t_" + n, (nseq, nch, E, E))
         direct = classes is not None and self.fused_segments   # block-0 consumers read the class tables through the class index
         self._saved = dict(obs=obs, prev_idx=prev_idx, pos=pos, dones=dones, nseq=nseq, T=T, R=R, classes=classes, direct=direct)
         rep, reppe, hv, value = g("rep"), g("reppe"), g("hv"), b.get("t_value", (R,))
-        logits = b.get("t_logits", (R, E), zero=True)
+        logits = b.get("t_logits", (R, LW), zero=True)
         # ---- encoder
         if classes is not None:   # embedding + first projection on the Ce distinct (agent, target, step) rows, gathered by class
             obs_c, pos_c = classes["rows"][0], classes["rows"][1]
             Ce = obs_c.shape[0]
             xn_c, kin_c, qkvg_c = b.get("c_xn0", (Ce, E)), b.get("c_kin0", (Ce, E)), b.get("c_qkvg0", (Ce, 4 * E))
             L.call("magpo_embed_fwd", 0, obs_c, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
-                   self.pe, pos_c, 1, self.npos, None, 0, xn_c, E, kin_c, E, Ce, st)
+                   self.pe, pos_c, 1, self.npos, None, 0, xn_c, E, kin_c, E, Ce, E, st)
             self.lin(kin_c, E, self.wt["qkvg0"], None, qkvg_c, 4 * E, Ce, E, 4 * E)
             if not direct:   # per-token copies for the unfused segment kernels; the fused ones read the tables through the class index
                 L.call("magpo_gather_rows", xn_c, E, classes["enc"][0], g("xn0"), E, R, E, st)
@@ -437,11 +537,11 @@ class SableGuider:
             on, z0 = b.get("t_on", (R, 128)), g("z0")
             L.call("magpo_obsnorm_fwd", obs, self.Fld, F, v["enc.obs.norm.scale"], on, R, st)
             self.lin(on, 128, self.wt["wobs"], None, z0, E, R, 128, E)
-            L.call("magpo_headmid_fwd", z0, E, v["enc.ln.scale"], g("xn0"), E, None, None, None, 0, R, st)
+            L.call("magpo_headmid_fwd", z0, E, v["enc.ln.scale"], g("xn0"), E, None, None, None, 0, R, E, st)
             L.call("magpo_add_pe", g("xn0"), E, self.pe, pos, 1, self.npos, g("kin0"), E, R, st)
         else:
             L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
-                   self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, st)   # z is recomputed by the backward
+                   self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, E, st)   # z is recomputed by the backward
         for k in range(nb):
             e = f"enc.block{k}."
             rows = classes["enc"][0] if direct and k == 0 else None
@@ -465,36 +565,36 @@ class SableGuider:
                 self._seg_post(0, r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], self.wt[f"wo{k}"], xn,
                                v[e + "ln1.scale"], v[e + "ln2.scale"], pos, u, y, repb, None, R, rows=rows)
                 L.call("magpo_resnorm_fwd", repb, E, None, 0, v["enc.ln.scale"], None, self.pe, pos, 1, self.npos,
-                       g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, st)
+                       g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, E, st)
                 continue
             self._retpost_fwd(r, qkvg[:, 3 * E:], 4 * E, v[e + "retn.gn.scale"], v[e + "retn.gn.bias"], u, R)
             self.lin(u, E, self.wt[f"wo{k}"], None, y, E, R, E, E)
             if k == nb - 1:
                 L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], self.pe, pos, 1, self.npos,
-                       rep, E, reppe, E, R, st)
+                       rep, E, reppe, E, R, E, st)
             else:
                 repb = g(f"repb{k}")
-                L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], None, None, 0, 0, repb, E, None, 0, R, st)
+                L.call("magpo_resnorm_fwd", xn, E, y, E, v[e + "ln1.scale"], v[e + "ln2.scale"], None, None, 0, 0, repb, E, None, 0, R, E, st)
                 L.call("magpo_resnorm_fwd", repb, E, None, 0, v["enc.ln.scale"], None, self.pe, pos, 1, self.npos,
-                       g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, st)
+                       g(f"xn{k + 1}"), E, g(f"kin{k + 1}"), E, R, E, st)
         if not self.fused_segments:
             self.lin(rep, E, self.wt["vh0"], v["enc.head.dense0.bias"], hv, E, R, E, E)
             L.call("magpo_headmid_fwd", hv, E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
-                   value, 1, R, st)
+                   value, 1, R, E, st)
         # ---- decoder
         if classes is not None:   # action embedding + first projection on the Cd distinct (previous action, step) rows
             prev_c, posd_c = classes["rows"][2], classes["rows"][3]
             Cd = prev_c.shape[0]
             x_c, xpe_c, qkvg1_c = b.get("c_x0", (Cd, E)), b.get("c_xpe0", (Cd, E)), b.get("c_qkvg10", (Cd, 4 * E))
             L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_c, 1, v["dec.ln.scale"], self.pe, posd_c, 1, self.npos,
-                   None, 0, x_c, E, xpe_c, E, Cd, st)
+                   None, 0, x_c, E, xpe_c, E, Cd, E, st)
             self.lin(xpe_c, E, self.wt["qkvg10"], None, qkvg1_c, 4 * E, Cd, E, 4 * E)
             if not direct:
                 L.call("magpo_gather_rows", x_c, E, classes["dec"][0], g("x0"), E, R, E, st)
                 L.call("magpo_gather_rows", qkvg1_c, 4 * E, classes["dec"][0], g("qkvg10", 4 * E), 4 * E, R, 4 * E, st)
         else:
             L.call("magpo_embed_fwd", 1, None, 0, 0, None, v["dec.act.kernel"], prev_idx, 1, v["dec.ln.scale"], self.pe, pos, 1, self.npos,
-                   None, 0, g("x0"), E, g("xpe0"), E, R, st)   # za = W_act[prev] is gathered again by the backward
+                   None, 0, g("x0"), E, g("xpe0"), E, R, E, st)   # za = W_act[prev] is gathered again by the backward
         for k in range(nb):
             d = f"dec.block{k}."
             rows = classes["dec"][0] if direct and k == 0 else None
@@ -523,7 +623,7 @@ class SableGuider:
                 continue
             self._retpost_fwd(r1, qkvg1[:, 3 * E:], 4 * E, v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"], u1, R)
             self.lin(u1, E, self.wt[f"wo1{k}"], None, y1, E, R, E, E)
-            L.call("magpo_resnorm_fwd", x, E, y1, E, v[d + "ln1.scale"], None, self.pe, pos, 1, self.npos, None, 0, cpe, E, R, st)   # only c + pe is consumed
+            L.call("magpo_resnorm_fwd", x, E, y1, E, v[d + "ln1.scale"], None, self.pe, pos, 1, self.npos, None, 0, cpe, E, R, E, st)   # only c + pe is consumed
             self.lin(reppe, E, self.wt[f"q2{k}"], None, q2, E, R, E, E)
             self.lin(cpe, E, self.wt[f"kvg2{k}"], None, kvg2, 3 * E, R, E, 3 * E)
             self._ret_fwd(q2, E, kvg2, 3 * E, kvg2[:, E:], 3 * E, r2, s0[2][k], seq_env, dones, f"st_2{k}", nseq, T, 1)
@@ -531,22 +631,22 @@ class SableGuider:
             self.lin(u2, E, self.wt[f"wo2{k}"], None, y2, E, R, E, E)
             if k == nb - 1:
                 L.call("magpo_resnorm_fwd", rep, E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], None, None, 0, 0, g(f"x{nb}"), E,
-                       None, 0, R, st)
+                       None, 0, R, E, st)
             else:
                 L.call("magpo_resnorm_fwd", rep, E, y2, E, v[d + "ln2.scale"], v[d + "ln3.scale"], self.pe, pos, 1, self.npos,
-                       g(f"x{k + 1}"), E, g(f"xpe{k + 1}"), E, R, st)
+                       g(f"x{k + 1}"), E, g(f"xpe{k + 1}"), E, R, E, st)
         if not self.fused_segments:
             hp, hn = g("hp"), g("hn")
             self.lin(g(f"x{nb}"), E, self.wt["h0"], v["dec.head.dense0.bias"], hp, E, R, E, E)
-            L.call("magpo_headmid_fwd", hp, E, v["dec.head.norm.scale"], hn, E, None, None, None, 0, R, st)
-            self.lin(hn, E, self.wt["h1"], v["dec.head.dense1.bias"], logits, E, R, E, K)
+            L.call("magpo_headmid_fwd", hp, E, v["dec.head.norm.scale"], hn, E, None, None, None, 0, R, E, st)
+            self.lin(hn, E, self.wt["h1"], v["dec.head.dense1.bias"], logits, LW, R, E, K)
         return logits, value
 
     # ------------------------------------------------------------------ training backward
     def train_bwd(self, dlogits, dvalue):
         """dlogits [R,64] (columns >= K zero), dvalue [R]; fills self.grads (every entry written exactly once, the
         shared encoder ln scale accumulates over blocks)."""
-        L, st, A, K, F, v, gv, b, nb = self.L, self._st(), self.A, self.K, self.F, self.v, self.gv, self.b, self.nb
+        L, st, A, K, F, v, gv, b, nb, E = self.L, self._st(), self.A, self.K, self.F, self.v, self.gv, self.b, self.nb, self.E
         sv = self._saved
         R, nseq, T = sv["R"], sv["nseq"], sv["T"]
         obs, prev_idx, pos, dones = sv["obs"], sv["prev_idx"], sv["pos"], sv["dones"]
@@ -554,13 +654,13 @@ class SableGuider:
         t = lambda n: b.t["t_" + n]
         g = lambda n, w=E: b.get("g_" + n, (R, w))
         grid = L.call("magpo_row_grid", R)
-        slab = lambda n, w=64: b.get("s_" + n, (grid, w))
+        slab = lambda n, w=E: b.get("s_" + n, (grid, w))
         # ---- logit head
-        self.wgrad(t("hn"), E, dlogits, E, R, E, K, gv["dec.head.dense1.kernel"], gv["dec.head.dense1.bias"])
+        self.wgrad(t("hn"), E, dlogits, LW, R, E, K, gv["dec.head.dense1.kernel"], gv["dec.head.dense1.bias"])
         dhn = g("dhn")
-        self.lin(dlogits, E, self.wt["h1_nat_pad"], None, dhn, E, R, E, E)
+        self.lin(dlogits, LW, self.wt["h1_nat_pad"], None, dhn, E, R, LW, E)
         dhp = g("dhp_l")
-        L.call("magpo_headmid_bwd", t("hp"), E, v["dec.head.norm.scale"], dhn, E, None, None, 0, dhp, E, slab("a"), None, None, R, st)
+        L.call("magpo_headmid_bwd", t("hp"), E, v["dec.head.norm.scale"], dhn, E, None, None, 0, dhp, E, slab("a"), None, None, R, E, st)
         self.reduce(slab("a"), gv["dec.head.norm.scale"])
         self.wgrad(t(f"x{nb}"), E, dhp, E, R, E, E, gv["dec.head.dense0.kernel"], gv["dec.head.dense0.bias"])
         dout = g("dout")
@@ -579,7 +679,7 @@ class SableGuider:
                 self.wgrad(t(f"u2{k}"), E, dsum2, E, R, E, E, gv[d + "retn2.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t("rep"), E, t(f"y2{k}"), E, v[d + "ln2.scale"], v[d + "ln3.scale"], din0, E, din1, E if din1 is not None else 0,
-                       None, 0, dsum2, E, slab("a"), slab("b"), R, st)
+                       None, 0, dsum2, E, slab("a"), slab("b"), R, E, st)
                 self.reduce(slab("a"), gv[d + "ln2.scale"]); self.reduce(slab("b"), gv[d + "ln3.scale"])
                 self.wgrad(t(f"u2{k}"), E, dsum2, E, R, E, E, gv[d + "retn2.w_o"])
                 du2 = g("du")
@@ -607,7 +707,7 @@ class SableGuider:
                 self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t(f"x{k}"), E, t(f"y1{k}"), E, v[d + "ln1.scale"], None, dcpe, E, None, 0, None, 0, dsum1, E,
-                       slab("a"), None, R, st)
+                       slab("a"), None, R, E, st)
                 self.reduce(slab("a"), gv[d + "ln1.scale"])
                 self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
                 du1 = g("du")
@@ -624,23 +724,23 @@ class SableGuider:
                 L.call("magpo_class_sum", dsum1, E, order, offsets, Cd, E, part, ds_c, st)
                 self.wgrad(b.t["c_xpe0"], E, dq_c, 4 * E, Cd, E, 4 * E, gv[d + "retn1.w_qkvg"])
                 dkin1 = b.get("gc_dkin1", (Cd, E))
-                self.lin(dq_c, 4 * E, v[d + "retn1.w_qkvg"], None, dkin1, E, Cd, 4 * E, E)
+                self.lin_dx_qkvg(dq_c, d + "retn1.w_qkvg", dkin1, Cd)
                 din0, din1, prev_idx, Rd = ds_c, dkin1, cl["rows"][2], Cd
                 break
             self.wgrad(t(f"xpe{k}"), E, dqkvg1, 4 * E, R, E, 4 * E, gv[d + "retn1.w_qkvg"])
             dkin1 = g(f"dkin1_{k}")
-            self.lin(dqkvg1, 4 * E, v[d + "retn1.w_qkvg"], None, dkin1, E, R, 4 * E, E)
+            self.lin_dx_qkvg(dqkvg1, d + "retn1.w_qkvg", dkin1, R)
             din0, din1 = dsum1, dkin1      # gradient of x_k (block input): residual path + key/query/value path
         gridd = L.call("magpo_row_grid", Rd)
-        sa_d, sw_d = b.get("s_a_d", (gridd, 64)), b.get("s_w_d", (gridd, 32 * E))
+        sa_d, sw_d = b.get("s_a_d", (gridd, E)), b.get("s_w_d", (gridd, 32 * E))
         L.call("magpo_embed_bwd", 1, None, 0, din0, E, din1, E, None, 0, v["dec.ln.scale"], None, 0, sa_d, sw_d,
-               K + 1, None, 0, 0, None, v["dec.act.kernel"], None, prev_idx, 1, Rd, st)
+               K + 1, None, 0, 0, None, v["dec.act.kernel"], None, prev_idx, 1, Rd, E, st)
         self.reduce(sa_d, gv["dec.ln.scale"])
         self.reduce(sw_d, gv["dec.act.kernel"], P=(K + 1) * E, stride=32 * E)
         # ---- value head
         dhv = g("dhv")
         L.call("magpo_headmid_bwd", t("hv"), E, v["enc.head.norm.scale"], None, 0, v["enc.head.dense1.kernel"], dvalue, 1, dhv, E,
-               slab("a"), slab("b"), slab("c", 1), R, st)
+               slab("a"), slab("b"), slab("c", 1), R, E, st)
         self.reduce(slab("a"), gv["enc.head.norm.scale"]); self.reduce(slab("b"), gv["enc.head.dense1.kernel"])
         self.reduce(slab("c", 1), gv["enc.head.dense1.bias"], P=1, stride=1)
         self.wgrad(t("rep"), E, dhv, E, R, E, E, gv["enc.head.dense0.kernel"], gv["enc.head.dense0.bias"])
@@ -661,7 +761,7 @@ class SableGuider:
                 self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t(f"xn{k}"), E, t(f"y{k}"), E, v[e + "ln1.scale"], v[e + "ln2.scale"], e0, E, e1, E if e1 is not None else 0,
-                       e2, E if e2 is not None else 0, dsum0, E, slab("a"), slab("b"), R, st)
+                       e2, E if e2 is not None else 0, dsum0, E, slab("a"), slab("b"), R, E, st)
                 self.reduce(slab("a"), gv[e + "ln1.scale"]); self.reduce(slab("b"), gv[e + "ln2.scale"])
                 self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
                 du = g("du")
@@ -679,22 +779,22 @@ class SableGuider:
                 L.call("magpo_class_sum", dsum0, E, order, offsets, Ce, E, part, ds_c, st)
                 self.wgrad(b.t["c_kin0"], E, dq_c, 4 * E, Ce, E, 4 * E, gv[e + "retn.w_qkvg"])
                 dkin = b.get("gc_dkin0", (Ce, E))
-                self.lin(dq_c, 4 * E, v[e + "retn.w_qkvg"], None, dkin, E, Ce, 4 * E, E)
+                self.lin_dx_qkvg(dq_c, e + "retn.w_qkvg", dkin, Ce)
                 gride = L.call("magpo_row_grid", Ce)
-                sa, sw, sd = b.get("s_a_e", (gride, 64)), b.get("s_w_e", (gride, 32 * E)), b.get("s_d_e", (gride, 32))
+                sa, sw, sd = b.get("s_a_e", (gride, E)), b.get("s_w_e", (gride, 32 * E)), b.get("s_d_e", (gride, 32))
                 L.call("magpo_embed_bwd", 0, None, 0, ds_c, E, dkin, E, None, 0, v["enc.ln.scale"], None, 0, sa, sw, F,
-                       obs_c, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], sd, None, 0, Ce, st)
+                       obs_c, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], sd, None, 0, Ce, E, st)
                 self.reduce(sa, gv["enc.ln.scale"], accumulate=not first_ln)
                 self.reduce(sd, gv["enc.obs.norm.scale"], P=F, stride=32)
                 self.reduce(sw, gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)
                 break
             self.wgrad(t(f"kin{k}"), E, dqkvg, 4 * E, R, E, 4 * E, gv[e + "retn.w_qkvg"])
             dkin = g(f"dkin_{k}")
-            self.lin(dqkvg, 4 * E, v[e + "retn.w_qkvg"], None, dkin, E, R, 4 * E, E)
+            self.lin_dx_qkvg(dqkvg, e + "retn.w_qkvg", dkin, R)
             if k > 0:  # xn_k = rms(rep_{k-1}) * enc.ln (shared scale): d(rep_{k-1})
                 drepb = g(f"drepb_{k}")
                 L.call("magpo_resnorm_bwd", t(f"repb{k - 1}"), E, None, 0, v["enc.ln.scale"], None, dsum0, E, dkin, E, None, 0, drepb, E,
-                       slab("a"), None, R, st)
+                       slab("a"), None, R, E, st)
                 self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
                 first_ln = False
                 e0, e1, e2 = drepb, None, None
@@ -702,7 +802,7 @@ class SableGuider:
                 dxn, dz, don = g("dxn0"), g("dz0"), b.get("g_don", (R, 128))
                 L.call("magpo_copy_rows", dsum0, E, dxn, E, R, E, st)
                 self.add_(dxn, dkin)
-                L.call("magpo_headmid_bwd", t("z0"), E, v["enc.ln.scale"], dxn, E, None, None, 0, dz, E, slab("a"), None, None, R, st)
+                L.call("magpo_headmid_bwd", t("z0"), E, v["enc.ln.scale"], dxn, E, None, None, 0, dz, E, slab("a"), None, None, R, E, st)
                 self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
                 self.wgrad(b.t["t_on"], 128, dz, E, R, 128, E, gv["enc.obs.dense.kernel"], krows=F)
                 self.lin(dz, E, self.wt["wobs_nat_pad"], None, don, 128, R, E, 128)
@@ -711,7 +811,7 @@ class SableGuider:
                 self.reduce(so, gv["enc.obs.norm.scale"], P=F, stride=128)
             else:
                 L.call("magpo_embed_bwd", 0, None, 0, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], None, 0, slab("a"), slab("w", 32 * E), F,
-                       obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, st)
+                       obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, E, st)
                 self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
                 self.reduce(slab("d", 32), gv["enc.obs.norm.scale"], P=F, stride=32)
                 self.reduce(slab("w", 32 * E), gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)

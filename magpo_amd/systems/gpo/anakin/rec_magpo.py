@@ -56,8 +56,15 @@ def _snapshot_state(learner: MagpoLearner) -> GPOLearnerState:
     # The state carries the reference's [embed_dim / n_head, embed_dim / n_head] head states (get_init_hstates.py:20-43).  On the
     # device a head state sits in a zero-padded 64 x 64 tile, and a narrow net (embed_dim < 64, params.WidthEmbedding) keeps logical
     # entry (i, j) at device rows m i (q / k live in the first copy) and columns m j .. m j + m - 1 (v is duplicated), m = 64 / embed_dim.
-    hw, m = learner.guider.hs, 64 // learner.guider.EL
-    hs = HiddenStates(SableHiddenStates(*[torch.stack([g.sable_hs[i][..., :hw:m, :hw:m] for g in gs]) for i in range(3)]),
+    # The one 128-wide head of embed_dim 128 / n_head 1 lives in four 64 x 64 tiles S[I][J] (tile 2 I + J).
+    gd = learner.guider
+    hw, m = gd.hs, max(1, 64 // gd.EL)
+
+    def logical(t):   # [n_block, ntile, N, 64, 64] -> [n_block, n_head, N, hs_logical, hs_logical]
+        if gd.blockwise:
+            return torch.cat([torch.cat([t[:, 0], t[:, 1]], -1), torch.cat([t[:, 2], t[:, 3]], -1)], -2).unsqueeze(1)
+        return t[..., :hw:m, :hw:m]
+    hs = HiddenStates(SableHiddenStates(*[torch.stack([logical(g.sable_hs[i]) for g in gs]) for i in range(3)]),
                       torch.stack([g.policy_h[g.cur] for g in gs]))
     env_state = {f: torch.stack([getattr(g.env, f) for g in gs]) for f in gs[0].env.state_fields}
     timestep = dict(agents_view=torch.stack([g.traj["obs"][0] for g in gs]), step_count=torch.stack([g.traj["step_count"][0] for g in gs]))
@@ -88,9 +95,15 @@ def load_learner_state(learner: MagpoLearner, state: GPOLearnerState) -> None:
             grp.traj["mask"][0].copy_(state.timestep["action_mask"][gi])
         grp.traj["step_count"][0].copy_(state.timestep["step_count"][gi])
         grp.traj["done"][0].copy_(state.dones[gi])
-        hw, m = learner.guider.hs, 64 // learner.guider.EL
+        gd = learner.guider
+        hw, m = gd.hs, max(1, 64 // gd.EL)
         for i in range(3):
             grp.sable_hs[i].zero_()
+            if gd.blockwise:   # [n_block, 1, N, 128, 128] -> tiles (I, J)
+                full = sable[i][gi][:, 0]
+                for ti in range(4):
+                    grp.sable_hs[i][:, ti].copy_(full[..., 64 * (ti // 2):64 * (ti // 2) + 64, 64 * (ti % 2):64 * (ti % 2) + 64])
+                continue
             for c in range(m):   # rows m i, every column copy (inverse of the collapse in _snapshot_state)
                 grp.sable_hs[i][..., :hw:m, c:hw:m].copy_(sable[i][gi])
         grp.policy_h[grp.cur].copy_(hst["policy_hidden_state"][gi])
@@ -150,8 +163,8 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
         mc.chunk_size = config.system.rollout_length * env.num_agents
     if mc.type != "rec_sable":
         raise NotImplementedError("memory_config.type must be rec_sable")
-    if int(nc.embed_dim) not in (16, 32, 64) or int(nc.n_head) not in (1, 2, 4) or int(config.network.hidden_state_dim) != 128:
-        raise NotImplementedError("HIP kernels support embed_dim in {16,32,64}, n_head in {1,2,4}, hidden_state_dim=128 (any n_block)")
+    if int(nc.embed_dim) not in (16, 32, 64, 128) or int(nc.n_head) not in (1, 2, 4) or int(config.network.hidden_state_dim) != 128:
+        raise NotImplementedError("HIP kernels support embed_dim in {16,32,64,128}, n_head in {1,2,4}, hidden_state_dim=128 (any n_block)")
     device = device or torch.device("cuda", torch.cuda.current_device())
     U = int(config.system.update_batch_size)
     learner = MagpoLearner(env.cfg, int(config.arch.num_envs), _system_config(config), device,

@@ -1,0 +1,33 @@
+"""Acting kernel alone at a given shape: us per launch in rollout mode (pending decoder-state rows, no flush), by device events.
+usage: python scripts/debug/act_time.py [N] [A] [n_block] [K] [launches]     (MAGPO_LIB=path selects an experiment build, MAGPO_ACT_EPW the wave shape)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import magpo_amd._lib as _lib
+if os.environ.get("MAGPO_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["MAGPO_LIB"])
+import torch
+from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig, host_split, prng_key
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+A = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+nb = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 40
+l = MagpoLearner(CoordSumConfig(A, K, 100, 60), N, SystemConfig(rollout_length=4, ppo_epochs=1, num_minibatches=1), "cuda", net_seed=0, n_block=nb)
+l.use_graph = False
+l.setup(host_split(prng_key(1), 4)[0])
+g = l.groups[0]; tr = g.traj
+l._rollout_keys(g)
+def call(pending=True):
+    l.guider.act_fused(tr["obs"][0], tr["step_count"][0], g.sable_hs, g.skeys_host[0], tr["action"][0], tr["log_prob"][0], tr["value"][0],
+                       done=tr["done"][0], pending=pending, flush=False)
+call(False)
+for _ in range(3): call()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): call()
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / reps * 1e3
+alg = 6.0 * 16384 * nb * N
+print(f"N={N} A={A} nb={nb} K={K} epw={l.tuning.act_envs_per_wave or 'auto'} lib={os.path.basename(_lib.LIB_PATH)}: {us:8.1f} us per launch, "
+      f"{alg / us / 1e6:7.1f} GB/s algorithmic ({alg / us / 1e6 / 8000:.3f} of 8 TB/s)")
