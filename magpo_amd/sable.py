@@ -283,10 +283,11 @@ class SableGuider:
         E, R = self.E, nseq * T * self.A
         for ti, oq, ov, w, kap in self._tiles():
             stt = self.b.get(f"t_{name}_{ti}", (nseq, nch, TILE, TILE))
-            out, ldo = (r[:, ov:], E) if (not self.blockwise or oq == 0) else (self.b.get("rf_tmp", (R, TILE)), TILE)
+            partial = self.blockwise and oq != 0   # second q / k half of the 128-wide head: its contribution adds to the first one's
+            out, ldo = (self.b.get("rf_tmp", (R, TILE)), TILE) if partial else (r[:, ov:], E)
             self.L.call("magpo_retention_chunk_fwd", q[:, oq:], ldq, k[:, oq:], ldk, v[:, ov:], ldv, out, ldo, s0[ti], seq_env, dones, stt,
                         None, nseq, T, self.A, masked, kap, w, rows, ct, self._st())
-            if out is not r and ldo == TILE:
+            if partial:
                 self.add_rows(r[:, ov:], E, out, TILE, R, TILE)
 
     def _ret_bwd(self, q, ldq, k, ldk, v, ldv, dr, dq, lddq, dk, lddk, dv, lddv, dones, name, nseq, T, masked, rows=None):
