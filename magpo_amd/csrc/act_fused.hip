@@ -464,6 +464,12 @@ __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const R
 #ifndef MAGPO_ACT_NBUF16
 #define MAGPO_ACT_NBUF16 2
 #endif
+// A/B hook (scripts/debug/act_ab.sh): 1 = the first state of a pass is requested ahead of the dense phase in front of it instead of at the
+// start of the pass.  Measured on one box, 16 384 envs: 582 / 584 us with, 574 / 575 us without (4 096 envs: 280 vs 273) -- with 1 024
+// independent waves the memory system already has work while a wave runs its dense phase; the extra live registers cost more.  Off.
+#ifndef MAGPO_ACT_PRIME
+#define MAGPO_ACT_PRIME 0
+#endif
 constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
 
 template <int EPW, int NA, int NH>
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
 
   // first state of the block-0 encoder pass: in flight while the token rows are computed
   float4 pS[16];
-  prime_state(pS, a.S_enc + (long)env0 * 4096, lane);
+  if (MAGPO_ACT_PRIME) prime_state(pS, a.S_enc + (long)env0 * 4096, lane);
 
   // ---------------- encoder over the A tokens of the step (act_encoder_fn, encode.py:58-84)
   for (int b = 0; b < nb; ++b) {
@@ -528,10 +534,10 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
     }
     wsync();
     PROF(0);
-    if (b == 0) ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH, true>(TQ, HK, U, a.S_enc, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask, nullptr, 0, 0, pS);
+    if (b == 0) ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH, MAGPO_ACT_PRIME != 0>(TQ, HK, U, a.S_enc, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask, nullptr, 0, 0, pS);
     else ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
     // the first cross-retention state of the decoder pre-pass rides along with the encoder's post-retention dense phase
-    if (b == nb - 1 && !a.value_only) prime_state(pS, a.S_d2 + (long)env0 * 4096, lane);
+    if (MAGPO_ACT_PRIME && b == nb - 1 && !a.value_only) prime_state(pS, a.S_d2 + (long)env0 * 4096, lane);
     wsync();
     PROF(1);
     for (int t = 0; t < A; ++t) {
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
     float4 pS1[16];   // block 0, one head: the first self-retention state of the candidate pass
-    if (b == 0) ret_pass<4, NA, NBF, NH, true>(TQ, HK, U, a.S_d2, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
+    if (b == 0) ret_pass<4, NA, NBF, NH, MAGPO_ACT_PRIME != 0>(TQ, HK, U, a.S_d2, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
                                                B.q2, AE, a.pending, pS);
     else ret_pass<4, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
                                   B.q2, AE, a.pending);
