@@ -263,6 +263,10 @@ def main():
                          "--num-envs 4096): UNPINNED dynamics, csrc/lbf.hip / csrc/rware.hip restate Jumanji's published algorithm")
     ap.add_argument("--micro-batches", type=int, default=0, help="train every minibatch in this many slabs with accumulated gradients (same update, "
                     "activations in HBM scale with the slab); 0 = the workload's default (1; coordsum-8x15: 4)")
+    ap.add_argument("--embed-dim", type=int, default=64, help="Sable embed_dim (16 / 32 / 64 / 128); the headline is the reference default 64")
+    ap.add_argument("--n-head", type=int, default=1)
+    ap.add_argument("--n-block", type=int, default=0, help="0 = the workload's default (1; coordsum-8x15: 2)")
+    ap.add_argument("--ppo-epochs", type=int, default=0, help="0 = the reference default 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
@@ -313,7 +317,10 @@ def main():
         sysc = SystemConfig(micro_batches=args.micro_batches or 1)  # reference defaults (configs/system/gpo/rec_magpo.yaml)
         env_cfg = CoordSumConfig(num_agents=4, num_actions=20, time_limit=100, maxval=60)
         n_block = 1
-    learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0, n_block=n_block, tuning=tuning)  # same seed => replicated parameters on every rank
+    n_block = args.n_block or n_block
+    if args.ppo_epochs:
+        sysc.ppo_epochs = args.ppo_epochs
+    learner = MagpoLearner(env_cfg, N, sysc, dev, net_seed=0, n_block=n_block, n_head=args.n_head, embed_dim=args.embed_dim, tuning=tuning)  # same seed => replicated parameters on every rank
     key = host_split(prng_key(42), 4)[0]
     learner.setup(key, n_groups=world, group=rank)
     if args.overlap:
@@ -420,7 +427,7 @@ def main():
             "data": f"synthetic (fixed-seed {env_name} episodes, random-init networks)",
             "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
                                    f"num_minibatches={sysc.num_minibatches}" + (f" (each in {sysc.micro_batches} slabs, gradients accumulated)" if sysc.micro_batches > 1 else "")
-                                   + f", Sable embed 64 / 1 head / {n_block} block, GRU 128",
+                                   + f", Sable embed {args.embed_dim} / {args.n_head} head / {n_block} block, GRU 128",
                        "agent_steps_per_s": round(env_steps * env_cfg.num_agents / elapsed, 1),
                        "first_layer_class_tables": bool(learner.class_tables),   # exact (no caching across updates); MAGPO_CLASS_TABLES=0 = dense path
                        "parallelism": f"dp{world} (envs sharded, one flat grad all-reduce per minibatch)"},

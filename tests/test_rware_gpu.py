@@ -63,20 +63,21 @@ def test_rware_env_matches_oracle(CH, SR, SC, A, Q, TL, N):
     assert resets > N and early > 0, "the test must see horizon endings and collision endings"
 
 
-def _mk(cfg_args, N, T, P=2, M=2, seed=5):
+def _mk(cfg_args, N, T, P=2, M=2, seed=5, E=64, nh=1, nb=1):
     from magpo_amd.learner import MagpoLearner, RwareConfig, SystemConfig
     spec = orw.RwareSpec(*cfg_args)
     cfg = RwareConfig(*cfg_args)
     A, K, F = spec.num_agents, 5, spec.obs_dim
-    scfg = onets.SableCfg(A, K, F)
-    gp = onets.init_guider_params(1, 64, F, K)
+    scfg = onets.SableCfg(A, K, F, embed_dim=E, n_head=nh, n_block=nb)
+    gp = onets.init_guider_params(1, E, F, K, nh=nh, nb=nb)
     ap = onets.init_actor_params(2, F, 128, K)
     gp["dec.head.dense1.kernel"] = gp["dec.head.dense1.kernel"] * 30
     ap["head.kernel"] = ap["head.kernel"] * 30
     ol = olearn.OracleLearner(spec, N, olearn.SystemCfg(rollout_length=T, ppo_epochs=P, num_minibatches=M), scfg, gp, ap, env=orw)
     key = oprng.split(oprng.prng_key(seed), 4)[0]
     ol.setup(key)
-    dl = MagpoLearner(cfg, N, SystemConfig(rollout_length=T, ppo_epochs=P, num_minibatches=M), "cuda", net_seed=None, wgrad_groups=4)
+    dl = MagpoLearner(cfg, N, SystemConfig(rollout_length=T, ppo_epochs=P, num_minibatches=M), "cuda", net_seed=None, wgrad_groups=4,
+                      embed_dim=E, n_head=nh, n_block=nb)
     dl.guider.load_named(gp); dl.actor.load_named(ap)
     dl.setup(key)
     return ol, dl
@@ -88,10 +89,12 @@ def _close(a, b, rtol, atol, what):
     assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} (ref scale {ref:.3e})"
 
 
-def test_rware_learner_parity():
-    """Wide observations (75 features) through rollout, minibatch gradients and a full update, against the oracle."""
+@pytest.mark.parametrize("E,nh,nb", [(64, 1, 1), (128, 2, 3), (128, 1, 1)])
+def test_rware_learner_parity(E, nh, nb):
+    """Wide observations (75 features) through rollout, minibatch gradients and a full update, against the oracle.  (128, 2, 3) is the tuned
+    MAGPO network of RWARE tiny-4ag (experiment_data/params.csv: n_embd 128, n_head 2, n_block 3), (128, 1, 1) that of tiny-2ag / medium-4ag."""
     N, T = 8, 16
-    ol, dl = _mk((8, 1, 3, 4, 1, 4, 11), N, T)
+    ol, dl = _mk((8, 1, 3, 4, 1, 4, 11), N, T, E=E, nh=nh, nb=nb)
     F = 75
     om = ol.rollout()
     dl.rollout()
