@@ -43,6 +43,19 @@ constexpr int QP = 272;          // LDS pitch of a [q|k|v|g] token row: 16 mod 6
 constexpr int UP = 80;
            // LDS pitch of a 64-wide row
 
+// Timing experiments only (scripts/debug/act_ab.sh; results are WRONG with them): -DMAGPO_ACT_X_NOLOAD replaces every retention-state load
+// by a constant, -DMAGPO_ACT_X_NOSTORE drops the state stores -- what is left is the kernel's compute + scratch-row time.
+#ifdef MAGPO_ACT_X_NOLOAD
+#define XLOAD(p) make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f)
+#else
+#define XLOAD(p) ld4nt(p)
+#endif
+#ifdef MAGPO_ACT_X_NOSTORE
+#define XSTORE(p, v) do { if ((v).x == 123.456f) st4nt(p, v); } while (0)
+#else
+#define XSTORE(p, v) st4nt(p, v)
+#endif
+
 struct ActBlk {
   const float *qkvg_t, *wo_t, *ln1, *ln2, *gn_g, *gn_b;                                     // encoder block
   const float *qkvg1_t, *wo1_t, *dln1, *gn1_g, *gn1_b;                                       // decoder self-retention
@@ -138,7 +151,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
     const float* Se = S0 + (long)h * NS + (long)(env0 + e) * 4096;
     if (with_state) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = ld4nt(Se + (16 * rg + r) * 64 + c4);
+      for (int r = 0; r < 16; ++r) dst[r] = XLOAD(Se + (16 * rg + r) * 64 + c4);
     }
     const long row0 = (long)(env0 + e) * A;
 #pragma unroll
@@ -219,7 +232,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
       }
       if (write_state && live) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st4nt(Se + (16 * rg + r) * 64 + c4, s[r]);
+        for (int r = 0; r < 16; ++r) XSTORE(Se + (16 * rg + r) * 64 + c4, s[r]);
       }
       if (MODE == 4) {   // the outputs see kappa S
         const float kp = a.kappa[h];
@@ -277,20 +290,20 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
 // layout), B = the state registers.  For that the lane (col group n = l & 15, kq = l >> 4) holds state rows rho(j) = 16 (j >> 2) +
 // 4 kq + (j & 3), j < 16 -- the Row feature order -- of columns 4 n .. 4 n + 3; k-step j multiplies feature rho(j) on both sides.
 // Output tile (mt, nt): lane holds candidates 16 mt + 4 kq + i (i < 4) of column 4 n + nt, i.e. one float4 of row c per lane.
-template <int NA, int MT>
+template <int NA, int MT, int NB>
 __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* __restrict__ S0, const ActArgs& a, int env0, int nvalid,
                                                   const float* __restrict__ pend, const Row (&xq)[MT], unsigned long long dmask,
                                                   const float4* __restrict__ primed) {
   const int lane = threadIdx.x, n16 = lane & 15, c4 = 4 * n16, kq = lane >> 4, A = a.A;
   const float kappa = a.kappa[0];
   const int pe_row = a.K + 1, pe_mt = pe_row >> 4, pe_m = pe_row & 15;
-  float4 buf[2][16], hreg[2][NA];
+  float4 buf[NB][16], hreg[NB][NA];   // NB states rotate: NB - 1 in flight behind the one in use
   auto prefetch = [&](float4 (&dst)[16], float4 (&tok)[NA], int e, bool with_state = true) {
     e = min(e, nvalid - 1);
     const float* Se = S0 + (long)(env0 + e) * 4096;
     if (with_state) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) dst[j] = ld4nt(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4);
+      for (int j = 0; j < 16; ++j) dst[j] = XLOAD(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4);
     }
     const long row0 = (long)(env0 + e) * A;
 #pragma unroll
@@ -300,13 +313,15 @@ __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* 
 #pragma unroll
   for (int j = 0; j < 16; ++j) buf[0][j] = primed[j];   // env 0's state: requested by the caller (prime_state_perm)
   prefetch(buf[0], hreg[0], 0, false);
-  for (int base = 0; base < nvalid; base += 2) {
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+  for (int j = 1; j < NB - 1; ++j) prefetch(buf[j], hreg[j], j);
+  for (int base = 0; base < nvalid; base += NB) {
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
       const int e = min(base + jb, nvalid - 1);
       const bool live = base + jb < nvalid;
       float4 (&s)[16] = buf[jb];
-      prefetch(buf[jb ^ 1], hreg[jb ^ 1], base + jb + 1);
+      prefetch(buf[(jb + NB - 1) % NB], hreg[(jb + NB - 1) % NB], base + jb + NB - 1);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int t = 0; t < NA; ++t)
@@ -336,7 +351,7 @@ __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* 
       if (live) {
         float* Se = S0 + (long)(env0 + e) * 4096;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) st4nt(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4, s[j]);
+        for (int j = 0; j < 16; ++j) XSTORE(Se + (16 * (j >> 2) + 4 * kq + (j & 3)) * 64 + c4, s[j]);
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) { s[j].x *= kappa; s[j].y *= kappa; s[j].z *= kappa; s[j].w *= kappa; }
@@ -471,6 +486,15 @@ __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const R
 #define MAGPO_ACT_PRIME 0
 #endif
 constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
+#ifndef MAGPO_ACT_NBUF_ENC
+#define MAGPO_ACT_NBUF_ENC MAGPO_ACT_NBUF16
+#endif
+#ifndef MAGPO_ACT_NBUF_PRE
+#define MAGPO_ACT_NBUF_PRE MAGPO_ACT_NBUF16
+#endif
+#ifndef MAGPO_ACT_NBUF_CAND
+#define MAGPO_ACT_NBUF_CAND 2
+#endif
 
 template <int EPW, int NA, int NH>
 __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
@@ -534,7 +558,7 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
     }
     wsync();
     PROF(0);
-    if (b == 0) ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH, MAGPO_ACT_PRIME != 0>(TQ, HK, U, a.S_enc, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask, nullptr, 0, 0, pS);
+    if (b == 0) ret_pass<0, NA, (EPW == 16 ? MAGPO_ACT_NBUF_ENC : 2), NH, MAGPO_ACT_PRIME != 0>(TQ, HK, U, a.S_enc, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask, nullptr, 0, 0, pS);
     else ret_pass<0, NA, (EPW == 16 ? ACT_NBUF16 : 2), NH>(TQ, HK, U, a.S_enc + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, a.qkvg, 256, 0, a.u, AE, B.gn_g, B.gn_b, a.value_only ? 0 : 1, dmask);
     // the first cross-retention state of the decoder pre-pass rides along with the encoder's post-retention dense phase
     if (MAGPO_ACT_PRIME && b == nb - 1 && !a.value_only) prime_state(pS, a.S_d2 + (long)env0 * 4096, lane);
@@ -589,7 +613,7 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
     float4 pS1[16];   // block 0, one head: the first self-retention state of the candidate pass
-    if (b == 0) ret_pass<4, NA, NBF, NH, MAGPO_ACT_PRIME != 0>(TQ, HK, U, a.S_d2, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
+    if (b == 0) ret_pass<4, NA, (EPW == 16 ? MAGPO_ACT_NBUF_PRE : 2), NH, MAGPO_ACT_PRIME != 0>(TQ, HK, U, a.S_d2, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
                                                B.q2, AE, a.pending, pS);
     else ret_pass<4, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
                                   B.q2, AE, a.pending);
@@ -607,7 +631,7 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
           const int c = min(16 * mt + env, a.K);                                                                               \
           xq[mt] = dense64(row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq), B.qkvg1_t, nullptr, m, kq); \
         }                                                                                                                      \
-        self_prepass_cand<NA, MT_>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask, pS1);                                 \
+        self_prepass_cand<NA, MT_, (EPW == 16 ? MAGPO_ACT_NBUF_CAND : 2)>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask, pS1);                                 \
       }
       if (ntile == 1) CAND_ROWS(1) else if (ntile == 2) CAND_ROWS(2) else CAND_ROWS(3)
 #undef CAND_ROWS
