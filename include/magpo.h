@@ -222,9 +222,10 @@ int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int
 /* ---- K3/K8 GRU actor (base.py:121-184; flax GRUCell) ----
  * gates [R][512] is an opaque save-for-backward buffer written by magpo_gru_scan_fwd and read by magpo_gru_scan_bwd
  * ((r, z, n, h W_hn + b_hn) interleaved per hidden column).
- * Per-call tuning: split_bf16 -- the TRAINING scans (T > 1 with all save buffers) on 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA (x = hi + lo in
- * bf16, product = hi*hi + hi*lo + lo*hi with fp32 accumulation, ~2^-16 relative per product); forward and backward of one pass take the same
- * value.  block_rows -- recurrent rows per workgroup of the fp32 scans: 0 = by size (32 when 64-row blocks would leave half of the compute
+ * Per-call tuning: split_bf16 -- the TRAINING scans (T > 1 with all save buffers) on 0 = fp32 MFMA; 1 = bf16 pairs (x = hi + lo, product =
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation, ~2^-16 relative per product; forward and backward); 2 = bf16 triples (x = hi + mid + lo: the 24
+ * mantissa bits of an fp32 operand, six products hh hm mh hl lh mm = 6/16 of the fp32 MFMA time at fp32 accuracy; forward scan, the backward --
+ * bound by its gate / gradient traffic -- stays on fp32 MFMA).  Forward and backward of one pass take the same value.  block_rows -- recurrent rows per workgroup of the fp32 scans: 0 = by size (32 when 64-row blocks would leave half of the compute
  * units idle), or 32 / 64 forced.
  * xi_cls (nullable): xi is a table over the distinct input rows and token row r takes xi[xi_cls[r]] (csrc/classtab.hip). */
 int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, const float* h0, const int* h0_idx,

@@ -211,17 +211,28 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(x - (float)hi);
 }
 
-template <bool FULL>
+// NP = pieces per operand: 2 (x = hi + lo, 16 mantissa bits, products hh + hl + lh) or 3 (x = hi + mid + lo, 24 mantissa bits -- what an
+// fp32 operand holds -- products hh + hm + mh + hl + lh + mm on the same instruction: 6/16 of the fp32 MFMA time at fp32 accuracy; the dropped
+// products ml, lm, ll are below 2^-24 of the result).
+template <int NP> __device__ __forceinline__ void split_pieces(float x, __bf16 (&p)[NP]) {
+  p[0] = (__bf16)x;
+  float r = x - (float)p[0];
+  p[1] = (__bf16)r;
+  if (NP == 3) { r -= (float)p[1]; p[2] = (__bf16)r; }
+}
+
+template <bool FULL, int NP>
 __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd_bf3(GruArgs a, int block0) {
-  __shared__ __align__(16) float hf[64 * HP];            // fp32 state (carry term), updated in place by the lane that owns the element
-  __shared__ __align__(16) __bf16 hsp[2][2][64 * HB];    // [buffer][hi | lo][row][k] MFMA A operand
-  extern __shared__ unsigned char rflag[];               // [64][T] reset flags, then (xi_cls) [64][T] int xi rows
+  constexpr int ROWS = NP == 3 ? 32 : 64;   // recurrent rows per workgroup: three pieces double-buffered for 64 rows would not fit the 160 KB of LDS
+  __shared__ __align__(16) float hf[ROWS * HP];            // fp32 state (carry term), updated in place by the lane that owns the element
+  __shared__ __align__(16) __bf16 hsp[2][NP][ROWS * HB];   // [buffer][piece][row][k] MFMA A operand
+  extern __shared__ unsigned char rflag[];                 // [ROWS][T] reset flags, then (xi_cls) [ROWS][T] int xi rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
-  const int rho0 = (block0 + blockIdx.x) * 64;
+  const int rho0 = (block0 + blockIdx.x) * ROWS;
   const int col = 32 * wave + lr;
   const int T = a.T;
   // B fragments: gate g, k-step s: k = 64 h + 8 s + j (j = 0..7), column col
-  bf16x8 whi[3][8], wlo[3][8];
+  bf16x8 wp[NP][3][8];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -230,23 +241,28 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd_bf3(GruArgs a, int bloc
       const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
       const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { __bf16 hi, lo; split_bf16(wv[j], hi, lo); whi[g][s8][j] = hi; wlo[g][s8][j] = lo; }
+      for (int j = 0; j < 8; ++j) {
+        __bf16 pc[NP];
+        split_pieces<NP>(wv[j], pc);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) wp[q][g][s8][j] = pc[q];
+      }
     }
   const float bhn = a.b_hn[col];
-  for (int i = tid; i < 64 * T; i += 256) {
+  for (int i = tid; i < ROWS * T; i += 256) {
     const int rl = i / T, t = i - rl * T;
     const int rho = min(rho0 + rl, a.NR - 1);
     rflag[i] = a.reset[(long)(rho / a.A) * T + t];
   }
-  int* ctab = reinterpret_cast<int*>(rflag + 64 * T);
+  int* ctab = reinterpret_cast<int*>(rflag + ROWS * T);
   const bool by_cls = a.xi_cls != nullptr;
   if (by_cls) {
-    for (int i = tid; i < 64 * T; i += 256) {
+    for (int i = tid; i < ROWS * T; i += 256) {
       const int rl = i / T, t = i - rl * T;
       ctab[i] = a.xi_cls[tok_row(min(rho0 + rl, a.NR - 1), t, T, a.A)];
     }
   }
-  for (int i = tid; i < 64 * (H / 4); i += 256) {   // initial carry (with the reset of step 0 applied)
+  for (int i = tid; i < ROWS * (H / 4); i += 256) {   // initial carry (with the reset of step 0 applied)
     const int r = i / (H / 4), c4 = i - r * (H / 4);
     const int rho = rho0 + r;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -257,18 +273,20 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd_bf3(GruArgs a, int bloc
     *reinterpret_cast<float4*>(&hf[r * HP + 4 * c4]) = v;
     const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { __bf16 hi, lo; split_bf16(vv[j], hi, lo); hsp[0][0][r * HB + 4 * c4 + j] = hi; hsp[0][1][r * HB + 4 * c4 + j] = lo; }
+    for (int j = 0; j < 4; ++j) {
+      __bf16 pc[NP];
+      split_pieces<NP>(vv[j], pc);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) hsp[0][q][r * HB + 4 * c4 + j] = pc[q];
+    }
   }
-  __shared__ long rbase[64];
-  if (tid < 64) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
+  __shared__ long rbase[ROWS];
+  if (tid < ROWS) rbase[tid] = tok_row(min(rho0 + tid, a.NR - 1), 0, T, a.A);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
-    const __bf16* ahi = hsp[t & 1][0];
-    const __bf16* alo = hsp[t & 1][1];
-    __bf16* nhi = hsp[(t + 1) & 1][0];
-    __bf16* nlo = hsp[(t + 1) & 1][1];
+    const int cur = t & 1, nxt = (t + 1) & 1;
 #pragma unroll
-    for (int wr = 0; wr < 2; ++wr) {
+    for (int wr = 0; wr < ROWS / 32; ++wr) {
       float xr[16], xz[16], xn[16];
       long rowi[16];
 #pragma unroll
@@ -294,17 +312,18 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd_bf3(GruArgs a, int bloc
       const int aoff = (32 * wr + lr) * HB + 64 * h;
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ahi + aoff + 8 * s8);
-        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(alo + aoff + 8 * s8);
-        ar = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, whi[0][s8], ar, 0, 0, 0);
-        az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, whi[1][s8], az, 0, 0, 0);
-        an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, whi[2][s8], an, 0, 0, 0);
-        ar = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo[0][s8], ar, 0, 0, 0);
-        az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo[1][s8], az, 0, 0, 0);
-        an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wlo[2][s8], an, 0, 0, 0);
-        ar = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, whi[0][s8], ar, 0, 0, 0);
-        az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, whi[1][s8], az, 0, 0, 0);
-        an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, whi[2][s8], an, 0, 0, 0);
+        bf16x8 xp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) xp[q] = *reinterpret_cast<const bf16x8*>(&hsp[cur][q][aoff + 8 * s8]);
+        // products in decreasing order of magnitude: (0,0) (0,1) (1,0) [(0,2) (2,0) (1,1)]
+#pragma unroll
+        for (int pr = 0; pr < (NP == 3 ? 6 : 3); ++pr) {
+          const int qa = pr == 0 ? 0 : (pr == 1 ? 0 : (pr == 2 ? 1 : (pr == 3 ? 0 : (pr == 4 ? 2 : 1))));
+          const int qb = pr == 0 ? 0 : (pr == 1 ? 1 : (pr == 2 ? 0 : (pr == 3 ? 2 : (pr == 4 ? 0 : 1))));
+          ar = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[qa], wp[qb][0][s8], ar, 0, 0, 0);
+          az = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[qa], wp[qb][1][s8], az, 0, 0, 0);
+          an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[qa], wp[qb][2][s8], an, 0, 0, 0);
+        }
       }
       const bool more = t + 1 < T;
 #pragma unroll
@@ -324,10 +343,10 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd_bf3(GruArgs a, int bloc
         }
         const float nx = (more & (rf[i] != 0)) ? 0.f : hn_new;
         hf[rl * HP + col] = nx;
-        __bf16 hi, lo;
-        split_bf16(nx, hi, lo);
-        nhi[rl * HB + col] = hi;
-        nlo[rl * HB + col] = lo;
+        __bf16 pc[NP];
+        split_pieces<NP>(nx, pc);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) hsp[nxt][q][rl * HB + col] = pc[q];
       }
     }
     __syncthreads();
@@ -678,13 +697,14 @@ __global__ __launch_bounds__(256) void k_small_linear128(const float* __restrict
 using namespace magpo;
 
 // Per-call tuning arguments (no library state):
-//   split_bf16  the TRAINING scans (T > 1 with all save buffers) on 0 = fp32 MFMA, 1 = split-bf16 x3 MFMA; forward and backward of one
-//               pass must be given the same value;
+//   split_bf16  the TRAINING scans (T > 1 with all save buffers) on 0 = fp32 MFMA, 1 = bf16 pairs (16 mantissa bits, 3 products, forward and
+//               backward), 2 = bf16 triples (24 mantissa bits = fp32 operands, 6 products; forward scan only, the backward stays on fp32 MFMA:
+//               it is bound by its gate / gradient traffic);
 //   block_rows  recurrent rows per workgroup of the fp32 scans: 0 = by size (32 when 64-row blocks would occupy at most half of the compute
 //               units: the scan is a latency chain of T steps whose step time follows the block's rows), or 32 / 64 forced.
 static int check_gru_tuning(int split_bf16, int block_rows) {
-  if ((split_bf16 != 0 && split_bf16 != 1) || (block_rows != 0 && block_rows != 32 && block_rows != 64)) {
-    set_error("gru: split_bf16 must be 0 / 1, block_rows 0 / 32 / 64");
+  if (split_bf16 < 0 || split_bf16 > 2 || (block_rows != 0 && block_rows != 32 && block_rows != 64)) {
+    set_error("gru: split_bf16 must be 0 / 1 / 2, block_rows 0 / 32 / 64");
     return MAGPO_EINVAL;
   }
   return MAGPO_OK;
@@ -706,15 +726,23 @@ extern "C" int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float
   if (lds > (xi_cls ? 80 : 24) * 1024) { set_error("magpo_gru_scan_fwd: T too large for the LDS tables"); return MAGPO_EINVAL; }
   const int nfull = a.NR / 64;
   const bool split = split_bf16 != 0;
-  if (hs && gates && hprev && split && T > 1) {   // training scan on split-bf16 x3 MFMA (see k_gru_scan_fwd_bf3)
-    static size_t lf_set = 0;
+  if (hs && gates && hprev && split && T > 1) {   // training scan on bf16 MFMA with split operands (see k_gru_scan_fwd_bf3)
+    static size_t lf_set = 0;   // (memoised device attribute: idempotent)
     if (lds > lf_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_scan_fwd_bf3<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       lf_set = lds;
     }
-    if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<true>), dim3(nfull), dim3(256), lds, st, a, 0);
-    if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<false>), dim3(1), dim3(256), lds, st, a, nfull);
+    if (split_bf16 == 2) {   // 32-row blocks
+      const int nf = a.NR / 32;
+      if (nf) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<true, 3>), dim3(nf), dim3(256), lds / 2, st, a, 0);
+      if (a.NR % 32) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<false, 3>), dim3(1), dim3(256), lds / 2, st, a, nf);
+    } else {
+      if (nfull) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<true, 2>), dim3(nfull), dim3(256), lds, st, a, 0);
+      if (a.NR % 64) hipLaunchKernelGGL((k_gru_scan_fwd_bf3<false, 2>), dim3(1), dim3(256), lds, st, a, nfull);
+    }
   } else if (hs && gates && hprev) {
     if (gru_half_blocks(a.NR, block_rows)) {
       const int nf = a.NR / 32;
@@ -771,7 +799,7 @@ extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const 
     lds_set = lds;
   }
   const int nfull = a.NR / 64;
-  if (split_bf16) {   // split-bf16 x3 MFMA (k_gru_scan_bwd_bf3): fp32 dht + two bf16 dhh tiles + flags
+  if (split_bf16 == 1) {   // bf16 pairs (k_gru_scan_bwd_bf3): fp32 dht + two bf16 dhh tiles + flags
     const size_t ldb = (size_t)64 * HP * sizeof(float) + (size_t)2 * 64 * G3B * sizeof(__bf16) + (size_t)64 * T;
     static size_t ldb_set = 0;
     if (ldb > ldb_set) {

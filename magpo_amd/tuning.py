@@ -7,7 +7,8 @@ can run under different settings and a forward / backward pair can never see dif
 
 Environment variables are read HERE, once, when the default instance is built (A/B measurements from the shell):
     MAGPO_RET_CHUNK=64          retention chunk kernels on 64-token chunks (default 32)
-    MAGPO_GRU_SPLIT_BF16=1      GRU training scans on split-bf16 x3 MFMA (default exact fp32 MFMA)
+    MAGPO_GRU_SPLIT_BF16=1|2    GRU training scans on bf16 MFMA with split operands: 1 = pairs (16 mantissa bits), 2 = triples (24 bits = fp32 operands,
+                                forward scan); default 0 = fp32 MFMA
     MAGPO_GRU_BLOCK_ROWS=32|64  recurrent rows per workgroup of the fp32 GRU scans (default: by size)
     MAGPO_LINEAR_LDS=0          wave-autonomous dense kernels instead of the shared-tile ones (MAGPO_LINEAR_LDS64=0: KIN = 64 only)
     MAGPO_WGRAD_FULL=0 / MAGPO_WGRAD_FULL_X=0 / MAGPO_WGRAD_PAD0=0 / MAGPO_WGRAD_G2=1 / MAGPO_WGRAD_GALT=1|2|3
@@ -35,7 +36,7 @@ class Tuning:
         on = lambda name: e.get(name) is not None and int(e[name]) != 0
         t = cls()
         t.ret_chunk_tokens = 64 if e.get("MAGPO_RET_CHUNK") == "64" else 0
-        t.gru_split_bf16 = 1 if on("MAGPO_GRU_SPLIT_BF16") else 0
+        t.gru_split_bf16 = int(e["MAGPO_GRU_SPLIT_BF16"]) if e.get("MAGPO_GRU_SPLIT_BF16") in ("1", "2") else 0
         t.gru_block_rows = int(e.get("MAGPO_GRU_BLOCK_ROWS", 0)) if e.get("MAGPO_GRU_BLOCK_ROWS") in ("32", "64") else 0
         t.linear_variant = (1 if off("MAGPO_LINEAR_LDS") else 0) | (2 if off("MAGPO_LINEAR_LDS64") else 0)
         t.wgrad_variant = ((1 if off("MAGPO_WGRAD_FULL") else 0) | (2 if off("MAGPO_WGRAD_FULL_X") else 0) | (4 if off("MAGPO_WGRAD_PAD0") else 0)
