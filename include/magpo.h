@@ -157,7 +157,7 @@ int magpo_obsnorm_grid(long R);
 int magpo_obsnorm_fwd(const float* obs, long ldo, int F, const float* s_obs, float* on, long R, magpo_stream_t stream);
 int magpo_obsnorm_bwd(const float* obs, long ldo, int F, const float* don, float* slab_s, long R, magpo_stream_t stream);
 int magpo_add_pe(const float* x, long ldx, const float* pe, const int* pos, long pos_stride, int npos, float* out,
-                 long ldout, long R, magpo_stream_t stream);
+                 long ldout, long R, int E, magpo_stream_t stream);
 int magpo_relu_bwd(const float* act, const float* dy, float* dx, long n, magpo_stream_t stream);
 int magpo_add_inplace(float* dst, const float* src, long n, magpo_stream_t stream);
 /* dst[r][0..W) += src[r][0..W) over R rows (row strides ldd / lds): the partial sums of the blockwise 128-wide retention head */

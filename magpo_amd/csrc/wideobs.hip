@@ -3,7 +3,7 @@
 //   k_obsnorm_fwd   on[r][f] = obs[r][f] * rsqrt(mean_{f < F} obs[r]^2 + eps) * s_obs[f]   (nn.RMSNorm over the F features,
 //                   sable_network.py:93-95), columns F..127 written as zeros
 //   k_obsnorm_bwd   slab_s[g][f] = sum_r don[r][f] * obs[r][f] * rstd_r   (gradient of s_obs; the observation needs none)
-//   k_add_pe        out[r] = x[r] + pe[clamp(pos[r])]   (64-wide rows)
+//   k_add_pe        out[r] = x[r] + pe[clamp(pos[r])]   (E-wide rows, E = 64 or 128)
 #include "common.hpp"
 
 namespace magpo {
@@ -61,14 +61,15 @@ __global__ __launch_bounds__(256) void k_obsnorm_bwd(const float* __restrict__ o
 }
 
 __global__ __launch_bounds__(256) void k_add_pe(const float* __restrict__ x, long ldx, const float* __restrict__ pe, const int* __restrict__ pos,
-                                                long pos_stride, int npos, float* __restrict__ out, long ldout, long R) {
+                                                long pos_stride, int npos, float* __restrict__ out, long ldout, long R, int E) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long row = i >> 4;
+  const int w4 = E >> 2;
+  const long row = i / w4;
   if (row >= R) return;
-  const int c4 = 4 * (int)(i & 15);
+  const int c4 = 4 * (int)(i - row * w4);
   int p = pos[row * pos_stride];
   p = p < 0 ? 0 : (p >= npos ? npos - 1 : p);
-  const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c4), b = *reinterpret_cast<const float4*>(pe + (long)p * 64 + c4);
+  const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c4), b = *reinterpret_cast<const float4*>(pe + (long)p * E + c4);
   *reinterpret_cast<float4*>(out + row * ldout + c4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
@@ -99,8 +100,9 @@ extern "C" int magpo_obsnorm_bwd(const float* obs, long ldo, int F, const float*
 }
 
 extern "C" int magpo_add_pe(const float* x, long ldx, const float* pe, const int* pos, long pos_stride, int npos, float* out, long ldout,
-                            long R, hipStream_t st) {
+                            long R, int E, hipStream_t st) {
+  if (E != 64 && E != 128) { set_error("magpo_add_pe: the row width must be 64 or 128"); return MAGPO_EINVAL; }
   if (R <= 0) return MAGPO_OK;
-  hipLaunchKernelGGL(k_add_pe, dim3((unsigned)((R * 16 + 255) / 256)), dim3(256), 0, st, x, ldx, pe, pos, pos_stride, npos, out, ldout, R);
+  hipLaunchKernelGGL(k_add_pe, dim3((unsigned)((R * (E / 4) + 255) / 256)), dim3(256), 0, st, x, ldx, pe, pos, pos_stride, npos, out, ldout, R, E);
   return check_launch("magpo_add_pe");
 }

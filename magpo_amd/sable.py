@@ -539,7 +539,7 @@ class SableGuider:
             L.call("magpo_obsnorm_fwd", obs, self.Fld, F, v["enc.obs.norm.scale"], on, R, st)
             self.lin(on, 128, self.wt["wobs"], None, z0, E, R, 128, E)
             L.call("magpo_headmid_fwd", z0, E, v["enc.ln.scale"], g("xn0"), E, None, None, None, 0, R, E, st)
-            L.call("magpo_add_pe", g("xn0"), E, self.pe, pos, 1, self.npos, g("kin0"), E, R, st)
+            L.call("magpo_add_pe", g("xn0"), E, self.pe, pos, 1, self.npos, g("kin0"), E, R, E, st)
         else:
             L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
                    self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, E, st)   # z is recomputed by the backward
