@@ -24,10 +24,10 @@ TUNED = {
     "3x30-50": dict(M=4, mgn=0.5, E=64, P=15, clip=0.1, dsf=1.0, nh=1, ent=0.01, nb=1, lr=0.0005, alpha=8, delta=1.2),
     "5x20-80": dict(M=8, mgn=0.5, E=64, P=15, clip=0.2, dsf=0.5, nh=2, ent=0.01, nb=2, lr=0.0005, alpha=4, delta=1.1),
     "8x15-100": dict(M=8, mgn=0.5, E=64, P=15, clip=0.2, dsf=1.0, nh=1, ent=0.01, nb=2, lr=0.001, alpha=8, delta=1.3),
-    # params.csv:88,98 (LBF rows; lr = actor_lr column) and :83 (RWARE tiny-4ag: its n_embd = 128 is not built, 64 is used instead)
+    # params.csv:88,98 (LBF rows; lr = actor_lr column) and :83 (RWARE tiny-4ag: n_embd 128, n_head 2, n_block 3)
     "8x8-2p-2f-coop": dict(env="lbf", M=4, mgn=10, E=32, P=15, clip=0.2, dsf=0.3, nh=4, ent=0.001, nb=2, lr=0.00025, alpha=2, delta=1.5),
     "2s-8x8-2p-2f-coop": dict(env="lbf", M=4, mgn=0.5, E=32, P=5, clip=0.2, dsf=0.3, nh=4, ent=0.001, nb=2, lr=0.0005, alpha=2, delta=1.5),
-    "tiny-4ag": dict(env="rware", M=2, mgn=0.5, E=64, P=5, clip=0.2, dsf=0.5, nh=2, ent=0.01, nb=3, lr=0.0005, alpha=8, delta=1.3),
+    "tiny-4ag": dict(env="rware", M=2, mgn=0.5, E=128, P=5, clip=0.2, dsf=0.5, nh=2, ent=0.01, nb=3, lr=0.0005, alpha=8, delta=1.3),
 }
 
 
