@@ -52,6 +52,13 @@ class GruActor:
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
 
+    def bind_grads(self, grads: torch.Tensor) -> None:
+        """Make ``grads`` (flat, P.numel floats, e.g. a slice of the learner's all-reduce message) the gradient buffer."""
+        assert grads.numel() == self.P.numel
+        self.grads = grads
+        self.gv = self.P.views(self.grads)
+        self.named_grads = actor_named_views(self.gv)
+
     def load_named(self, params):
         with torch.no_grad():
             for n, v in self.named.items():
@@ -214,3 +221,6 @@ class GruActor:
         L.call("magpo_reduce_slabs", sw[:, 32 * H:], gv["pre.bias"], grid, H, 33 * H, 1.0, 0, st)
         if self.overlap_wgrad and self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+
+GruActor.apply = GruActor.seq_fwd   # actor_network.apply (rec_magpo.py:631): the scanned training forward (its backward: seq_bwd)

@@ -53,6 +53,13 @@ def shard_env_keys(total_keys: torch.Tensor, num_envs: int, rank: int) -> torch.
     return total_keys[1 + rank * num_envs: 1 + (rank + 1) * num_envs]
 
 
+def rank_world():
+    """(rank, world size) of the initialised process group, (0, 1) for a single process."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -261,9 +261,12 @@ class EnvGroup:
 class MagpoLearner:
     def __init__(self, env_cfg, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
                  decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 512, num_groups: int = 1,
-                 n_block: int = 1, n_head: int = 1, embed_dim: int = 64, tuning=None):
+                 n_block: int = 1, n_head: int = 1, embed_dim: int = 64, tuning=None, guider: Optional[SableGuider] = None,
+                 actor: Optional[GruActor] = None, optims=None):
+        """``guider`` / ``actor`` / ``optims`` = (guider ClipAdam, actor ClipAdam): networks and optimisers built by the caller
+        (rec_magpo.learner_setup hands them to get_learner_fn as its apply / update functions); by default the learner builds its own."""
         from .tuning import Tuning
-        self.tuning = tuning if tuning is not None else Tuning.from_env()   # ONE object shared by both networks (tuning.py)
+        self.tuning = tuning if tuning is not None else (guider.tuning if guider is not None else Tuning.from_env())   # ONE object shared by both networks (tuning.py)
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
         F = env_cfg.obs_dim  # with the AgentIDWrapper's one-hot id (observation.py:42-54), add_agent_id: True
@@ -273,18 +276,30 @@ class MagpoLearner:
             raise ValueError("num_envs must be divisible by num_minibatches")
         self.L = lib()
         # one contiguous buffer [guider grads | actor grads | loss scalars] = one all-reduce message (rec_magpo.py:395-409)
+        from .optim import ClipAdam
         from .params import FlatParams, actor_layout, guider_layout
+        if guider is not None:
+            n_block, n_head, embed_dim = guider.nb, guider.nh, guider.EL
         self.nb, self.nh = int(n_block), int(n_head)
         gn = FlatParams(guider_layout(int(embed_dim), F, K, self.nb, self.nh), "cpu").numel
         an = FlatParams(actor_layout(F, 128, K), "cpu").numel
         self.grad_all = torch.zeros(gn + an + 16, dtype=torch.float32, device=device)
         self.grad_acc = torch.zeros_like(self.grad_all) if num_groups > 1 else None
         self.grad_mu = torch.zeros_like(self.grad_all) if sys.micro_batches > 1 else None
-        self.guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
-                                  max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh, embed_dim=int(embed_dim),
-                                  seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn], tuning=self.tuning)
-        self.actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
-                              grads=self.grad_all[gn:gn + an], tuning=self.tuning)
+        if guider is None:
+            guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
+                                 max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh, embed_dim=int(embed_dim),
+                                 seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn], tuning=self.tuning)
+        else:
+            guider.bind_grads(self.grad_all[:gn])
+        if actor is None:
+            actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
+                             grads=self.grad_all[gn:gn + an], tuning=self.tuning)
+        else:
+            actor.bind_grads(self.grad_all[gn:gn + an])
+        self.guider, self.actor = guider, actor
+        self.g_opt, self.a_opt = optims if optims is not None else (ClipAdam(guider, sys), ClipAdam(actor, sys))
+        assert self.g_opt.net is guider and self.a_opt.net is actor
         self.loss_out = self.grad_all[gn + an:gn + an + 9]
         self.nt = self.guider.ntile
         self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb, self.nt) for _ in range(num_groups)]
@@ -297,11 +312,7 @@ class MagpoLearner:
             g.prev_sable_hs = tuple(t[:, :, gi * N_:(gi + 1) * N_] for t in self._prev_hs)
             g.policy_h0 = self._policy_h0[gi * N_ * A:(gi + 1) * N_ * A]
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
-        # optimiser state (optax adam: count, mu, nu)
-        self.g_mu, self.g_nu = torch.zeros_like(self.guider.P.flat), torch.zeros_like(self.guider.P.flat)
-        self.a_mu, self.a_nu = torch.zeros_like(self.actor.P.flat), torch.zeros_like(self.actor.P.flat)
-        self.g_count = 0
-        self.a_count = 0
+        # optimiser state (optax adam: count, mu, nu) lives in the two ClipAdam objects: g_mu / g_nu / g_count ... below are views of it
         self.ws64 = torch.zeros(8 * 1024, dtype=torch.float64, device=device)
         self.gnorm = f32(2)
         self.adv_stats = f32(2)
@@ -315,6 +326,13 @@ class MagpoLearner:
         # the actor's forward / backward run on a second HIP stream next to the guider's (independent until the loss)
         self.overlap_actor = False  # opt-in (bench.py --overlap): ~3 %, but per-kernel timings then include contention
         self._actor_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+
+    g_mu = property(lambda self: self.g_opt.mu)
+    g_nu = property(lambda self: self.g_opt.nu)
+    a_mu = property(lambda self: self.a_opt.mu)
+    a_nu = property(lambda self: self.a_opt.nu)
+    g_count = property(lambda self: self.g_opt.count, lambda self, v: setattr(self.g_opt, "count", int(v)))
+    a_count = property(lambda self: self.a_opt.count, lambda self, v: setattr(self.a_opt, "count", int(v)))
 
     # group-0 shortcuts (single-group callers and the parity tests)
     env = property(lambda self: self.groups[0].env)
@@ -657,23 +675,9 @@ class MagpoLearner:
             self.actor.seq_bwd(m["da"])
 
     def apply_grads(self, grad_scale: float = 1.0):
-        """optax clip_by_global_norm + adam + apply_updates on both flat buffers (rec_magpo.py:412-420)."""
-        s, st = self.sys, self._st()
-        for net, mu, nu, which in ((self.guider, self.g_mu, self.g_nu, "g"), (self.actor, self.a_mu, self.a_nu, "a")):
-            cnt = (self.g_count if which == "g" else self.a_count) + 1
-            bc1 = float(np.float32(1) - np.float32(0.9) ** np.float32(cnt))
-            bc2 = float(np.float32(1) - np.float32(0.999) ** np.float32(cnt))
-            lr = s.actor_lr
-            if s.decay_learning_rates:
-                lr = s.actor_lr * (1.0 - ((cnt - 1) // (s.ppo_epochs * s.num_minibatches)) / s.lr_num_updates)
-            self.last_lr = lr
-            self.L.call("magpo_clip_adam", net.P.flat, net.grads, mu, nu, net.P.numel, grad_scale, s.max_grad_norm, lr,
-                        0.9, 0.999, 1e-5, bc1, bc2, self.ws64, self.gnorm[0:1] if which == "g" else self.gnorm[1:2], st)
-            if which == "g":
-                self.g_count = cnt
-            else:
-                self.a_count = cnt
-            net.refresh()
+        """optax clip_by_global_norm + adam + apply_updates on both flat buffers (rec_magpo.py:412-420): the two update functions."""
+        self.g_opt.update(grad_scale, self.ws64, self.gnorm[0:1])
+        self.last_lr = self.a_opt.update(grad_scale, self.ws64, self.gnorm[1:2])
 
     # ------------------------------------------------------------------ update (rec_magpo.py:214-487)
     def update(self, grad_sync: Optional[Callable[["MagpoLearner"], float]] = None) -> torch.Tensor:

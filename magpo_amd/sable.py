@@ -121,6 +121,15 @@ class SableGuider:
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
 
+    def bind_grads(self, grads: torch.Tensor) -> None:
+        """Make ``grads`` (a flat fp32 buffer of P.numel floats, e.g. a slice of the learner's all-reduce message) the gradient buffer."""
+        assert grads.numel() == self.P.numel
+        self.grads = grads
+        if self.emb is None:
+            self.grads_D = grads
+        self.gv = self.PD.views(self.grads_D)
+        self.named_grads = guider_named_views(self.P.views(self.grads), self.EL, self.nh)
+
     def check_ffn_zero(self):
         for n, v in self.v.items():
             if ".ffn." in n and bool(v.any().item()):
@@ -473,6 +482,9 @@ class SableGuider:
         self.L.call("magpo_sable_act", dims.ctypes.data, kap.ctypes.data, None if keys is None else keys.ctypes.data,
                     gp.ctypes.data, int(gp.size), bp.ctypes.data, int(bp.size), self._st())
 
+    # the reference's names for the two apply functions of the Sable network (rec_magpo.py:624-628)
+    get_actions = act_fused          # partial(sable_network.apply, method="get_actions"): execution  (apply = train_fwd: end of the file)
+
     def _seg_post(self, tail, r, gp, ldg, gamma, beta, wo_t, res, s1, s2, pos, u, y, o, ope, R, w0_t=None, b0=None, out0=None, ld0=0,
                   hs=None, hw=None, hb1=None, value=None, q2_t=(), q2=(), hn=None, w1_t=None, b1=None, logits=None, rows=None):
         """One fused launch for the token-local part between two retention ops (csrc/seg_fused.hip)."""
@@ -820,3 +832,6 @@ class SableGuider:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         if self.emb is not None:   # gradient of a logical parameter = sum over its tied device copies
             self.emb.fold(self.grads_D, self.grads)
+
+
+SableGuider.apply = SableGuider.train_fwd   # sable_network.apply: the chunkwise training forward (its backward: train_bwd)

@@ -27,6 +27,8 @@ from magpo_amd.actor import GruActor
 from magpo_amd.config import Config, compose
 from magpo_amd.evaluator import get_eval_fn, get_num_eval_envs, make_rec_eval_act_fn
 from magpo_amd.learner import MagpoLearner, SystemConfig, host_split, prng_key
+from magpo_amd.optim import ClipAdam
+from magpo_amd.sable import SableGuider
 from magpo_amd.types import ExperimentOutput, GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
 from magpo_amd.utils import make_env as environments
 from magpo_amd.utils.checkpointing import Checkpointer, latest_valid_checkpoint, load_checkpoint, restore_learner_state
@@ -112,16 +114,29 @@ def load_learner_state(learner: MagpoLearner, state: GPOLearnerState) -> None:
 
 def get_learner_fn(env, apply_fns, update_fn, config):
     """Returns ``learn(learner_state) -> ExperimentOutput``: ``config.system.num_updates_per_eval`` update steps
-    (rec_magpo.py:501-528).  In the reference ``apply_fns`` / ``update_fn`` are the networks' apply functions and the optax
-    update functions; here both roles are played by objects that own HIP kernels and their device buffers: ``apply_fns`` is
-    the MagpoLearner (guider + actor kernels), ``update_fn`` the optional gradient-sync hook (RCCL all-reduce) that runs
-    in front of the fused clip + Adam kernel.
+    (rec_magpo.py:91-530).  Same contract as the reference:
+
+        apply_fns = (sable_action_select_fn, sable_apply_fn, actor_apply_fn)     rec_magpo.py:99   (execution / training / training)
+        update_fn = (sable_update_fn, actor_update_fn)                           rec_magpo.py:100  (the two optimisers' update functions)
+
+    In the reference these are pure functions of parameter pytrees; here they are the bound methods of the objects that own the HIP
+    kernels' device buffers -- ``SableGuider.get_actions`` / ``SableGuider.apply`` / ``GruActor.apply`` and ``ClipAdam.update`` -- so the
+    networks and optimiser states they act on are reached through them (``fn.__self__``), and the learner loop (rollout, GAE, shuffles,
+    both losses, gradient mean over groups / ranks) is composed around them.  ``env``: the MarlEnv whose batched kernels the rollout steps.
 
     State in, state out: the learner's device buffers are a cache of the last state it produced.  When ``learner_state``
     is that state (the normal host loop, rec_magpo.py:754,792) nothing is copied; any other state (an older one, a restored
     checkpoint) is loaded into the buffers first, so ``learn`` is a function of its argument."""
-    learner: MagpoLearner = apply_fns
-    grad_sync = update_fn
+    sable_action_select_fn, sable_apply_fn, actor_apply_fn = apply_fns
+    sable_update_fn, actor_update_fn = update_fn
+    guider, actor = sable_apply_fn.__self__, actor_apply_fn.__self__
+    if sable_action_select_fn.__self__ is not guider:
+        raise ValueError("the execution and the training function must belong to one Sable network")
+    g_opt, a_opt = sable_update_fn.__self__, actor_update_fn.__self__
+    rank, world = mdist.rank_world()
+    U = int(config.system.update_batch_size)
+    learner = MagpoLearner(env.cfg, int(config.arch.num_envs), g_opt.sys, guider.dev, num_groups=U, guider=guider, actor=actor, optims=(g_opt, a_opt))
+    grad_sync = mdist.make_grad_sync(world)   # the pmean over ("batch", "device") of rec_magpo.py:395-409: one all-reduce of the flat buffer
 
     def learner_fn(learner_state: GPOLearnerState) -> ExperimentOutput:
         if learner_state is not getattr(learner, "_live_state", None):
@@ -145,6 +160,7 @@ def get_learner_fn(env, apply_fns, update_fn, config):
         learner._live_state = _snapshot_state(learner)
         return ExperimentOutput(learner._live_state, episode_metrics, train_metrics)
 
+    learner_fn.learner = learner
     return learner_fn
 
 
@@ -167,14 +183,20 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
         raise NotImplementedError("HIP kernels support embed_dim in {16,32,64,128}, n_head in {1,2,4}, hidden_state_dim=128 (any n_block)")
     device = device or torch.device("cuda", torch.cuda.current_device())
     U = int(config.system.update_batch_size)
-    learner = MagpoLearner(env.cfg, int(config.arch.num_envs), _system_config(config), device,
-                           net_seed=int(net_key[1]) & 0x7FFFFFFF, decay_scaling_factor=float(mc.decay_scaling_factor),
-                           use_pe=bool(mc.timestep_positional_encoding), num_groups=U, n_block=int(nc.n_block), n_head=int(nc.n_head),
-                           embed_dim=int(nc.embed_dim))
+    # networks (rec_magpo.py:559-579), optimisers (:581-589) -- objects that own their kernels' device buffers
+    cfg, sysc = env.cfg, _system_config(config)
+    seed = int(net_key[1]) & 0x7FFFFFFF
+    sable_network = SableGuider(cfg.num_agents, cfg.num_actions, cfg.obs_dim, device, embed_dim=int(nc.embed_dim), n_head=int(nc.n_head),
+                                n_block=int(nc.n_block), decay_scaling_factor=float(mc.decay_scaling_factor),
+                                use_pe=bool(mc.timestep_positional_encoding), max_pos=cfg.time_limit + 1, seed=seed)
+    actor_network = GruActor(cfg.num_agents, cfg.num_actions, cfg.obs_dim, device, seed=seed + 1, tuning=sable_network.tuning)
+    guider_optim, actor_optim = ClipAdam(sable_network, sysc), ClipAdam(actor_network, sysc)
+    # Pack apply and update functions (rec_magpo.py:624-632)
+    apply_fns = (sable_network.get_actions, sable_network.apply, actor_network.apply)
+    update_fns = (guider_optim.update, actor_optim.update)
+    learn = get_learner_fn(env, apply_fns, update_fns, config)
+    learner = learn.learner
     learner.setup(key, n_groups=world * U, group=rank * U)
-    grad_sync = mdist.make_grad_sync(world)
-    learn = get_learner_fn(env, learner, grad_sync, config)
-    learn.learner = learner
     learner._live_state = _snapshot_state(learner)
     return learn, learner.actor, learner._live_state
 
