@@ -648,6 +648,8 @@ using namespace magpo;
 // teams of at most 32 agents) or 64 (k_ret_chunk_*).  The forward's saved chunk-entry states and the backward must be given the same value
 // (magpo_retention_num_chunks takes it too).
 static bool ret32(int A, int chunk_tokens) { return chunk_tokens != 64 && A <= 32; }
+// branch-free chunk loop of the 32-token kernels: every chunk full, 64-wide head, all bookkeeping built up front
+static bool ret32_fast(int T, int A, int hs, int nch) { return hs == 64 && 32 % A == 0 && T % (32 / A) == 0 && nch <= MAXC32; }
 static int check_chunk_tokens(int chunk_tokens) {
   if (chunk_tokens != 0 && chunk_tokens != 32 && chunk_tokens != 64) { set_error("retention: chunk_tokens must be 0 (default), 32 or 64"); return MAGPO_EINVAL; }
   return MAGPO_OK;
@@ -670,10 +672,14 @@ extern "C" int magpo_retention_chunk_fwd(const float* q, long ldq, const float* 
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetArgs a{q, k, v, ldq, ldk, ldv, r, ldr, s0, seq_env, dones, states, s_final, T, A, masked, kappa, hs, qkv_rows};
   if (ret32(A, chunk_tokens)) {
-    const size_t lds32 = ret32_fwd_lds(magpo_retention_num_chunks(T, A, chunk_tokens));
-    static size_t attr32 = 0;
-    if (lds32 > attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32 = lds32; }
-    hipLaunchKernelGGL(k_ret32_fwd, dim3(nseq), dim3(256), lds32, st, a);
+    const int nch = magpo_retention_num_chunks(T, A, chunk_tokens);
+    const bool fast = ret32_fast(T, A, hs, nch) && states != nullptr;
+    const size_t lds32 = ret32_fwd_lds(nch);
+    const int v = (fast ? 2 : 0) | (qkv_rows ? 1 : 0);
+    static size_t attr32[4] = {0, 0, 0, 0};
+    void (*const kern[4])(RetArgs) = {k_ret32_fwd<false, false>, k_ret32_fwd<false, true>, k_ret32_fwd<true, false>, k_ret32_fwd<true, true>};
+    if (lds32 > attr32[v]) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern[v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32[v] = lds32; }
+    hipLaunchKernelGGL(kern[v], dim3(nseq), dim3(256), lds32, st, a);
     return check_launch("magpo_retention_chunk_fwd");
   }
   size_t lds = 4 * 64 * TL * sizeof(float) + sizeof(SeqMeta<FWD_MAXC>);
@@ -692,10 +698,14 @@ extern "C" int magpo_retention_chunk_bwd(const float* q, long ldq, const float* 
   if (hs < 4 || hs > 64 || (hs & 3)) { set_error("retention: head width must be a multiple of 4 in [4, 64]"); return MAGPO_EINVAL; }
   RetBwdArgs a{q, k, v, ldq, ldk, ldv, dr, lddr, dq, dk, dv, lddq, lddk, lddv, dones, states, T, A, masked, kappa, hs, qkv_rows};
   if (ret32(A, chunk_tokens)) {
-    const size_t lds32 = ret32_bwd_lds(magpo_retention_num_chunks(T, A, chunk_tokens));
-    static size_t attr32 = 0;
-    if (lds32 > attr32) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ret32_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32 = lds32; }
-    hipLaunchKernelGGL(k_ret32_bwd, dim3(nseq), dim3(256), lds32, st, a);
+    const int nch = magpo_retention_num_chunks(T, A, chunk_tokens);
+    const bool fast = ret32_fast(T, A, hs, nch);
+    const size_t lds32 = ret32_bwd_lds(nch) + ret32_rowtab_bytes(nch, fast && qkv_rows);
+    const int v = (fast ? 2 : 0) | (qkv_rows ? 1 : 0);
+    static size_t attr32[4] = {0, 0, 0, 0};
+    void (*const kern[4])(RetBwdArgs) = {k_ret32_bwd<false, false>, k_ret32_bwd<false, true>, k_ret32_bwd<true, false>, k_ret32_bwd<true, true>};
+    if (lds32 > attr32[v]) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern[v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32); attr32[v] = lds32; }
+    hipLaunchKernelGGL(kern[v], dim3(nseq), dim3(256), lds32, st, a);
     return check_launch("magpo_retention_chunk_bwd");
   }
   size_t lds = 8 * 64 * TL * sizeof(float) + sizeof(SeqMeta<BWD_MAXC>);

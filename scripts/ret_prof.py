@@ -3,6 +3,9 @@ import os
 import sys, os, ctypes, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from magpo_amd import _lib
+if os.environ.get("MAGPO_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["MAGPO_LIB"])
 from magpo_amd._lib import lib
 L = lib()
 CT, SPLIT = int(os.environ.get("MAGPO_RET_CHUNK", 0)), int(os.environ.get("MAGPO_GRU_SPLIT_BF16", 0))   # per-call tuning arguments (the library keeps no state)
