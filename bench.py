@@ -89,9 +89,9 @@ class KernelTimer:
             rows = nseq * T * A
             return "k_gru_scan_fwd<true,0>", 4.0 * rows * (384 + 128 + 512 + 128), 2.0 * rows * 128 * 384
         if name == "magpo_gru_scan_bwd":
-            nseq, T, A = a[8], a[9], a[10]
+            nseq, T, A = a[7], a[8], a[9]
             rows = nseq * T * A
-            return "k_gru_scan_bwd<true>", 4.0 * rows * (512 + 128 + 128 + 768), 2.0 * rows * 384 * 128
+            return "k_gru_scan_bwd<true>", 4.0 * rows * (512 + 128 + 128 + 512), 2.0 * rows * 384 * 128
         if name == "magpo_seg_bwd":
             R = a[0]
             return "k_seg_bwd", 4.0 * R * 64 * 9, 2.0 * R * 64 * 64

@@ -234,8 +234,12 @@ int magpo_gru_scan_fwd(const float* xi, const float* Wht, const float* b_hn, con
 /* hidden-state carry over a TIME-MAJOR trajectory: xi rows (t, env, agent), reset_tm [T][nenv]; writes only the state after step T-1 */
 int magpo_gru_carry(const float* xi, const float* Wht, const float* b_hn, const float* h0, const unsigned char* reset_tm,
                     float* h_last, int nenv, int T, int A, const int* xi_cls, int block_rows, magpo_stream_t stream);
+/* backward scan.  dg [R][512] = the gate pre-activation gradients of every token row as ONE matrix (dn_in | dr | dz | dn_hid): the
+ * gradient of the input projection xi = (r | z | n) is its columns (128..383 | 0..127) and that of the hidden projection h W_h its columns
+ * 128..511 (dr and dz are shared by the two sides and written once; ld 512 either way).  slab_bhn [ceil(nseq A / 64)][128]: per-block
+ * column sums of dn_hid (the b_hn gradient, folded by magpo_reduce_slabs). */
 int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned char* reset, const float* dhs,
-                       const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
+                       const float* Wh, float* dg, float* slab_bhn, int nseq, int T, int A,
                        int split_bf16, int block_rows, magpo_stream_t stream);
 
 /* ---- K2 sampling, K5 GAE, K6 shuffle/layout, K9 losses (decode.py:128-149; multistep.py:24-68; rec_magpo.py:222-370,439-462) ---- */

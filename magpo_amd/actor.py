@@ -9,6 +9,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import contextlib
 import torch
 
 from ._lib import lib
@@ -84,6 +85,20 @@ class GruActor:
         self._tp("wi", v["gru.wi"]); self._tp("wh", v["gru.wh"]); self._tp("post", v["post.kernel"])
         ht = self._tp("head", v["head.kernel"], 64)      # [64][128]
         self._tp("head_nat_pad", ht, H)                   # [128][64]
+        # W_i with its gate columns in the order of the backward scan's gradient matrix (n | r | z), see seq_bwd
+        if "wi_nrz" not in self.wt:
+            self.wt["wi_nrz"] = torch.empty(H, 3 * H, device=self.dev)
+        self._cols_nrz(v["gru.wi"], self.wt["wi_nrz"], H, inverse=True)
+
+    def _cols_nrz(self, src, dst, rows, inverse=False):
+        """[rows, 3H] matrices, gate column blocks (n | r | z) -> (r | z | n) (inverse: the other way), on the current stream."""
+        L, st = self.L, self._st()
+        if inverse:
+            L.call("magpo_copy_rows", src[:, 2 * H:], 3 * H, dst, 3 * H, rows, H, st)
+            L.call("magpo_copy_rows", src, 3 * H, dst[:, H:], 3 * H, rows, 2 * H, st)
+        else:
+            L.call("magpo_copy_rows", src, 3 * H, dst[:, 2 * H:], 3 * H, rows, H, st)
+            L.call("magpo_copy_rows", src[:, H:], 3 * H, dst, 3 * H, rows, 2 * H, st)
 
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self.tuning.linear_variant, self._st())
@@ -108,6 +123,17 @@ class GruActor:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.L.call("magpo_wgrad", X, ldx, dY, ldy, R, KIN, krows or KIN, NOUT, dW, db, self.wg_ws, self._groups(R), 1.0, 0, self.tuning.wgrad_variant, self._st())
+
+    def _wgrad_nrz(self, emb, dg, R, gw, dW, db):
+        """dW_i, db_i from dg's columns 0..3H (gate blocks n | r | z) into W_i's order, on the weight-gradient stream."""
+        side = self.wgrad_stream if self.overlap_wgrad else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            st = self._st()
+            self.L.call("magpo_wgrad", emb, H, dg, 4 * H, R, H, H, 3 * H, gw[:H], gw[H], self.wg_ws, self._groups(R), 1.0, 0, self.tuning.wgrad_variant, st)
+            self._cols_nrz(gw[:H], dW, H)
+            self._cols_nrz(gw[H:], db.view(1, 3 * H), 1)
 
     # one step for N envs: returns new hidden [N*A,128]; logits [N*A,64] if want_logits
     def step(self, obs, h_in, reset_env, h_out, want_logits: bool = False):
@@ -190,30 +216,41 @@ class GruActor:
         self.wgrad(t("hs"), H, dy, H, R, H, H, gv["post.kernel"], gv["post.bias"])
         dhs = b.get("g_dhs", (R, H))
         self.lin(dy, H, v["post.kernel"], None, dhs, H, R, H, H)
-        dxi = b.get("g_dxi", (R, 3 * H)); dhh = b.get("g_dhh", (R, 3 * H))
+        # one gradient matrix for both projections (include/magpo.h): dg = (dn_in | dr | dz | dn_hid); the hidden side is its columns
+        # H..4H in W_h's own gate order, the input side its columns 0..3H in the order (n | r | z)
+        dg = b.get("g_dg", (R, 4 * H))
         nblk = (nseq * A + 63) // 64
         slab = b.get("g_slab", (nblk, H))
-        L.call("magpo_gru_scan_bwd", t("gates"), t("hprev"), dones, dhs, v["gru.wh"], dxi, dhh, slab, nseq, T, A, self.tuning.gru_split_bf16, self.tuning.gru_block_rows, st)
+        L.call("magpo_gru_scan_bwd", t("gates"), t("hprev"), dones, dhs, v["gru.wh"], dg, slab, nseq, T, A, self.tuning.gru_split_bf16, self.tuning.gru_block_rows, st)
         L.call("magpo_reduce_slabs", slab, gv["gru.hn.bias"], nblk, H, H, 1.0, 0, st)
-        self.wgrad(t("hprev"), H, dhh, 3 * H, R, H, 3 * H, gv["gru.wh"])
+        self.wgrad(t("hprev"), H, dg[:, H:], 4 * H, R, H, 3 * H, gv["gru.wh"])
         if sv["classes"] is not None:
-            # input side on the class table: S[c] = sum of dxi over the rows of class c, then the layers' backward on C rows
+            # input side on the class table: S[c] = sum of the rows of class c, gate blocks back into W_i's order on the C rows, then the
+            # layers' backward on C rows
             obs, _, order, offsets = sv["classes"]
             C = obs.shape[0]
-            part = b.get("g_cpart", (L.call("magpo_class_sum_slots", C), C, 3 * H)); dxi_c = b.get("g_dxic", (C, 3 * H))
-            L.call("magpo_class_sum", dxi, 3 * H, order, offsets, C, 3 * H, part, dxi_c, st)
-            emb, dxi, R = b.t["c_embtab"], dxi_c, C
+            part = b.get("g_cpart", (L.call("magpo_class_sum_slots", C), C, 3 * H))
+            s_nrz = b.get("g_dxic_nrz", (C, 3 * H)); dxi = b.get("g_dxic", (C, 3 * H))
+            L.call("magpo_class_sum", dg, 4 * H, order, offsets, C, 3 * H, part, s_nrz, st)
+            self._cols_nrz(s_nrz, dxi, C)
+            emb, R = b.t["c_embtab"], C
+            self.wgrad(emb, H, dxi, 3 * H, R, H, 3 * H, gv["gru.wi"], gv["gru.bi"])
+            ldx, wi_t = 3 * H, v["gru.wi"]
         else:
+            # per token row: weight gradient with its gate blocks in dg's order, put back into W_i's order on the [H, 3H] result; the dX
+            # GEMM contracts over the gates in dg's order against the equally permuted copy of W_i
             emb = t("emb")
-        self.wgrad(emb, H, dxi, 3 * H, R, H, 3 * H, gv["gru.wi"], gv["gru.bi"])
+            gw = b.get("g_gwi_nrz", (H + 1, 3 * H))
+            self._wgrad_nrz(emb, dg, R, gw, gv["gru.wi"], gv["gru.bi"])
+            dxi, ldx, wi_t = dg, 4 * H, self.wt["wi_nrz"]
         demb = b.get("g_demb", (R, H))
         if self.wide:   # ReLU backward fused into the dX GEMM (act 4 takes the mask), then dW_pre = obs^T demb on the dense kernel
-            self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H, act=4, Ypre=emb)
+            self.lin(dxi, ldx, wi_t, None, demb, H, R, 3 * H, H, act=4, Ypre=emb)
             self.wgrad(obs, 128, demb, H, R, 128, H, gv["pre.kernel"], gv["pre.bias"], krows=F)
             if self.overlap_wgrad and self.wgrad_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             return
-        self.lin(dxi, 3 * H, v["gru.wi"], None, demb, H, R, 3 * H, H)
+        self.lin(dxi, ldx, wi_t, None, demb, H, R, 3 * H, H)
         grid = L.call("magpo_row_grid", R)
         sw = b.get("g_slabw", (grid, 33 * H))
         L.call("magpo_small_relu_wgrad", obs, F, F, emb, demb, sw, R, st)

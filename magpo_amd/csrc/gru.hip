@@ -359,8 +359,7 @@ struct GruBwdArgs {
   const unsigned char* reset;
   const float* dhs;       // [R][H] dL/dh_t from the post-torso path
   const float* Wh;        // [H][3H] natural layout (used as "Wt" of dh_prev = dhh @ W_h^T)
-  float* dxi;             // [R][3H]
-  float* dhh;             // [R][3H]
+  float* dg;              // [R][4H] gate pre-activation gradients (dn_in | dr | dz | dn_hid), see magpo.h
   float* slab_bhn;        // [grid][H]
   int T, A, NR;
 };
@@ -433,10 +432,9 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd(GruBwdArgs a, int block
         GRU_BWD_ELEM(x) GRU_BWD_ELEM(y) GRU_BWD_ELEM(z) GRU_BWD_ELEM(w)
 #undef GRU_BWD_ELEM
         if (ok) {
-          float* dx = a.dxi + rowv[k] * G3 + c4;
-          *reinterpret_cast<float4*>(dx) = o_r; *reinterpret_cast<float4*>(dx + H) = o_z; *reinterpret_cast<float4*>(dx + 2 * H) = o_an;
-          float* dq = a.dhh + rowv[k] * G3 + c4;
-          *reinterpret_cast<float4*>(dq) = o_r; *reinterpret_cast<float4*>(dq + H) = o_z; *reinterpret_cast<float4*>(dq + 2 * H) = o_hb;
+          float* dx = a.dg + rowv[k] * (4 * H) + c4;   // (dr, dz are shared by the input and the hidden side: written once)
+          *reinterpret_cast<float4*>(dx) = o_an; *reinterpret_cast<float4*>(dx + H) = o_r; *reinterpret_cast<float4*>(dx + 2 * H) = o_z;
+          *reinterpret_cast<float4*>(dx + 3 * H) = o_hb;
           bacc4.x += o_hb.x; bacc4.y += o_hb.y; bacc4.z += o_hb.z; bacc4.w += o_hb.w;
         }
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -560,10 +558,9 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_bwd_bf3(GruBwdArgs a, int b
         GRU_BWD_ELEM(x) GRU_BWD_ELEM(y) GRU_BWD_ELEM(z) GRU_BWD_ELEM(w)
 #undef GRU_BWD_ELEM
         if (ok) {
-          float* dx = a.dxi + rowv[k] * G3 + c4;
-          *reinterpret_cast<float4*>(dx) = o_r; *reinterpret_cast<float4*>(dx + H) = o_z; *reinterpret_cast<float4*>(dx + 2 * H) = o_an;
-          float* dq = a.dhh + rowv[k] * G3 + c4;
-          *reinterpret_cast<float4*>(dq) = o_r; *reinterpret_cast<float4*>(dq + H) = o_z; *reinterpret_cast<float4*>(dq + 2 * H) = o_hb;
+          float* dx = a.dg + rowv[k] * (4 * H) + c4;   // (dr, dz are shared by the input and the hidden side: written once)
+          *reinterpret_cast<float4*>(dx) = o_an; *reinterpret_cast<float4*>(dx + H) = o_r; *reinterpret_cast<float4*>(dx + 2 * H) = o_z;
+          *reinterpret_cast<float4*>(dx + 3 * H) = o_hb;
           bacc4.x += o_hb.x; bacc4.y += o_hb.y; bacc4.z += o_hb.z; bacc4.w += o_hb.w;
         }
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -783,10 +780,10 @@ extern "C" int magpo_gru_carry(const float* xi, const float* Wht, const float* b
 
 // slab_bhn: [ceil(NR/64)][128]
 extern "C" int magpo_gru_scan_bwd(const float* gates, const float* hprev, const unsigned char* reset, const float* dhs,
-                                  const float* Wh, float* dxi, float* dhh, float* slab_bhn, int nseq, int T, int A,
+                                  const float* Wh, float* dg, float* slab_bhn, int nseq, int T, int A,
                                   int split_bf16, int block_rows, hipStream_t st) {
   if (int e = check_gru_tuning(split_bf16, block_rows)) return e;
-  GruBwdArgs a{gates, hprev, reset, dhs, Wh, dxi, dhh, slab_bhn, T, A, nseq * A};
+  GruBwdArgs a{gates, hprev, reset, dhs, Wh, dg, slab_bhn, T, A, nseq * A};
   if (a.NR <= 0) return MAGPO_OK;
   const size_t lds = (size_t)(64 * HP + 64 * G3P) * sizeof(float) + (size_t)64 * T;
   if (lds > 150 * 1024) { set_error("magpo_gru_scan_bwd: T too large for the LDS flag table"); return MAGPO_EINVAL; }

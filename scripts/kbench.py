@@ -55,8 +55,8 @@ if "gru" in which:
     hs = torch.empty(R, H, device=dev); gates = torch.empty(R, 4 * H, device=dev); hprev = torch.empty(R, H, device=dev)
     timeit("gru_scan_fwd", lambda: L.call("magpo_gru_scan_fwd", xi, Wht, bhn, h0, None, reset, hs, gates, hprev, nseq, T, A, None, SPLIT, 0, st), 2.0 * R * H * 3 * H, 0)
     dhs = torch.randn(R, H, device=dev, generator=g) * 0.1
-    dxi = torch.empty(R, 3 * H, device=dev); dhh = torch.empty(R, 3 * H, device=dev); slab = torch.empty((nseq * A + 63) // 64, H, device=dev)
-    timeit("gru_scan_bwd", lambda: L.call("magpo_gru_scan_bwd", gates, hprev, reset, dhs, Wh, dxi, dhh, slab, nseq, T, A, SPLIT, 0, st), 2.0 * R * H * 3 * H, 0)
+    dg = torch.empty(R, 4 * H, device=dev); slab = torch.empty((nseq * A + 63) // 64, H, device=dev)
+    timeit("gru_scan_bwd", lambda: L.call("magpo_gru_scan_bwd", gates, hprev, reset, dhs, Wh, dg, slab, nseq, T, A, SPLIT, 0, st), 2.0 * R * H * 3 * H, 0)
 if "rows" in which:
     F, K = 5, 20
     obs = torch.randn(R, F, device=dev, generator=g)

@@ -541,16 +541,18 @@ def _gru_scan_case(L, stream, split, rows):
     L.call("magpo_gru_scan_fwd", xi, Wht, dev(p["gru.hn.bias"].detach().float()), dev(h0_store), dev(perm), rs, hsd, gates, hprev,
            nseq, T, A, None, split, rows, stream)
     close(hsd, to_rows(hs), 1e-4, 1e-5, "hs")
-    dxi = torch.empty(R, 3 * H, device=DEV); dhh = torch.empty(R, 3 * H, device=DEV)
+    dg = torch.empty(R, 4 * H, device=DEV)     # (dn_in | dr | dz | dn_hid), include/magpo.h
     nblk = (nseq * A + 63) // 64
     slab = torch.zeros(nblk, H, device=DEV)
-    L.call("magpo_gru_scan_bwd", gates, hprev, rs, dev(to_rows(dhs)), dev(Wh), dxi, dhh, slab, nseq, T, A, split, rows, stream)
+    L.call("magpo_gru_scan_bwd", gates, hprev, rs, dev(to_rows(dhs)), dev(Wh), dg, slab, nseq, T, A, split, rows, stream)
+    dxi = torch.cat([dg[:, H:3 * H], dg[:, :H]], 1).contiguous()     # input side in W_i's gate order (r | z | n)
+    dhh = dg[:, H:]                                                  # hidden side (r | z | n), ld 4H
     # check through the parameter gradients
     G = 3
     ws = torch.empty(L.call("magpo_wgrad_workspace_floats", H, 3 * H, G), device=DEV)
     dWi = torch.zeros(H, 3 * H, device=DEV); dbi = torch.zeros(3 * H, device=DEV); dWh = torch.zeros(H, 3 * H, device=DEV)
     L.call("magpo_wgrad", dev(to_rows(emb)), H, dxi, 3 * H, R, H, H, 3 * H, dWi, dbi, ws, G, 1.0, 0, 0, stream)
-    L.call("magpo_wgrad", hprev, H, dhh, 3 * H, R, H, H, 3 * H, dWh, None, ws, G, 1.0, 0, 0, stream)
+    L.call("magpo_wgrad", hprev, H, dhh, 4 * H, R, H, H, 3 * H, dWh, None, ws, G, 1.0, 0, 0, stream)
     refWi = torch.cat([p["gru.ir.kernel"].grad, p["gru.iz.kernel"].grad, p["gru.in.kernel"].grad], 1)
     refWh = torch.cat([p["gru.hr.kernel"].grad, p["gru.hz.kernel"].grad, p["gru.hn.kernel"].grad], 1)
     refbi = torch.cat([p["gru.ir.bias"].grad, p["gru.iz.bias"].grad, p["gru.in.bias"].grad])
