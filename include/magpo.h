@@ -209,13 +209,14 @@ int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_
  *   tail 1 (encoder): hv = o W0 + b0, value = rms(gelu(hv)) hs . hw + hb1, q2[k] = ope Wq2[k]   tail 2: out0 = ope W0 (192 columns)
  *   tail 3 (last decoder block): hp = o W0 + b0, hn = rms(gelu(hp)) hs, logits = hn W1 + b1 (K columns)   tail 0: none
  * dims_host[6] = {tail, K, npos, ldg, ld0, nq2}; ptrs_host[34] (device pointers): r gp gamma beta wo_t res s1 s2 pe pos | u y o ope |
- *   w0_t b0 out0 | hs hw hb1 value | q2_t[4] q2[4] | hn w1_t b1 logits | rows   (o, ope, s2, rows and unused tail pointers may be NULL;
+ *   w0_t b0 out0 | hs hw hb1 value | q2_t[4] q2[4] | hn w1_t b1 logits | rows   (y, o, ope, s2, rows and unused tail pointers may be NULL;
  *   with rows (i32 [R]) gp and res are row tables and token row r reads table row rows[r]) */
 int magpo_seg_post(const int* dims_host, long R, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
 
 /* backward of that front: dsum = d(res + y) through the RMSNorm(s), du = dsum W_o^T, (dr, dg) through GroupNorm + swish gate, and the
- * parameter-gradient rows (s1, s2, gamma, beta) as [magpo_seg_bwd_grid(R)][64] slabs.  ptrs_host[20]: a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta |
- * dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be | rows   (y, s2, d1, d2, slab_s2, rows may be NULL; with rows, a and gp are row tables) */
+ * parameter-gradient rows (s1, s2, gamma, beta) as [magpo_seg_bwd_grid(R)][64] slabs.  ptrs_host[21]: a y s1 s2 d0 d1 d2 wo_nat r gp gamma beta |
+ * dsum dr dgp | slab_s1 slab_s2 slab_ga slab_be | rows | wo_t   (y, s2, d1, d2, slab_s2, rows, wo_t may be NULL; with rows, a and gp are row
+ * tables; with wo_t -- W_o^T as magpo_seg_post takes it -- y is not read but recomputed from r and gp, and magpo_seg_post may be given y = NULL) */
 int magpo_seg_bwd_grid(long R);
 int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* ptrs_host, int nptrs, magpo_stream_t stream);
 

@@ -58,6 +58,25 @@ __device__ __forceinline__ Row dense64_reg(const Row& x, const float4 (&w)[4][4]
   }
   return y;
 }
+// same layer with the weight fragments read from an LDS copy of W^T ([64][WSP] floats: same products in the same order as dense64_reg)
+constexpr int WSP = 68;
+__device__ __forceinline__ Row dense64_lds(const Row& x, const float* __restrict__ ws, int m, int kq) {
+  Row y;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {
+      const float4 w = *reinterpret_cast<const float4*>(ws + (16 * g + m) * WSP + 16 * gk + 4 * kq);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.v[4 * gk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.v[4 * gk + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.v[4 * gk + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.v[4 * gk + 3], acc, 0, 0, 0);
+    }
+    y.v[4 * g] = acc[0]; y.v[4 * g + 1] = acc[1]; y.v[4 * g + 2] = acc[2]; y.v[4 * g + 3] = acc[3];
+  }
+  return y;
+}
 __device__ __forceinline__ void load_w64(float4 (&w)[4][4], const float* __restrict__ Wt, int m, int kq) {
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(64, 1) void k_seg_post(SegArgs a) {
     for (int j = 0; j < 16; ++j) u.v[j] = fswish(g.v[j]) * ((r.v[j] - mu) * rstd * gam.v[j] + bet.v[j]);
     row_store(a.u + rw * AE, kq, u);
     const Row y = dense64_reg(u, wo, nullptr, kq);
-    row_store(a.y + rw * AE, kq, y);
+    if (a.y) row_store(a.y + rw * AE, kq, y);   // (not kept for the fused backward, which recomputes it from r and gp: k_seg_bwd)
     // o = rms(res + y) s1 [-> rms s2]
     Row o = row_add(res, y);
     {
@@ -202,20 +221,51 @@ struct SegBwdArgs {
   const float* a; const float* y; const float* s1; const float* s2;
   const float* d0; const float* d1; const float* d2;
   const float* wo_nat;                 // W_o [64 in][64 out] natural layout = "W^T" of du = dsum W_o^T
+  const float* wo_t;                   // nullable: W_o^T as the forward holds it -- then y is not read but recomputed (y = u W_o, u from r and gp)
   const float* r; const float* gp; long ldg; const float* gamma; const float* beta;
   float* dsum; float* dr; float* dgp; long lddg;
   float* slab_s1; float* slab_s2; float* slab_ga; float* slab_be;   // [grid][64]
   const int* rows;   // nullable: a and gp are row tables, token row r reads table row rows[r]
 };
 
+template <bool RECOMP>
 __global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
   const int lane = threadIdx.x, m = lane & 15, kq = lane >> 4;
   const long ntiles = (a.R + 15) >> 4;
   float4 wo[4][4];
+  __shared__ __align__(16) float wot[RECOMP ? 64 * WSP : 4];   // W_o^T for the recomputed y: in LDS, the register file is full (466 of 512)
   load_w64(wo, a.wo_nat, m, kq);
-  const Row s1 = row_load(a.s1, kq), gam = row_load(a.gamma, kq), bet = row_load(a.beta, kq);
-  Row s2;
-  if (a.s2) s2 = row_load(a.s2, kq);
+  // The forward's y = u W_o is recomputed here instead of being written there and read here: the kernel streams at the HBM rate with the
+  // matrix cores at 0.16, a second 64 x 64 GEMM per row is free, 256 bytes per row on either side are not.  Same instructions on the same
+  // operands as k_seg_post (fswish, the fused multiply-adds of the GroupNorm, dense64_reg on W_o^T): the same bits.
+  constexpr bool recompute = RECOMP;
+  if (recompute) {
+    for (int i = lane; i < 64 * 16; i += 64) *reinterpret_cast<float4*>(&wot[(i >> 4) * WSP + 4 * (i & 15)]) = ld4g(a.wo_t + (i >> 4) * AE + 4 * (i & 15));
+    __syncthreads();
+  }
+  // the four per-feature parameter rows: in registers, or (RECOMP: no registers left) in LDS and re-read where a tile uses them -- the
+  // opaque offset keeps the compiler from hoisting those reads back out of the tile loop into 64 live registers
+  __shared__ __align__(16) float prm[RECOMP ? 4 * 64 : 4];
+  Row s1_, s2_, gam_, bet_;
+  if (!RECOMP) {
+    s1_ = row_load(a.s1, kq); gam_ = row_load(a.gamma, kq); bet_ = row_load(a.beta, kq);
+    if (a.s2) s2_ = row_load(a.s2, kq);
+  } else {
+    prm[lane] = a.s1[lane]; prm[64 + lane] = a.s2 ? a.s2[lane] : 0.f; prm[128 + lane] = a.gamma[lane]; prm[192 + lane] = a.beta[lane];
+    __syncthreads();
+  }
+  auto prow = [&](int which, const Row& reg) -> Row {
+    if (!RECOMP) return reg;
+    int off = which * 64 + 4 * kq;
+    asm volatile("" : "+v"(off));
+    Row r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t4 = *reinterpret_cast<const float4*>(&prm[off + 16 * g]);
+      r.v[4 * g] = t4.x; r.v[4 * g + 1] = t4.y; r.v[4 * g + 2] = t4.z; r.v[4 * g + 3] = t4.w;
+    }
+    return r;
+  };
   Row ds1, ds2, dga, dbe;
 #pragma unroll
   for (int j = 0; j < 16; ++j) { ds1.v[j] = 0.f; ds2.v[j] = 0.f; dga.v[j] = 0.f; dbe.v[j] = 0.f; }
@@ -224,7 +274,7 @@ __global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
   auto fetch = [&](long row) {
     const long src = a.rows ? (long)a.rows[row] : row;
     na = row_load(a.a + src * AE, kq);
-    if (a.y) ny = row_load(a.y + row * AE, kq);
+    if (a.y && !recompute) ny = row_load(a.y + row * AE, kq);
     nd = row_load(a.d0 + row * AE, kq);
     if (a.d1) nd1 = row_load(a.d1 + row * AE, kq);
     if (a.d2) nd2 = row_load(a.d2 + row * AE, kq);
@@ -237,21 +287,35 @@ __global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
     const long row = tile * 16 + m;
     const long rw = min(row, a.R - 1);
     const float live = row < a.R ? 1.f : 0.f;   // shadow rows are stored (same values as the last row) but not accumulated
-    Row x = a.y ? row_add(na, ny) : na;
+    Row x = (a.y && !recompute) ? row_add(na, ny) : na;
     Row d = nd;
     if (a.d1) d = row_add(d, nd1);
     if (a.d2) d = row_add(d, nd2);
     const Row r = nr, g = ng;
     fetch(rowc(min(tile + (long)gridDim.x, ntiles - 1)));
-    // ---- residual + RMSNorm(s) backward
+    // ---- GroupNorm + swish gate forward (their backward further down uses the same values)
     Row t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t.v[j] = r.v[j] * r.v[j];
+    const float mu = row_sum(r) * (1.0f / 64.0f), m2 = row_sum(t) * (1.0f / 64.0f);
+    const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
+    if (recompute) {
+      const Row gam = prow(2, gam_), bet = prow(3, bet_);
+      Row u;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) u.v[j] = fswish(g.v[j]) * ((r.v[j] - mu) * rstd * gam.v[j] + bet.v[j]);
+      x = row_add(x, dense64_lds(u, wot, m, kq));
+    }
+    // ---- residual + RMSNorm(s) backward
 #pragma unroll
     for (int j = 0; j < 16; ++j) t.v[j] = x.v[j] * x.v[j];
     const float rstd1 = rsqrtf(row_sum(t) * (1.0f / 64.0f) + EPSN);
     Row xh1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) xh1.v[j] = x.v[j] * rstd1;
+    const Row s1 = prow(0, s1_);
     if (a.s2) {
+      const Row s2 = prow(1, s2_);
       Row y1;
 #pragma unroll
       for (int j = 0; j < 16; ++j) { y1.v[j] = xh1.v[j] * s1.v[j]; t.v[j] = y1.v[j] * y1.v[j]; }
@@ -281,10 +345,7 @@ __global__ __launch_bounds__(64, 1) void k_seg_bwd(SegBwdArgs a) {
     row_store(a.dsum + rw * AE, kq, dsum);
     // ---- du = dsum W_o^T, then GroupNorm + swish gate backward
     const Row du = dense64_reg(dsum, wo, nullptr, kq);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) t.v[j] = r.v[j] * r.v[j];
-    const float mu = row_sum(r) * (1.0f / 64.0f), m2 = row_sum(t) * (1.0f / 64.0f);
-    const float rstd = rsqrtf(fmaxf(m2 - mu * mu, 0.f) + EPSN);
+    const Row gam = prow(2, gam_), bet = prow(3, bet_);
     Row xh, gg, dg;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -361,7 +422,7 @@ extern "C" int magpo_seg_bwd_grid(long R) { const long nt = (R + 15) / 16; retur
 // (y, s2, d1, d2, slab_s2, rows may be NULL; with rows, a and gp are row tables read through rows[r]); ldg / lddg: row strides of gp / dgp.  Slabs: [magpo_seg_bwd_grid(R)][64].
 extern "C" int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* p, int nptrs, hipStream_t st) {
   if (R <= 0) return MAGPO_OK;
-  if (nptrs != 20) { set_error("magpo_seg_bwd: pointer table size mismatch"); return MAGPO_EINVAL; }
+  if (nptrs != 21) { set_error("magpo_seg_bwd: pointer table size mismatch"); return MAGPO_EINVAL; }
   SegBwdArgs a;
   a.R = R; a.ldg = ldg; a.lddg = lddg;
   int i = 0;
@@ -371,6 +432,8 @@ extern "C" int magpo_seg_bwd(long R, long ldg, long lddg, const void* const* p, 
   a.dsum = (float*)p[i++]; a.dr = (float*)p[i++]; a.dgp = (float*)p[i++];
   a.slab_s1 = (float*)p[i++]; a.slab_s2 = (float*)p[i++]; a.slab_ga = (float*)p[i++]; a.slab_be = (float*)p[i++];
   a.rows = (const int*)p[i++];
-  hipLaunchKernelGGL(k_seg_bwd, dim3((unsigned)magpo_seg_bwd_grid(R)), dim3(64), 0, st, a);
+  a.wo_t = (const float*)p[i++];
+  if (a.wo_t) hipLaunchKernelGGL(k_seg_bwd<true>, dim3((unsigned)magpo_seg_bwd_grid(R)), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_seg_bwd<false>, dim3((unsigned)magpo_seg_bwd_grid(R)), dim3(64), 0, st, a);
   return check_launch("magpo_seg_bwd");
 }

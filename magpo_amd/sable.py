@@ -501,14 +501,14 @@ class SableGuider:
             self._seg_tabs[key] = ent
         self.L.call("magpo_seg_post", ent[0].ctypes.data, R, ent[1].ctypes.data, int(ent[1].size), self._st())
 
-    def _seg_bwd(self, a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, ldg, pfx, dsum, dr, dgp, lddg, R, g_s1, g_s2, acc_s1=False, rows=None):
+    def _seg_bwd(self, a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, ldg, pfx, dsum, dr, dgp, lddg, R, g_s1, g_s2, acc_s1=False, rows=None, wo_t=None):
         """Backward of the front of a post-retention segment in one launch (csrc/seg_fused.hip: k_seg_bwd): d(res + y) through the
         RMSNorm(s), dsum W_o^T, GroupNorm + gate backward, and the four parameter-gradient rows (reduced from per-wave slabs)."""
         v, gv, b = self.v, self.gv, self.b
         ptr = lambda t: 0 if t is None else t.data_ptr()
         G = self.L.call("magpo_seg_bwd_grid", R)
         sl = [b.get(f"sb_{i}", (G, E)) for i in range(4)]
-        tab = [a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, v[pfx + "gn.scale"], v[pfx + "gn.bias"], dsum, dr, dgp, sl[0], sl[1] if s2 is not None else None, sl[2], sl[3], rows]
+        tab = [a, y, s1, s2, d0, d1, d2, wo_nat, r, gp, v[pfx + "gn.scale"], v[pfx + "gn.bias"], dsum, dr, dgp, sl[0], sl[1] if s2 is not None else None, sl[2], sl[3], rows, wo_t]
         key = ("bwd", R, ldg, lddg, tuple(ptr(t) for t in tab))
         ent = self._seg_tabs.get(key)
         if ent is None:
@@ -562,7 +562,8 @@ class SableGuider:
                 xn, qkvg = xn_c, qkvg_c
             else:
                 xn, qkvg = g(f"xn{k}"), g(f"qkvg{k}", 4 * E)
-            r, u, y = g(f"r{k}"), g(f"u{k}"), g(f"y{k}")
+            r, u = g(f"r{k}"), g(f"u{k}")
+            y = None if self.fused_segments else g(f"y{k}")   # (fused segments: y = u W_o is recomputed by the backward, never stored)
             if k > 0 or classes is None:
                 self.lin(g(f"kin{k}"), E, self.wt[f"qkvg{k}"], None, qkvg, 4 * E, R, E, 4 * E)
             self._ret_fwd(qkvg, 4 * E, qkvg[:, E:], 4 * E, qkvg[:, 2 * E:], 4 * E, r, s0[0][k], seq_env, dones, f"st_e{k}", nseq, T, 0, rows=rows)
@@ -615,8 +616,9 @@ class SableGuider:
                 x, qkvg1 = x_c, qkvg1_c
             else:
                 x, qkvg1 = g(f"x{k}"), g(f"qkvg1{k}", 4 * E)
-            r1, u1, y1 = g(f"r1{k}"), g(f"u1{k}"), g(f"y1{k}")
-            cpe, q2, kvg2, r2, u2, y2 = g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}"), g(f"y2{k}")
+            r1, u1 = g(f"r1{k}"), g(f"u1{k}")
+            cpe, q2, kvg2, r2, u2 = g(f"cpe{k}"), g(f"q2{k}"), g(f"kvg2{k}", 3 * E), g(f"r2{k}"), g(f"u2{k}")
+            y1, y2 = (None, None) if self.fused_segments else (g(f"y1{k}"), g(f"y2{k}"))
             if k > 0 or classes is None:
                 self.lin(g(f"xpe{k}"), E, self.wt[f"qkvg1{k}"], None, qkvg1, 4 * E, R, E, 4 * E)
             self._ret_fwd(qkvg1, 4 * E, qkvg1[:, E:], 4 * E, qkvg1[:, 2 * E:], 4 * E, r1, s0[1][k], seq_env, dones, f"st_1{k}", nseq, T, 1, rows=rows)
@@ -687,8 +689,9 @@ class SableGuider:
             dr2 = g("dr"); dq2 = g(f"dq2_{k}"); dkvg2 = g(f"dkvg2_{k}", 3 * E)
             kvg2 = t(f"kvg2{k}")
             if self.fused_segments:
-                self._seg_bwd(t("rep"), t(f"y2{k}"), v[d + "ln2.scale"], v[d + "ln3.scale"], din0, din1, None, v[d + "retn2.w_o"], t(f"r2{k}"),
-                              kvg2[:, 2 * E:], 3 * E, d + "retn2.", dsum2, dr2, dkvg2[:, 2 * E:], 3 * E, R, gv[d + "ln2.scale"], gv[d + "ln3.scale"])
+                self._seg_bwd(t("rep"), None, v[d + "ln2.scale"], v[d + "ln3.scale"], din0, din1, None, v[d + "retn2.w_o"], t(f"r2{k}"),
+                              kvg2[:, 2 * E:], 3 * E, d + "retn2.", dsum2, dr2, dkvg2[:, 2 * E:], 3 * E, R, gv[d + "ln2.scale"], gv[d + "ln3.scale"],
+                              wo_t=self.wt[f"wo2{k}"])
                 self.wgrad(t(f"u2{k}"), E, dsum2, E, R, E, E, gv[d + "retn2.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t("rep"), E, t(f"y2{k}"), E, v[d + "ln2.scale"], v[d + "ln3.scale"], din0, E, din1, E if din1 is not None else 0,
@@ -715,8 +718,9 @@ class SableGuider:
             rows = cl["dec"][0] if sv["direct"] and k == 0 else None
             qkvg1, xk = (b.t["c_qkvg10"], b.t["c_x0"]) if rows is not None else (t(f"qkvg1{k}"), t(f"x{k}"))
             if self.fused_segments:
-                self._seg_bwd(xk, t(f"y1{k}"), v[d + "ln1.scale"], None, dcpe, None, None, v[d + "retn1.w_o"], t(f"r1{k}"),
-                              qkvg1[:, 3 * E:], 4 * E, d + "retn1.", dsum1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, gv[d + "ln1.scale"], None, rows=rows)
+                self._seg_bwd(xk, None, v[d + "ln1.scale"], None, dcpe, None, None, v[d + "retn1.w_o"], t(f"r1{k}"),
+                              qkvg1[:, 3 * E:], 4 * E, d + "retn1.", dsum1, dr1, dqkvg1[:, 3 * E:], 4 * E, R, gv[d + "ln1.scale"], None, rows=rows,
+                              wo_t=self.wt[f"wo1{k}"])
                 self.wgrad(t(f"u1{k}"), E, dsum1, E, R, E, E, gv[d + "retn1.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t(f"x{k}"), E, t(f"y1{k}"), E, v[d + "ln1.scale"], None, dcpe, E, None, 0, None, 0, dsum1, E,
@@ -769,8 +773,9 @@ class SableGuider:
             rows = cl["enc"][0] if sv["direct"] and k == 0 else None
             qkvg, xnk = (b.t["c_qkvg0"], b.t["c_xn0"]) if rows is not None else (t(f"qkvg{k}"), t(f"xn{k}"))
             if self.fused_segments:
-                self._seg_bwd(xnk, t(f"y{k}"), v[e + "ln1.scale"], v[e + "ln2.scale"], e0, e1, e2, v[e + "retn.w_o"], t(f"r{k}"),
-                              qkvg[:, 3 * E:], 4 * E, e + "retn.", dsum0, dr, dqkvg[:, 3 * E:], 4 * E, R, gv[e + "ln1.scale"], gv[e + "ln2.scale"], rows=rows)
+                self._seg_bwd(xnk, None, v[e + "ln1.scale"], v[e + "ln2.scale"], e0, e1, e2, v[e + "retn.w_o"], t(f"r{k}"),
+                              qkvg[:, 3 * E:], 4 * E, e + "retn.", dsum0, dr, dqkvg[:, 3 * E:], 4 * E, R, gv[e + "ln1.scale"], gv[e + "ln2.scale"], rows=rows,
+                              wo_t=self.wt[f"wo{k}"])
                 self.wgrad(t(f"u{k}"), E, dsum0, E, R, E, E, gv[e + "retn.w_o"])
             else:
                 L.call("magpo_resnorm_bwd", t(f"xn{k}"), E, t(f"y{k}"), E, v[e + "ln1.scale"], v[e + "ln2.scale"], e0, E, e1, E if e1 is not None else 0,
