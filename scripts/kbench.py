@@ -4,6 +4,9 @@ usage: python scripts/kbench.py [wgrad] [linear] [ret] [gru] [rows] [loss]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from magpo_amd import _lib
+if os.environ.get("MAGPO_LIB"):   # experiment build (A/B runs)
+    _lib.LIB_PATH = os.path.abspath(os.environ["MAGPO_LIB"])
 from magpo_amd._lib import lib
 L = lib(); dev = 'cuda'
 CT, SPLIT = int(os.environ.get("MAGPO_RET_CHUNK", 0)), int(os.environ.get("MAGPO_GRU_SPLIT_BF16", 0))   # per-call tuning arguments (the library keeps no state)
