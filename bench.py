@@ -270,10 +270,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
-    ap.add_argument("--gru-split-bf16", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
-                    help="A/B (NOT the headline): the GRU training scans' recurrent GEMMs on bf16 MFMA with split operands instead of fp32 MFMA: 1 = pairs "
-                    "(hi*hi + hi*lo + lo*hi, ~2^-16 relative per product), 2 = triples (24 mantissa bits, six products, fp32 accuracy; forward scan); "
-                    "reported in the JSON")
+    ap.add_argument("--gru-split-bf16", type=int, default=2, choices=[0, 1, 2],
+                    help="recurrent GEMMs of the GRU training scans: 2 (default) = forward scan on bf16 MFMA with operands split in three pieces (24 mantissa "
+                    "bits, six products, fp32 accumulate: error against fp64 no larger than the fp32-MFMA scan's, test_gru_scan_bf16_triples_keep_fp32_accuracy), "
+                    "0 = fp32 MFMA everywhere, 1 = pairs (16 bits, forward and backward; A/B only).  The JSON's dtype names the mode")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
@@ -293,7 +293,7 @@ def main():
     rank, world, local = mdist.init_from_env(args.backend)
     gru_split = int(args.gru_split_bf16)
     tuning = Tuning.from_env()
-    tuning.gru_split_bf16 = gru_split   # the headline is fp32 MFMA whatever MAGPO_GRU_SPLIT_BF16 says
+    tuning.gru_split_bf16 = gru_split   # (the command line decides, whatever MAGPO_GRU_SPLIT_BF16 says)
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev)
     if world != args.gpus:
@@ -425,8 +425,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not gru_split else ("f32 (GRU recurrent GEMMs: bf16 pairs x3 MFMA, fp32 accumulate)" if gru_split == 1 else
-                                                 "f32 (GRU forward recurrent GEMM: bf16 triples x6 MFMA = 24 mantissa bits, fp32 accumulate)"),
+            "dtype": ("f32" if not gru_split else "f32 (GRU recurrent GEMMs: bf16 pairs x3 MFMA = 16 mantissa bits, fp32 accumulate)" if gru_split == 1 else
+                      "f32 (fp32 MFMA; the GRU forward scan's recurrent GEMM as bf16 x3 operand splits = 24 mantissa bits, six products, fp32 accumulate)"),
             "data": f"synthetic (fixed-seed {env_name} episodes, random-init networks)",
             "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
                                    f"num_minibatches={sysc.num_minibatches}" + (f" (each in {sysc.micro_batches} slabs, gradients accumulated)" if sysc.micro_batches > 1 else "")

@@ -7,8 +7,10 @@ can run under different settings and a forward / backward pair can never see dif
 
 Environment variables are read HERE, once, when the default instance is built (A/B measurements from the shell):
     MAGPO_RET_CHUNK=64          retention chunk kernels on 64-token chunks (default 32)
-    MAGPO_GRU_SPLIT_BF16=1|2    GRU training scans on bf16 MFMA with split operands: 1 = pairs (16 mantissa bits), 2 = triples (24 bits = fp32 operands,
-                                forward scan); default 0 = fp32 MFMA
+    MAGPO_GRU_SPLIT_BF16=0|1|2  GRU training scans: 2 (default) = the forward scan's recurrent GEMM on bf16 MFMA with operands split in THREE pieces (24
+                                mantissa bits = fp32 operands, six products, fp32 accumulate: error against fp64 no larger than the fp32-MFMA scan's,
+                                tests/test_kernels_gpu.py::test_gru_scan_bf16_triples_keep_fp32_accuracy), backward on fp32 MFMA; 0 = fp32 MFMA everywhere;
+                                1 = pairs (16 mantissa bits, forward and backward; never a default)
     MAGPO_GRU_BLOCK_ROWS=32|64  recurrent rows per workgroup of the fp32 GRU scans (default: by size)
     MAGPO_LINEAR_LDS=0          wave-autonomous dense kernels instead of the shared-tile ones (MAGPO_LINEAR_LDS64=0: KIN = 64 only)
     MAGPO_WGRAD_FULL=0 / MAGPO_WGRAD_FULL_X=0 / MAGPO_WGRAD_PAD0=0 / MAGPO_WGRAD_G2=1 / MAGPO_WGRAD_GALT=1|2|3
@@ -23,7 +25,7 @@ from dataclasses import dataclass
 @dataclass
 class Tuning:
     ret_chunk_tokens: int = 0     # 0 = default (32), 32 or 64: magpo_retention_num_chunks / _chunk_fwd / _chunk_bwd
-    gru_split_bf16: int = 0       # magpo_gru_scan_fwd / _bwd
+    gru_split_bf16: int = 2       # magpo_gru_scan_fwd / _bwd (2: forward scan on bf16 triples = fp32 accuracy, see above; 0: fp32 MFMA)
     gru_block_rows: int = 0       # magpo_gru_scan_fwd / _bwd / magpo_gru_carry
     linear_variant: int = 0       # magpo_linear (bit mask, see include/magpo.h)
     wgrad_variant: int = 0        # magpo_wgrad (bit mask)
@@ -36,7 +38,7 @@ class Tuning:
         on = lambda name: e.get(name) is not None and int(e[name]) != 0
         t = cls()
         t.ret_chunk_tokens = 64 if e.get("MAGPO_RET_CHUNK") == "64" else 0
-        t.gru_split_bf16 = int(e["MAGPO_GRU_SPLIT_BF16"]) if e.get("MAGPO_GRU_SPLIT_BF16") in ("1", "2") else 0
+        t.gru_split_bf16 = int(e["MAGPO_GRU_SPLIT_BF16"]) if e.get("MAGPO_GRU_SPLIT_BF16") in ("0", "1", "2") else cls().gru_split_bf16
         t.gru_block_rows = int(e.get("MAGPO_GRU_BLOCK_ROWS", 0)) if e.get("MAGPO_GRU_BLOCK_ROWS") in ("32", "64") else 0
         t.linear_variant = (1 if off("MAGPO_LINEAR_LDS") else 0) | (2 if off("MAGPO_LINEAR_LDS64") else 0)
         t.wgrad_variant = ((1 if off("MAGPO_WGRAD_FULL") else 0) | (2 if off("MAGPO_WGRAD_FULL_X") else 0) | (4 if off("MAGPO_WGRAD_PAD0") else 0)

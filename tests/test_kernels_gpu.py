@@ -492,7 +492,7 @@ def test_gru_scan_bf16_triples_keep_fp32_accuracy(L, stream):
         L.call("magpo_gru_scan_fwd", dev(xi), Wht, dev(bhn), dev(h0), None, dev(done.to(torch.uint8)), hs, gates, hp, nseq, T, A, None, mode, 0, stream)
         err[mode] = float((hs.cpu().double() - ref).abs().max())
     print("GRU forward scan, max |h - fp64|: fp32 MFMA %.2e, bf16 pairs %.2e, bf16 triples %.2e" % (err[0], err[1], err[2]))
-    assert err[2] <= 1.5 * err[0] + 1e-7, err
+    assert err[2] <= 1.05 * err[0], err     # (measured: 2.97e-7 vs 3.15e-7, profiles/r03_gru_bf16_triples_error_vs_fp64.txt)
     assert err[1] > err[2]
 
 
