@@ -274,6 +274,8 @@ def main():
                     help="recurrent GEMMs of the GRU training scans: 2 (default) = forward scan on bf16 MFMA with operands split in three pieces (24 mantissa "
                     "bits, six products, fp32 accumulate: error against fp64 no larger than the fp32-MFMA scan's, test_gru_scan_bf16_triples_keep_fp32_accuracy), "
                     "0 = fp32 MFMA everywhere, 1 = pairs (16 bits, forward and backward; A/B only).  The JSON's dtype names the mode")
+    ap.add_argument("--fp32-mfma", action="store_true", help="exact fp32 MFMA everywhere: --gru-split-bf16 0 and the 128 / 192-input dense layers on fp32 MFMA "
+                    "instead of bf16 MFMA with three-piece operand splits (the switch VERDICT r2 item 5 asks to keep)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
@@ -293,7 +295,11 @@ def main():
     rank, world, local = mdist.init_from_env(args.backend)
     gru_split = int(args.gru_split_bf16)
     tuning = Tuning.from_env()
+    if args.fp32_mfma:
+        gru_split = 0
+        tuning.linear_variant &= ~4
     tuning.gru_split_bf16 = gru_split   # (the command line decides, whatever MAGPO_GRU_SPLIT_BF16 says)
+    lin_bf3 = bool(tuning.linear_variant & 4)
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev)
     if world != args.gpus:
@@ -425,8 +431,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32" if not gru_split else "f32 (GRU recurrent GEMMs: bf16 pairs x3 MFMA = 16 mantissa bits, fp32 accumulate)" if gru_split == 1 else
-                      "f32 (fp32 MFMA; the GRU forward scan's recurrent GEMM as bf16 x3 operand splits = 24 mantissa bits, six products, fp32 accumulate)"),
+            "dtype": "f32" + ("" if not (gru_split or lin_bf3) else " (fp32 MFMA; as bf16 x3 operand splits = 24 mantissa bits, six products, fp32 accumulate: "
+                              + ", ".join(([] if gru_split != 2 else ["the GRU forward scan's recurrent GEMM"]) + ([] if not lin_bf3 else ["the dense layers with 128 / 192 inputs"]))
+                              + ("; GRU recurrent GEMMs as bf16 PAIRS = 16 mantissa bits" if gru_split == 1 else "") + ")"),
             "data": f"synthetic (fixed-seed {env_name} episodes, random-init networks)",
             "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "
                                    f"num_minibatches={sysc.num_minibatches}" + (f" (each in {sysc.micro_batches} slabs, gradients accumulated)" if sysc.micro_batches > 1 else "")

@@ -9,6 +9,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 
 namespace magpo {
 
@@ -143,6 +145,16 @@ __device__ __forceinline__ int choice_mask_cumsum(const unsigned long long (&m)[
     }
   }
   return 0;
+}
+
+// An fp32 operand as NP bf16 pieces for v_mfma_f32_32x32x16_bf16: 2 (x = hi + lo, 16 mantissa bits, products hh + hl + lh) or 3
+// (x = hi + mid + lo, 24 mantissa bits -- what an fp32 operand holds -- products hh + hm + mh + hl + lh + mm on the same instruction:
+// 6/16 of the fp32 MFMA time at fp32 accuracy; the dropped products ml, lm, ll are below 2^-24 of the result).
+template <int NP> __device__ __forceinline__ void split_pieces(float x, __bf16 (&p)[NP]) {
+  p[0] = (__bf16)x;
+  float r = x - (float)p[0];
+  p[1] = (__bf16)r;
+  if (NP == 3) { r -= (float)p[1]; p[2] = (__bf16)r; }
 }
 
 }  // namespace magpo

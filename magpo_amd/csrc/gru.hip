@@ -203,22 +203,11 @@ __global__ __launch_bounds__(256, 1) void k_gru_scan_fwd(GruArgs a, int block0) 
 // ~2^-16 (SURVEY 7 names split-bf16 x3 as the alternative to fp32 MFMA), 3 x 1/16 of the MFMA time.  W_h is split once per
 // kernel (same 192 VGPRs as the fp32 fragments); h is written to LDS as two bf16 tiles when the gate phase produces it (each
 // element is produced once and read by all four waves).  The carry itself (z * h_prev) stays exact fp32.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int HB = H + 8;   // bf16 tile pitch (elements): 272-byte rows, 16-byte aligned
 
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   hi = (__bf16)x;
   lo = (__bf16)(x - (float)hi);
-}
-
-// NP = pieces per operand: 2 (x = hi + lo, 16 mantissa bits, products hh + hl + lh) or 3 (x = hi + mid + lo, 24 mantissa bits -- what an
-// fp32 operand holds -- products hh + hm + mh + hl + lh + mm on the same instruction: 6/16 of the fp32 MFMA time at fp32 accuracy; the dropped
-// products ml, lm, ll are below 2^-24 of the result).
-template <int NP> __device__ __forceinline__ void split_pieces(float x, __bf16 (&p)[NP]) {
-  p[0] = (__bf16)x;
-  float r = x - (float)p[0];
-  p[1] = (__bf16)r;
-  if (NP == 3) { r -= (float)p[1]; p[2] = (__bf16)r; }
 }
 
 template <bool FULL, int NP>

@@ -406,22 +406,45 @@ __global__ __launch_bounds__(256) void k_linear_wk(const float* __restrict__ X, 
 // k_linear_wk lets every wave fetch its own copy of the tile as per-lane 128-B row pieces: 64 cache lines touched by each
 // load instruction, 4096 line requests per tile and workgroup -- the L1 tag rate, not MFMA or HBM, bounds it (~50 % of the
 // MFMA peak).  Here a tile costs KIN/4 coalesced line requests and one barrier.
-template <int KIN, int NW>
+template <int KIN, int NW, bool BF3 = false>
 __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict__ X, int ldx, const float* __restrict__ Wt,
                                                     const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                     int R, int NOUT, int act, const float* __restrict__ aux) {
   constexpr int NKC = KIN / 64, PT = KIN + LDP, NT = 64 * NW, NLD = 32 * (KIN / 4) / NT;   // NLD float4 per thread and tile
-  extern __shared__ __align__(16) float ll_smem[];                // 2 x [32][PT]
+  // BF3 (per-call variant bit 2): the GEMM on v_mfma_f32_32x32x16_bf16 with BOTH operands split into three bf16 pieces (24 mantissa bits =
+  // what an fp32 operand holds; six products hh hm mh hl lh mm, fp32 accumulate): 6/16 of the fp32 MFMA time at fp32 accuracy
+  // (tests/test_kernels_gpu.py::test_linear_bf16_triples_keep_fp32_accuracy).  The weight fragments are split once per kernel, a row tile once
+  // per workgroup when it is stashed (three bf16 planes [32][KIN + 8] instead of one fp32 tile); k of MFMA step s = (KIN / 2) h + 8 s + j.
+  constexpr int PB = KIN + 8, NS = KIN / 16;
+  extern __shared__ __align__(16) float ll_smem[];                // 2 x [32][PT]  (BF3: 2 x 3 x [32][PB] bf16)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, h = lane >> 5;
   const int c0 = (blockIdx.y * NW + wave) * 32;
   const bool colon = c0 < NOUT;                                   // waves past the last column group only help with the loads
   const int n = c0 + lr;
-  float4 wf[NKC][8];
+  float4 wf[BF3 ? 1 : NKC][8];
+  bf16x8 wp[BF3 ? 3 : 1][BF3 ? NS : 1];
+  if constexpr (!BF3) {
 #pragma unroll
-  for (int kc = 0; kc < NKC; ++kc)
+    for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      wf[kc][u] = colon ? *reinterpret_cast<const float4*>(Wt + (long)n * KIN + kc * 64 + 32 * h + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 8; ++u)
+        wf[kc][u] = colon ? *reinterpret_cast<const float4*>(Wt + (long)n * KIN + kc * 64 + 32 * h + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+#pragma unroll
+    for (int s8 = 0; s8 < NS; ++s8) {
+      const float* w = Wt + (long)n * KIN + (KIN / 2) * h + 8 * s8;
+      const float4 w0 = colon ? *reinterpret_cast<const float4*>(w) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 w1 = colon ? *reinterpret_cast<const float4*>(w + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 pc[3];
+        split_pieces<3>(wv[j], pc);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wp[q][s8][j] = pc[q];
+      }
+    }
+  }
   const float bv = (bias && n < NOUT) ? bias[n] : 0.f;
   const int ntiles = (R + 31) >> 5;
   float4 pre[NLD];
@@ -461,34 +484,64 @@ __global__ __launch_bounds__(64 * NW) void k_linear_lds(const float* __restrict_
       pre[j] = *reinterpret_cast<const float4*>(X + (long)row * ldx + 4 * (idx % (KIN / 4)));            \
     }                                                                                                    \
   }
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define LL_STASH(BUF)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                      \
     const int idx = tid + NT * j;                                                                        \
-    *reinterpret_cast<float4*>(&(BUF)[(idx / (KIN / 4)) * PT + 4 * (idx % (KIN / 4))]) = pre[j];         \
+    if constexpr (!BF3) {                                                                                \
+      *reinterpret_cast<float4*>(&(BUF)[(idx / (KIN / 4)) * PT + 4 * (idx % (KIN / 4))]) = pre[j];       \
+    } else {                                                                                             \
+      const float v4_[4] = {pre[j].x, pre[j].y, pre[j].z, pre[j].w};                                     \
+      bf16x4 pl_[3];                                                                                     \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+        __bf16 pc_[3];                                                                                   \
+        split_pieces<3>(v4_[e], pc_);                                                                    \
+        pl_[0][e] = pc_[0]; pl_[1][e] = pc_[1]; pl_[2][e] = pc_[2];                                      \
+      }                                                                                                  \
+      __bf16* bb_ = reinterpret_cast<__bf16*>(BUF) + (idx / (KIN / 4)) * PB + 4 * (idx % (KIN / 4));     \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(bb_ + q * 32 * PB) = pl_[q]; \
+    }                                                                                                    \
   }
   LL_FETCH(blockIdx.x)
   LL_STASH(ll_smem)
   __syncthreads();
   int par = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const float* buf = ll_smem + par * 32 * PT;
+    const float* buf = ll_smem + par * (BF3 ? 3 * 32 * PB / 2 : 32 * PT);
     LL_FETCH(min(tile + (int)gridDim.x, ntiles - 1))   // in flight under this tile's MFMAs
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float* ap = buf + lr * PT + 32 * h;
+    if constexpr (!BF3) {
+      const float* ap = buf + lr * PT + 32 * h;
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) {
+      for (int kc = 0; kc < NKC; ++kc) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float4 av = *reinterpret_cast<const float4*>(ap + kc * 64 + 4 * u);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[kc][u].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[kc][u].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[kc][u].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[kc][u].w, acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+          const float4 av = *reinterpret_cast<const float4*>(ap + kc * 64 + 4 * u);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wf[kc][u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wf[kc][u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wf[kc][u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wf[kc][u].w, acc, 0, 0, 0);
+        }
+      }
+    } else {
+      const __bf16* ab = reinterpret_cast<const __bf16*>(buf) + lr * PB + (KIN / 2) * h;
+#pragma unroll
+      for (int s8 = 0; s8 < NS; ++s8) {
+        bf16x8 xp[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xp[q] = *reinterpret_cast<const bf16x8*>(ab + q * 32 * PB + 8 * s8);
+        // products in decreasing order of magnitude: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], wp[0][s8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], wp[1][s8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], wp[0][s8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], wp[2][s8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[2], wp[0][s8], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], wp[1][s8], acc, 0, 0, 0);
       }
     }
-    float* nbuf = ll_smem + (par ^ 1) * 32 * PT;     // the other buffer: nobody reads it during this tile
+    float* nbuf = ll_smem + (par ^ 1) * (BF3 ? 3 * 32 * PB / 2 : 32 * PT);     // the other buffer: nobody reads it during this tile
     LL_STASH(nbuf)
     if (colon) {
       if ((act <= ACT_RELU || act == ACT_MASKPOS) && (long)tile * 32 + 32 <= R && c0 + 32 <= NOUT) {
@@ -1123,7 +1176,8 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
   if ((ldx & 3) || KIN % 64 || NOUT <= 0) { set_error("magpo_linear: KIN must be a multiple of 64, ldx of 4"); return MAGPO_EINVAL; }
   // variant (A/B reference paths, same results up to fp32 summation order; 0 = the fast path): bit 0 = wave-autonomous k_linear_wk instead of
   // the shared-tile k_linear_lds, bit 1 = the same for KIN = 64 only
-  if (variant < 0 || variant > 3) { set_error("magpo_linear: variant must be in [0, 3]"); return MAGPO_EINVAL; }
+  // bit 2 = bf16 triples (k_linear_lds<.., BF3>: KIN 128 / 192 on the shared-tile path; ignored elsewhere)
+  if (variant < 0 || variant > 7) { set_error("magpo_linear: variant must be in [0, 7]"); return MAGPO_EINVAL; }
   const bool lds64 = !(variant & 2);
   const float* aux = nullptr;
   if (act == ACT_MASKPOS) {   // the Ypre argument carries the mask INPUT (same shape / stride as Y), nothing else is written
@@ -1153,6 +1207,23 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
       if (gy >= 3) wk2 /= 2;
       if (wk2 > ntiles) wk2 = ntiles;
       dim3 g2((unsigned)wk2, (unsigned)gy), b2(64 * nw);
+      if ((variant & 4) && (KIN == 128 || KIN == 192)) {
+        const size_t ldb = (size_t)2 * 3 * 32 * (KIN + 8) * sizeof(__bf16);
+#define LAUNCH_BF3(K_)                                                                                                  \
+        {                                                                                                               \
+          static bool attr = false;                                                                                     \
+          if (!attr && ldb > 65536) {                                                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_lds<K_, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb); \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_lds<K_, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb); \
+            attr = true;                                                                                                \
+          }                                                                                                             \
+          if (nw == 4) hipLaunchKernelGGL((k_linear_lds<K_, 4, true>), g2, b2, ldb, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act, aux); \
+          else hipLaunchKernelGGL((k_linear_lds<K_, 2, true>), g2, b2, ldb, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act, aux); \
+        }
+        if (KIN == 128) LAUNCH_BF3(128) else LAUNCH_BF3(192)
+#undef LAUNCH_BF3
+        return check_launch("magpo_linear");
+      }
       const size_t lds = (size_t)2 * 32 * (KIN + LDP) * sizeof(float);
 #define LAUNCH_LDS(K_)                                                                                                   \
       {                                                                                                                 \

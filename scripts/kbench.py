@@ -37,7 +37,7 @@ if "linear" in which:
         X = torch.randn(R, KIN, device=dev, generator=g); Y = torch.empty(R, NOUT, device=dev)
         npad = (NOUT + 31) // 32 * 32
         Wt = torch.randn(npad, KIN, device=dev, generator=g)
-        timeit(f"linear {KIN}->{NOUT}", lambda: L.call("magpo_linear", X, KIN, Wt, None, Y, NOUT, None, R, KIN, NOUT, 0, 0, st),
+        timeit(f"linear {KIN}->{NOUT}", lambda: L.call("magpo_linear", X, KIN, Wt, None, Y, NOUT, None, R, KIN, NOUT, 0, int(os.environ.get("MAGPO_LINEAR_VARIANT", 0)), st),
                2.0 * R * KIN * NOUT, 4.0 * R * (KIN + NOUT))
 if "ret" in which:
     q, k, v, dr = (torch.randn(R, 64, device=dev, generator=g) * 0.3 for _ in range(4))

@@ -99,6 +99,39 @@ def test_linear_shared_tile(L, stream, KIN, NOUT, R, act):
     assert bool((Y[R] == 7.0).all()) and (ld == NOUT or bool((Y[:R, NOUT:] == 7.0).all()))
 
 
+@pytest.mark.parametrize("KIN,NOUT,R,act", [(128, 384, 1000, 0), (128, 128, 333, 1), (128, 96, 65, 0), (192, 64, 65, 2), (192, 64, 4001, 0), (128, 20, 77, 0)])
+def test_linear_bf16_triples(L, stream, KIN, NOUT, R, act):
+    """variant bit 2: the shared-tile dense kernel on bf16 MFMA with both operands split into three bf16 pieces (KIN 128 / 192): same
+    tolerances against fp64 as the fp32-MFMA kernel (full and ragged row tiles, ragged column groups, every epilogue)."""
+    g = torch.Generator().manual_seed(14)
+    X = torch.randn(R, KIN, generator=g); W = torch.randn(KIN, NOUT, generator=g) / math.sqrt(KIN); b = torch.randn(NOUT, generator=g)
+    Wt = transpose_pad(L, stream, dev(W))
+    ld = (NOUT + 3) // 4 * 4
+    Y = torch.zeros(R, ld, device=DEV)
+    L.call("magpo_linear", dev(X), KIN, Wt, dev(b), Y, ld, None, R, KIN, NOUT, act, 4, stream)
+    ref = X.double() @ W.double() + b.double()
+    ref = torch.relu(ref) if act == 1 else (torch.nn.functional.gelu(ref, approximate="tanh") if act == 2 else ref)
+    close(Y[:, :NOUT], ref, what="bf16 triples")
+
+
+def test_linear_bf16_triples_keep_fp32_accuracy(L, stream):
+    """Acceptance bar for taking a GEMM kernel off fp32 MFMA: the error against the fp64 product is no larger than the
+    fp32-MFMA kernel's on the same data (128 -> 384 and 192 -> 64, the two shapes the update step runs on this path)."""
+    g = torch.Generator().manual_seed(15)
+    for KIN, NOUT, R in ((128, 384, 8192), (192, 64, 8192), (128, 128, 8192)):
+        X = torch.randn(R, KIN, generator=g) * 1.3; W = torch.randn(KIN, NOUT, generator=g) / math.sqrt(KIN)
+        Wt = transpose_pad(L, stream, dev(W))
+        ref = X.double() @ W.double()
+        err = {}
+        for variant in (0, 4):
+            Y = torch.zeros(R, NOUT, device=DEV)
+            L.call("magpo_linear", dev(X), KIN, Wt, None, Y, NOUT, None, R, KIN, NOUT, 0, variant, stream)
+            d = (Y.cpu().double() - ref).abs()
+            err[variant] = (float(d.max()), float(d.mean()))
+        print("linear %d -> %d, |y - fp64| max / mean: fp32 MFMA %.2e / %.2e, bf16 triples %.2e / %.2e" % (KIN, NOUT, *err[0], *err[4]))
+        assert err[4][0] <= 1.05 * err[0][0] and err[4][1] <= 1.05 * err[0][1], err
+
+
 def test_linear_relu_mask_epilogue(L, stream):
     """act 4: dX = (dY W^T) masked by the forward activation passed in the Ypre slot (ReLU backward fused into the GEMM)."""
     KIN, NOUT, R = 64, 128, 173
