@@ -275,7 +275,7 @@ def main():
                     "bits, six products, fp32 accumulate: error against fp64 no larger than the fp32-MFMA scan's, test_gru_scan_bf16_triples_keep_fp32_accuracy), "
                     "0 = fp32 MFMA everywhere, 1 = pairs (16 bits, forward and backward; A/B only).  The JSON's dtype names the mode")
     ap.add_argument("--fp32-mfma", action="store_true", help="exact fp32 MFMA everywhere: --gru-split-bf16 0 and the 128 / 192-input dense layers on fp32 MFMA "
-                    "instead of bf16 MFMA with three-piece operand splits (the switch VERDICT r2 item 5 asks to keep)")
+                    "instead of bf16 MFMA with three-piece operand splits")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--check-replicas", action="store_true", help="assert that parameters stayed identical on all ranks")
     args = ap.parse_args()
@@ -298,8 +298,10 @@ def main():
     if args.fp32_mfma:
         gru_split = 0
         tuning.linear_variant &= ~4
+        tuning.actor_linear_variant &= ~4
     tuning.gru_split_bf16 = gru_split   # (the command line decides, whatever MAGPO_GRU_SPLIT_BF16 says)
-    lin_bf3 = bool(tuning.linear_variant & 4)
+    lin_bf3 = ([] if not tuning.actor_linear_variant & 4 else ["the GRU actor's 128-input dense layers"]) + \
+              ([] if not tuning.linear_variant & 4 else ["the guider's 128 / 192-input dense layers"])
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev)
     if world != args.gpus:
@@ -432,7 +434,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" + ("" if not (gru_split or lin_bf3) else " (fp32 MFMA; as bf16 x3 operand splits = 24 mantissa bits, six products, fp32 accumulate: "
-                              + ", ".join(([] if gru_split != 2 else ["the GRU forward scan's recurrent GEMM"]) + ([] if not lin_bf3 else ["the dense layers with 128 / 192 inputs"]))
+                              + ", ".join(([] if gru_split != 2 else ["the GRU forward scan's recurrent GEMM"]) + lin_bf3)
                               + ("; GRU recurrent GEMMs as bf16 PAIRS = 16 mantissa bits" if gru_split == 1 else "") + ")"),
             "data": f"synthetic (fixed-seed {env_name} episodes, random-init networks)",
             "config": {"workload": f"{env_desc}, {N} envs/GPU x {world} GPU, rollout_length=128, ppo_epochs={sysc.ppo_epochs}, "

@@ -101,7 +101,7 @@ class GruActor:
             L.call("magpo_copy_rows", src[:, H:], 3 * H, dst, 3 * H, rows, 2 * H, st)
 
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
-        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self.tuning.linear_variant, self._st())
+        self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self.tuning.actor_linear_variant, self._st())
 
     def pre_torso(self, obs, emb, R):
         """emb = relu(obs W_pre + b) (MLPTorso, torsos.py:36-47) for R observation rows (stride self.Fld)."""

@@ -1207,18 +1207,16 @@ extern "C" int magpo_linear(const float* X, int ldx, const float* Wt, const floa
       if (gy >= 3) wk2 /= 2;
       if (wk2 > ntiles) wk2 = ntiles;
       dim3 g2((unsigned)wk2, (unsigned)gy), b2(64 * nw);
-      if ((variant & 4) && (KIN == 128 || KIN == 192)) {
+      if ((variant & 4) && (KIN == 128 || KIN == 192) && nw == 4) {   // (two-wave blocks -- narrow outputs -- are slower on it: 128 -> 20 0.86 vs 1.35 ms)
         const size_t ldb = (size_t)2 * 3 * 32 * (KIN + 8) * sizeof(__bf16);
 #define LAUNCH_BF3(K_)                                                                                                  \
         {                                                                                                               \
           static bool attr = false;                                                                                     \
           if (!attr && ldb > 65536) {                                                                                   \
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_lds<K_, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb); \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_lds<K_, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb); \
             attr = true;                                                                                                \
           }                                                                                                             \
-          if (nw == 4) hipLaunchKernelGGL((k_linear_lds<K_, 4, true>), g2, b2, ldb, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act, aux); \
-          else hipLaunchKernelGGL((k_linear_lds<K_, 2, true>), g2, b2, ldb, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act, aux); \
+          hipLaunchKernelGGL((k_linear_lds<K_, 4, true>), g2, b2, ldb, stream, X, ldx, Wt, bias, Y, ldy, (int)R, NOUT, act, aux); \
         }
         if (KIN == 128) LAUNCH_BF3(128) else LAUNCH_BF3(192)
 #undef LAUNCH_BF3
