@@ -102,7 +102,8 @@ int magpo_coordsum_class_rows(int A, int maxval, int npos, int K, float* obs_tab
 /* variant: 0 = fast path; A/B reference kernels with the same result up to fp32 summation order: linear bit 0 = wave-autonomous kernels
  * instead of the shared-tile ones, bit 1 = the same for KIN = 64 only, bit 2 = KIN 128 / 192 with at least 128 output columns (four-wave column blocks) on bf16 MFMA with both operands
  * split into three bf16 pieces (24 mantissa bits, six products, fp32 accumulate: fp32 accuracy at 6/16 of the fp32 MFMA time; ignored for other shapes); wgrad bit mask 1 = split kernel for every shape, 2 = generic whole-matrix
- * kernel also on full tiles, 4 = no unpadded 64 x 256 kernel, 8 = 128 x 384 as two column halves, 16 / 32 = 64 x 64 / 64 x 256 on the wave-grid kernel. */
+ * kernel also on full tiles, 4 = no unpadded 64 x 256 kernel, 8 = 128 x 384 as two column halves, 16 / 32 = 64 x 64 / 64 x 256 on the wave-grid kernel,
+ * 64 = 128 x 384 on bf16 MFMA with three-piece operand splits (opt-in: faster, but its accumulation error is ~1.2 x the fp32-MFMA kernel's). */
 int magpo_linear(const float* X, int ldx, const float* Wt, const float* bias, float* Y, int ldy, float* Ypre,
                  long R, int KIN, int NOUT, int act, int variant, magpo_stream_t stream);
 int magpo_linear_pro(int pro, const float* a, long lda, const float* y, long ldy_in, const float* s1, const float* s2,

@@ -948,7 +948,22 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_full(const float* __restrict__
 //    was read -> wait -> MFMA, exposing one LDS latency per step;
 //  * the bias column sums are accumulated from the registers at stash time (each thread owns fixed columns of dY), not by
 //    re-reading the dY tile from LDS.
-template <int KT, int NT, int PAD = LDP>   // PAD 0: the operand reads here are column-consecutive (no row-per-lane reads), so the
+// BF3 (per-call variant bit 6, 128 x 384): the outer products on v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 pieces
+// (24 mantissa bits, six products, fp32 accumulate).  OPT-IN only: 3.6 -> 2.9 ms per launch, but over 65 536 rows its error against fp64 is
+// 19 % LARGER than the fp32-MFMA kernel's (accumulation error, six partial products per k-block: tests/test_kernels_gpu.py::
+// test_wgrad_bf16_triples), so it does not meet the bar the GRU scan and the dense layers meet.  The contraction
+// runs over ROWS, so a lane's eight consecutive k are eight rows of one column: it reads them as eight scalars from the fp32 tiles (the
+// same LDS reads as the fp32 path: one element per lane, row and operand) and splits / packs them in registers, once per operand and
+// 16-row step; 72 bf16 MFMAs (2 304 cycles) replace the 96 fp32 ones (6 144) of those 16 rows.
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&p)[3]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 pc[3];
+    split_pieces<3>(v[j], pc);
+    p[0][j] = pc[0]; p[1][j] = pc[1]; p[2][j] = pc[2];
+  }
+}
+template <int KT, int NT, int PAD = LDP, bool BF3 = false>   // PAD 0: the operand reads here are column-consecutive (no row-per-lane reads), so the
                                            // tiles need no pad; 64x256 then takes exactly 80 KB and two workgroups share a CU
 __global__ __launch_bounds__(256, 1) void k_wgrad_full_x(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy,
                                                          int R, float* __restrict__ slab, float* __restrict__ bias_slab) {
@@ -1002,6 +1017,48 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_full_x(const float* __restrict
       bsum[li % NT].x += v.x; bsum[li % NT].y += v.y; bsum[li % NT].z += v.z; bsum[li % NT].w += v.w;
     }
     __syncthreads();
+    if constexpr (BF3) {
+      // this lane's k of MFMA step s4: rows 16 s4 + 8 h + j, j = 0..7 (any bijection of the tile's 64 rows that A and B share)
+      const float* xb = xs + (8 * h) * LDX + lr;
+      const float* yb = ys + (8 * h) * LDY + 32 * NT * wave + lr;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        bf16x8 xp[KT][3], yp[NT][3];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = xb[(16 * s4 + j) * LDX + 32 * kt];
+          split8(v, xp[kt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = yb[(16 * s4 + j) * LDY + 32 * nt];
+          split8(v, yp[nt]);
+        }
+        // products in decreasing order of magnitude: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1); consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+          const int qa = pr == 0 ? 0 : (pr == 1 ? 0 : (pr == 2 ? 1 : (pr == 3 ? 0 : (pr == 4 ? 2 : 1))));
+          const int qb = pr == 0 ? 0 : (pr == 1 ? 1 : (pr == 2 ? 0 : (pr == 3 ? 2 : (pr == 4 ? 0 : 1))));
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[kt][qa], yp[nt][qb], acc[kt][nt], 0, 0, 0);
+        }
+        // the next tile's loads, spread over the four steps
+#pragma unroll
+        for (int li = 0; li < NY; ++li)
+          if (li * 4 / (NX + NY) == s4) { WFX_LOADY(li, row0n); }
+#pragma unroll
+        for (int li = 0; li < NX; ++li)
+          if ((NY + li) * 4 / (NX + NY) == s4) { WFX_LOADX(li, row0n); }
+      }
+      continue;
+    }
     float av[2][KT], bv[2][NT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) av[0][kt] = xr[32 * kt];
@@ -1317,7 +1374,7 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
   // variant (A/B reference paths, same results up to fp32 summation order; 0 = the fast path), bit mask: 1 = split kernel k_wgrad for every
   // shape, 2 = generic k_wgrad_full also on full tiles, 4 = no unpadded-tile 64 x 256 kernel, 8 = 128 x 384 as two column halves on the
   // wave-grid kernel, 16 = 64 x 64 on the wave-grid kernel, 32 = 64 x 256 on the wave-grid kernel
-  if (variant < 0 || variant > 63) { set_error("magpo_wgrad: variant must be in [0, 63]"); return MAGPO_EINVAL; }
+  if (variant < 0 || variant > 127) { set_error("magpo_wgrad: variant must be in [0, 127]"); return MAGPO_EINVAL; }
   float* slab = workspace;
   float* bslab = db ? workspace + (long)G * KIN * NOUT : nullptr;
   const bool use_full = !(variant & 1);
@@ -1385,6 +1442,11 @@ extern "C" int magpo_wgrad(const float* X, int ldx, const float* dY, int ldy, lo
       if (R % 64 == 0 && use_x) hipLaunchKernelGGL((k_wgrad_full_x<KT_, NT_>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl); \
       else hipLaunchKernelGGL((k_wgrad_full<KT_, NT_>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);  \
     }
+    if ((variant & 64) && KIN == 128 && NOUT == 384 && R % 64 == 0 && use_x) {   // bf16 triples (k_wgrad_full_x<4, 3, LDP, true>)
+      static bool attrb = false;
+      if (!attrb) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_full_x<4, 3, LDP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attrb = true; }
+      hipLaunchKernelGGL((k_wgrad_full_x<4, 3, LDP, true>), dim3(G), dim3(256), lds, stream, X, ldx, dY, ldy, (int)R, slab, bsl);
+    } else
     if (KIN == 64 && NOUT == 128) LAUNCH_FULL(2, 1) else if (KIN == 64 && NOUT == 256) LAUNCH_FULL(2, 2) else if (KIN == 64) LAUNCH_FULL(2, 3)
     else if (NOUT == 128) LAUNCH_FULL(4, 1) else if (NOUT == 256) LAUNCH_FULL(4, 2) else LAUNCH_FULL(4, 3)
 #undef LAUNCH_FULL

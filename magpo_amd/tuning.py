@@ -16,7 +16,8 @@ Environment variables are read HERE, once, when the default instance is built (A
     MAGPO_LINEAR_BF3=0|1        dense layers with 128 / 192 inputs (four-wave column blocks) on bf16 MFMA with three-piece operand splits (24 mantissa bits,
                                 error against fp64 no larger than the fp32-MFMA kernel's, test_linear_bf16_triples_keep_fp32_accuracy): unset = the GRU
                                 actor's layers only (default), 1 = the guider's too, 0 = fp32 MFMA everywhere
-    MAGPO_WGRAD_FULL=0 / MAGPO_WGRAD_FULL_X=0 / MAGPO_WGRAD_PAD0=0 / MAGPO_WGRAD_G2=1 / MAGPO_WGRAD_GALT=1|2|3
+    MAGPO_WGRAD_FULL=0 / MAGPO_WGRAD_FULL_X=0 / MAGPO_WGRAD_PAD0=0 / MAGPO_WGRAD_G2=1 / MAGPO_WGRAD_GALT=1|2|3 / MAGPO_WGRAD_BF3=1 (128 x 384 on bf16 triples: opt-in,
+                                its accumulation error is 1.2 x the fp32-MFMA kernel's)
     MAGPO_ACT_EPW=4|8|16        envs per wave of the fused acting kernel (default: by size)
 """
 from __future__ import annotations
@@ -48,6 +49,6 @@ class Tuning:
         t.linear_variant = base | (4 if on("MAGPO_LINEAR_BF3") else 0)
         t.actor_linear_variant = base | (0 if off("MAGPO_LINEAR_BF3") else 4)
         t.wgrad_variant = ((1 if off("MAGPO_WGRAD_FULL") else 0) | (2 if off("MAGPO_WGRAD_FULL_X") else 0) | (4 if off("MAGPO_WGRAD_PAD0") else 0)
-                           | (8 if on("MAGPO_WGRAD_G2") else 0) | ((int(e.get("MAGPO_WGRAD_GALT", 0)) & 3) << 4))
+                           | (8 if on("MAGPO_WGRAD_G2") else 0) | ((int(e.get("MAGPO_WGRAD_GALT", 0)) & 3) << 4) | (64 if on("MAGPO_WGRAD_BF3") else 0))
         t.act_envs_per_wave = int(e["MAGPO_ACT_EPW"]) if e.get("MAGPO_ACT_EPW") in ("4", "8", "16") else 0
         return t

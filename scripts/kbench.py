@@ -30,7 +30,7 @@ if "wgrad" in which:
         X = torch.randn(R, KIN, device=dev, generator=g); dY = torch.randn(R, NOUT, device=dev, generator=g)
         dW = torch.empty(KIN, NOUT, device=dev); G = 512
         ws = torch.empty(L.call("magpo_wgrad_workspace_floats", KIN, NOUT, G), device=dev)
-        timeit(f"wgrad {KIN}x{NOUT}", lambda: L.call("magpo_wgrad", X, KIN, dY, NOUT, R, KIN, KIN, NOUT, dW, None, ws, G, 1.0, 0, 0, st),
+        timeit(f"wgrad {KIN}x{NOUT}", lambda: L.call("magpo_wgrad", X, KIN, dY, NOUT, R, KIN, KIN, NOUT, dW, None, ws, G, 1.0, 0, int(os.environ.get("MAGPO_WGRAD_VARIANT", 0)), st),
                2.0 * R * KIN * NOUT, 4.0 * R * (KIN + NOUT))
 if "linear" in which:
     for KIN, NOUT in ((64, 256), (64, 64), (64, 192), (128, 384), (128, 128), (256, 64), (384, 128), (192, 64)):
