@@ -15,7 +15,7 @@ Environment variables are read HERE, once, when the default instance is built (A
     MAGPO_LINEAR_LDS=0          wave-autonomous dense kernels instead of the shared-tile ones (MAGPO_LINEAR_LDS64=0: KIN = 64 only)
     MAGPO_LINEAR_BF3=1          dense layers with 128 / 192 inputs (four-wave column blocks) on bf16 MFMA with three-piece operand splits (24 mantissa bits,
                                 error against fp64 no larger than the fp32-MFMA kernel's, test_linear_bf16_triples_keep_fp32_accuracy).  OPT-IN: on the
-                                3x30-50 sweep (5 seeds) the runs with it ended at 88.4 +- 2.1 / 90.8 +- 5.2 against 92.8 - 93.8 without
+                                3x30-50 sweep the runs with it on the actor ended at 90.5 (ten seeds) against 93.4 without
                                 (profiles/r03_sweep_return_at_10M.md) -- not understood, so not a default
     MAGPO_WGRAD_FULL=0 / MAGPO_WGRAD_FULL_X=0 / MAGPO_WGRAD_PAD0=0 / MAGPO_WGRAD_G2=1 / MAGPO_WGRAD_GALT=1|2|3 / MAGPO_WGRAD_BF3=1 (128 x 384 on bf16 triples: opt-in,
                                 its accumulation error is 1.2 x the fp32-MFMA kernel's)
