@@ -203,3 +203,16 @@ def test_checkpoints_are_safe_atomic_rank_aware_and_resumable(tmp_path):
     ck.save(400, mk(400), episode_return=1.0)
     assert sorted(os.listdir(d)) == ["200.pt", "400.pt", "metadata.json"]
     assert not [f for f in os.listdir(d) if f.endswith(".tmp")]
+
+
+def test_tuning_defaults_and_environment_switches():
+    """Host-side tuning object (the C ABI keeps no state): the shipped defaults, and every arithmetic mode one switch away."""
+    from magpo_amd.tuning import Tuning
+    d = Tuning.from_env({})
+    assert d == Tuning() and d.gru_split_bf16 == 2 and d.linear_variant == 0 and d.actor_linear_variant == 0 and d.wgrad_variant == 0
+    f = Tuning.from_env({"MAGPO_GRU_SPLIT_BF16": "0"})
+    assert f.gru_split_bf16 == 0 and f.linear_variant == 0 and f.actor_linear_variant == 0          # exact fp32 MFMA everywhere
+    o = Tuning.from_env({"MAGPO_LINEAR_BF3": "1", "MAGPO_WGRAD_BF3": "1", "MAGPO_GRU_SPLIT_BF16": "1", "MAGPO_RET_CHUNK": "64"})
+    assert o.linear_variant & 4 and o.actor_linear_variant & 4 and o.wgrad_variant & 64 and o.gru_split_bf16 == 1 and o.ret_chunk_tokens == 64
+    e = Tuning.from_env({"MAGPO_LINEAR_BF3": "", "MAGPO_GRU_SPLIT_BF16": ""})                         # empty variables = unset
+    assert e == Tuning()
