@@ -376,7 +376,7 @@ class MagpoLearner:
     # ------------------------------------------------------------------ rollout (rec_magpo.py:126-212)
     overlap_actor_step = False  # (measured slower: the acting kernel already fills every wave slot) actor hidden-state carry on a side stream beside the guider's acting kernel
     batched_actor_carry = True  # actor hidden-state carry as ONE scan over the finished trajectory (not T single steps)
-    fused_act = True  # one launch per env step for the whole Sable acting step (csrc/act_fused.hip)
+    fused_act = True  # one launch per env step for the whole Sable acting step (csrc/act_fused_kernel.hpp)
     use_graph = True  # replay the whole rollout as one HIP graph (removes ~11K host launches per rollout)
     batch_groups = True  # update_batch_size > 1: the minibatches of all local groups train as one batch of sequences
 

@@ -420,7 +420,7 @@ class SableGuider:
 
     def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag="",
                   pending=False, flush=True):
-        """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused.hip: k_sable_act): a wave carries 4 - 16 envs
+        """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused_kernel.hpp: k_sable_act): a wave carries 4 - 16 envs
         through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64].  ``done`` [N] u8
         (optional): envs whose episode ended on the previous step -- their carried states are read as zero
         (rec_magpo.py:164-169), which replaces a separate zeroing pass between steps.
