@@ -205,6 +205,10 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
  *   scratch qkvg1 [N*A][256], q2 [N*A][64], kvg2 [N*A][256] (rows [k | v | - | q2 (kappa S)]).   (*_t = transposed weights as produced by magpo_transpose_pad) */
 int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs_host,
                     int nptrs, const void* const* blk_ptrs_host, int nblk_ptrs, magpo_stream_t stream);
+/* Envs per wave (4, 8 or 16) of the launch magpo_sable_act makes for N envs of A agents; forced = dims_host[11] (0 = chosen by size).
+ * The kernel instance is k_sable_act<envs per wave, A <= 4 ? 4 : 8, (n_head == 1 && A <= 4) ? 1 : 0>.  Returns -1 for an invalid `forced`.
+ * Shape limits of magpo_sable_act: 1 <= A <= 8, n_block <= 4, n_head in {1, 2, 4}, K <= 31 (the candidate pre-pass holds K + 2 <= 48 rows). */
+int magpo_sable_act_envs_per_wave(int N, int A, int forced);
 
 /* ---- fused training-forward segment between two retention ops (sable_network.py:62-71,188-217,277-319; retention.py:289-295; n_head = 1):
  *   u = swish(g) * GroupNorm(r) ; y = u W_o ; o = rms(res + y) s1 [-> rms s2] ; ope = o + pe[pos] ; then the tail

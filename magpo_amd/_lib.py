@@ -95,7 +95,7 @@ class _Lib:
                 conv.append(a)
         rc = fn(*conv)
         if self.protos[name][0] == "int" and name not in ("magpo_abi_version", "magpo_row_grid", "magpo_retention_num_chunks", "magpo_seg_bwd_grid",
-                                                       "magpo_class_sum_slots", "magpo_obsnorm_grid") and rc != 0:
+                                                       "magpo_class_sum_slots", "magpo_obsnorm_grid", "magpo_sable_act_envs_per_wave") and rc != 0:
             msg = self.last_error()
             if rc == -1:
                 raise ValueError(f"{name}: {msg}")

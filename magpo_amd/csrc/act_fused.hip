@@ -9,6 +9,22 @@ extern template void launch_act<8>(const magpo::ActArgs&, hipStream_t);
 extern template void launch_act<16>(const magpo::ActArgs&, hipStream_t);
 #endif
 
+// Envs per wave of the launch magpo_sable_act makes for (N envs, A agents); forced = 0: by size, 4 / 8 / 16: the caller's choice.
+// Exported so that tests and benches can NAME the instance they ran (k_sable_act<epw, A <= 4 ? 4 : 8, n_head == 1 && A <= 4>).
+// envs per wave, measured per launch on MI355X with device events (scripts/debug/act_epw_small.py, act_epw.py; A = 4, one block, 4 / 8 / 16
+// envs per wave: N = 1024 -> 204 / 311 / 335 us, 2048 -> 237 / 331 / 348, 4096 -> 327 / 396 / 361, 8192 -> 606 / 553 / 434, 16384 -> 1360 / 922 / 698;
+// A = 8, two blocks (before the one-wave bound of the 4-env waves): N = 1024 -> 1114 / 1363 / 1882, 4096 -> 1691 / 1679 / 2088, 16384 -> 5212 / 4905 / 2340): few envs per wave while the
+// waves fit the chip's 1024 SIMDs (a rollout step is a latency chain per wave), full MFMA tiles and less weight traffic once they do not.
+// All variants run at one wave per SIMD (512 registers, no scratch).
+extern "C" int magpo_sable_act_envs_per_wave(int N, int A, int forced) {
+  if (forced) {   // envs per wave forced by the caller (A/B measurements, parity tests of every instance)
+    if (forced != 4 && forced != 8 && forced != 16) { set_error("magpo_sable_act: envs per wave must be 0, 4, 8 or 16"); return -1; }
+    return forced;
+  }
+  if (A <= 4) return N > 4096 ? 16 : (N >= 4096 ? 8 : 4);   // (4096 envs, round 3 kernel: 290 / 270 / 328 us for 4 / 8 / 16)
+  return N >= 16384 ? 16 : (N >= 4096 ? 8 : 4);
+}
+
 // Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
 //   dims_host[14] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride, envs per wave, pending, flush}; kappa_host[4];
 //   keys_host [A][2] or NULL (then ptrs[3] = device key table);  ptrs_host[49] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
@@ -20,9 +36,9 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9]; a.ldo = dims_host[10];
   a.pending = dims_host[12] != 0; a.flush = dims_host[13] != 0;
   if (a.N <= 0) return MAGPO_OK;
-  if (a.A < 1 || a.A > MAXA || a.nb < 1 || a.nb > MAXB || a.nh < 1 || a.nh > 4 || a.K < 1 || a.K > 64 || a.F < 1 || a.hs * a.nh != AE ||
+  if (a.A < 1 || a.A > MAXA || a.nb < 1 || a.nb > MAXB || a.nh < 1 || a.nh > 4 || a.K < 1 || a.K > 31 || a.F < 1 || a.hs * a.nh != AE ||
       a.gs < 4 || a.gs > a.hs || (a.gs & (a.gs - 1)) || a.npos < 1 || a.ldo < a.F) {
-    set_error("magpo_sable_act: unsupported shape (1 <= A <= 8, n_block <= 4, n_head in {1,2,4}, K <= 64)");
+    set_error("magpo_sable_act: unsupported shape (1 <= A <= 8, n_block <= 4, n_head in {1,2,4}, K <= 31)");
     return MAGPO_EINVAL;
   }
   if (nptrs != 49 || nblk_ptrs != 21 * a.nb) { set_error("magpo_sable_act: pointer table size mismatch"); return MAGPO_EINVAL; }
@@ -53,18 +69,8 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
     B.gn2_g = (const float*)q[16]; B.gn2_b = (const float*)q[17];
     B.qkvg1 = (float*)q[18]; B.q2 = (float*)q[19]; B.kvg2 = (float*)q[20];
   }
-  // envs per wave, measured per launch on MI355X with device events (scripts/debug/act_epw_small.py, act_epw.py; A = 4, one block, 4 / 8 / 16
-  // envs per wave: N = 1024 -> 204 / 311 / 335 us, 2048 -> 237 / 331 / 348, 4096 -> 327 / 396 / 361, 8192 -> 606 / 553 / 434, 16384 -> 1360 / 922 / 698;
-  // A = 8, two blocks (before the one-wave bound of the 4-env waves): N = 1024 -> 1114 / 1363 / 1882, 4096 -> 1691 / 1679 / 2088, 16384 -> 5212 / 4905 / 2340): few envs per wave while the
-  // waves fit the chip's 1024 SIMDs (a rollout step is a latency chain per wave), full MFMA tiles and less weight traffic once they do not.
-  // All variants run at one wave per SIMD (512 registers, no scratch).
-  int epw;
-  if (a.A <= 4) epw = a.N > 4096 ? 16 : (a.N >= 4096 ? 8 : 4);   // (4096 envs, round 3 kernel: 290 / 270 / 328 us for 4 / 8 / 16)
-  else epw = a.N >= 16384 ? 16 : (a.N >= 4096 ? 8 : 4);
-  if (dims_host[11]) {   // envs per wave forced by the caller (A/B measurements); 0 = by size as above
-    if (dims_host[11] != 4 && dims_host[11] != 8 && dims_host[11] != 16) { set_error("magpo_sable_act: envs per wave must be 0, 4, 8 or 16"); return MAGPO_EINVAL; }
-    epw = dims_host[11];
-  }
+  const int epw = magpo_sable_act_envs_per_wave(a.N, a.A, dims_host[11]);
+  if (epw < 0) return MAGPO_EINVAL;
   if (epw == 16) launch_act<16>(a, st); else if (epw == 4) launch_act<4>(a, st); else launch_act<8>(a, st);
   return check_launch("magpo_sable_act");
 }

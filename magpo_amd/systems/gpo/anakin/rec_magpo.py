@@ -289,6 +289,8 @@ def run_experiment(_config) -> float:
             checkpointer.save(timestep=t, unreplicated_learner_state=learner_output.learner_state, episode_return=episode_return,
                               extras=dict(eval_step=eval_step, key_e=key_e.copy(), max_episode_return=max_episode_return,
                                           best_params=None if best_params is None else {k: v.cpu() for k, v in best_params.items()}))
+            mdist.barrier()      # every rank's file of this timestep is on disk: only now may older checkpoints go
+            checkpointer.prune()
         learner_state = learner_output.learner_state
 
     eval_performance = float(np.mean(eval_metrics[config.env.eval_metric])) if eval_metrics else float("nan")

@@ -9,6 +9,7 @@ import glob
 import json
 import os
 import time
+import warnings
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -36,9 +37,13 @@ def _to_cpu(x: Any) -> Any:
 
 
 def _atomic_save(obj: Any, path: str) -> None:
-    """Write next to the target and rename: a kill during the write leaves the previous file set intact (resumable sweeps)."""
+    """Write next to the target, flush to disk and rename: a kill (or a power loss) during the write leaves the previous file set
+    intact and never a renamed-but-empty file (resumable sweeps)."""
     tmp = path + ".tmp"
-    torch.save(obj, tmp)
+    with open(tmp, "wb") as f:
+        torch.save(obj, f)
+        f.flush()
+        os.fsync(f.fileno())
     os.replace(tmp, path)
 
 
@@ -68,19 +73,29 @@ class Checkpointer:
         self.kept: List[Tuple[float, int, str]] = []   # (episode_return, timestep, path)
         self.calls = 0
         if self.rank == 0:
-            # a relaunch into an existing directory (resume): the files of the previous run take part in the retention
+            # a relaunch into an existing directory (resume): the files of the previous run take part in the retention.  A file that
+            # does not load is NEVER deleted (the atomic write cannot leave a truncated {t}.pt, so a failure means something else: an
+            # older format, another torch version, a transient I/O error): it is set aside as {t}.pt.corrupt, like JsonLogger does.
             for f in list_checkpoints(self.dir):
                 try:
                     head = torch.load(f, map_location="cpu", weights_only=True)
                     self.kept.append((float(head.get("episode_return", 0.0)), int(head["timestep"]), f))
-                except Exception:   # truncated by a kill: not a checkpoint
-                    os.remove(f)
+                except Exception as e:
+                    warnings.warn(f"checkpoint {f} does not load ({e!r}); kept aside as {os.path.basename(f)}.corrupt")
+                    os.replace(f, f + ".corrupt")
+            # what a kill really leaves behind: temporaries of interrupted writes
+            for f in glob.glob(os.path.join(self.dir, "*.tmp")):
+                os.remove(f)
+            self._sweep_orphans()
             tmp = os.path.join(self.dir, "metadata.json.tmp")
             with open(tmp, "w") as f:
                 json.dump({"checkpointer_version": CHECKPOINTER_VERSION, **(metadata or {})}, f, indent=1, default=str)
             os.replace(tmp, os.path.join(self.dir, "metadata.json"))
 
     def save(self, timestep: int, unreplicated_learner_state: Any, episode_return: float = 0.0, extras: Optional[Dict] = None) -> bool:
+        """WRITE this rank's file(s) of ``timestep``.  Older checkpoints are removed by ``prune()``: a single-rank job prunes right
+        here; a multi-rank job calls ``prune()`` after a barrier behind every rank's ``save`` (run_experiment does), so that the
+        previous complete checkpoint set disappears only once the new one is complete."""
         self.calls += 1
         if (self.calls - 1) % self.interval:
             return False
@@ -93,18 +108,42 @@ class Checkpointer:
         _atomic_save({"learner_state": state, "timestep": int(timestep), "episode_return": float(episode_return), "world": self.world,
                       "extras": _to_cpu(extras)}, path)
         self.kept.append((float(episode_return), int(timestep), path))
-        if self.max_to_keep:
-            # keep the best `max_to_keep` by episode_return (ties: latest), like orbax best_fn / best_mode="max"
-            self.kept.sort(key=(lambda e: e[1]) if self.keep_latest else (lambda e: (e[0], e[1])))
-            while len(self.kept) > int(self.max_to_keep):
-                ret, ts, victim = self.kept[0]
-                if self.keep_period and ts % int(self.keep_period) == 0:
-                    break
-                self.kept.pop(0)
-                for f in [victim] + glob.glob(victim[:-3] + ".rank*.pt"):
-                    if os.path.exists(f):
-                        os.remove(f)
+        if self.world == 1:
+            self.prune()
         return True
+
+    def _complete(self, path: str) -> bool:
+        return os.path.exists(path) and all(os.path.exists(_rank_path(path, r)) for r in range(1, self.world))
+
+    def prune(self) -> None:
+        """Rank 0: keep the best ``max_to_keep`` checkpoints by episode_return (ties: latest), like orbax best_fn / best_mode="max".
+        Nothing is removed while the newest timestep's file set is incomplete (a rank has not written its file yet, or was killed
+        before it could): until then the previous complete set is the one a resume needs."""
+        if self.rank != 0 or not self.max_to_keep or not self.kept:
+            return
+        newest = max(self.kept, key=lambda e: e[1])[2]
+        if not self._complete(newest):
+            return
+        self.kept.sort(key=(lambda e: e[1]) if self.keep_latest else (lambda e: (e[0], e[1])))
+        while len(self.kept) > int(self.max_to_keep):
+            ret, ts, victim = self.kept[0]
+            if self.keep_period and ts % int(self.keep_period) == 0:
+                break
+            self.kept.pop(0)
+            for f in [victim] + glob.glob(victim[:-3] + ".rank*.pt"):
+                if os.path.exists(f):
+                    os.remove(f)
+        self._sweep_orphans()
+
+    def _sweep_orphans(self) -> None:
+        """Rank files {t}.rank{r}.pt whose {t}.pt is gone (pruned before that rank had renamed its file) and that are older than
+        the newest rank-0 file: never part of a loadable checkpoint again (~0.8 GB each at 16 384 envs)."""
+        heads = {int(os.path.basename(f)[:-3]) for f in list_checkpoints(self.dir)}
+        newest = max(heads) if heads else -1
+        for f in glob.glob(os.path.join(self.dir, "*.rank*.pt")):
+            t = os.path.basename(f).split(".")[0]
+            if t.isdigit() and int(t) not in heads and int(t) < newest:
+                os.remove(f)
 
 
 def list_checkpoints(cdir: str) -> List[str]:
@@ -128,17 +167,22 @@ def load_checkpoint(path: str) -> Dict[str, Any]:
     return _from_saved(torch.load(path, map_location="cpu", weights_only=True))
 
 
+def _check_world(ck: Dict[str, Any], path: str, world: int) -> None:
+    """A checkpoint belongs to the job size that wrote it -- checked for EVERY world size: a single process resuming an N-rank
+    checkpoint would silently continue rank 0's envs with 1/N of the batch and a different gradient mean."""
+    if int(ck.get("world", 1)) != int(world):
+        raise ValueError(f"{path} was written by a {ck.get('world', 1)}-rank job, this one has {world} rank(s)")
+
+
 def latest_valid_checkpoint(cdir: str, rank: int = 0, world: int = 1) -> str:
     """Newest checkpoint of ``cdir`` that loads (a truncated newest file -- the run was killed while writing -- falls back to the
     one before it) and, for a multi-rank job, whose rank files are all present."""
     for f in reversed(list_checkpoints(cdir)):
         try:
             ck = load_checkpoint(f)
-            if world > 1:
-                if int(ck.get("world", 1)) != world:
-                    raise ValueError(f"{f} was written by a {ck.get('world', 1)}-rank job, this one has {world} ranks")
-                for r in range(1, world):
-                    load_checkpoint(_rank_path(f, r))
+            _check_world(ck, f, world)
+            for r in range(1, world):
+                load_checkpoint(_rank_path(f, r))
             return f
         except ValueError:
             raise
@@ -157,8 +201,7 @@ def restore_learner_state(path: str, device="cuda", rank: int = 0, world: int = 
     from ..types import GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
     ck = load_checkpoint(path)
     st = ck["learner_state"]
-    if world > 1 and int(ck.get("world", 1)) != world:
-        raise ValueError(f"{path} was written by a {ck.get('world', 1)}-rank job, this one has {world} ranks")
+    _check_world(ck, path, world)
     if rank != 0:
         mine = load_checkpoint(_rank_path(path, rank))
         if int(mine["timestep"]) != int(ck["timestep"]):

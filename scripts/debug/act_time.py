@@ -23,11 +23,21 @@ def call(pending=True):
 call(False)
 for _ in range(3): call()
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps): call()
-e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / reps * 1e3
-alg = 6.0 * 16384 * nb * N
-print(f"N={N} A={A} nb={nb} K={K} epw={l.tuning.act_envs_per_wave or 'auto'} lib={os.path.basename(_lib.LIB_PATH)}: {us:8.1f} us per launch, "
-      f"{alg / us / 1e6:7.1f} GB/s algorithmic ({alg / us / 1e6 / 8000:.3f} of 8 TB/s)")
+# Device events around a burst of eager launches also see the HOST when it falls behind (a Python GC pause of ~75 ms inside a 40-launch
+# window reads as +1.9 ms per launch: the 2 333.8 us "outlier" of profiles/r03_act_kernel_launch_times.txt:6).  So: GC off, several
+# windows, min and median reported; a window far above the median is host time, not kernel time.
+import gc
+gc.disable()
+wins = []
+for w in range(int(os.environ.get("WINDOWS", 7))):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): call()
+    e1.record(); torch.cuda.synchronize()
+    wins.append(e0.elapsed_time(e1) / reps * 1e3)
+wins.sort()
+us, med = wins[0], wins[len(wins) // 2]
+alg = 6.0 * 16384 * nb * N   # bytes: three 16 KiB states per block read + written once per env step
+epw = _lib.lib().call("magpo_sable_act_envs_per_wave", N, A, l.tuning.act_envs_per_wave)
+print(f"N={N} A={A} nb={nb} K={K} epw={epw}{'' if l.tuning.act_envs_per_wave else ' (auto)'} lib={os.path.basename(_lib.LIB_PATH)}: min {us:8.1f} us per launch "
+      f"(median {med:.1f}, max {wins[-1]:.1f} over {len(wins)} windows of {reps}), {alg / us / 1e6:7.3f} TB/s algorithmic ({alg / us / 1e6 / 8:.3f} of 8 TB/s)")

@@ -197,12 +197,67 @@ def test_checkpoints_are_safe_atomic_rank_aware_and_resumable(tmp_path):
     assert latest_valid_checkpoint(d, 0, 2).endswith("200.pt")
     os.remove(os.path.join(d, "200.rank1.pt"))
     assert latest_valid_checkpoint(d, 1, 2).endswith("100.pt")
-    # (3) relaunch: the truncated file is dropped, the old files are ranked, retention removes a timestep's files together
+    # (3) relaunch: the file that does not load is set aside (never deleted), the old files are ranked, retention removes a
+    # timestep's files together -- and only once the newest timestep's file set is complete
     ck = Checkpointer("rec_magpo", base_path=str(tmp_path), max_to_keep=2, keep_latest=True, checkpoint_uid="u", rank=0, world=2)
-    assert [k[1] for k in ck.kept] == [100, 200] and not os.path.exists(os.path.join(d, "300.pt"))
+    assert [k[1] for k in ck.kept] == [100, 200] and not os.path.exists(os.path.join(d, "300.pt")) and os.path.exists(os.path.join(d, "300.pt.corrupt"))
     ck.save(400, mk(400), episode_return=1.0)
-    assert sorted(os.listdir(d)) == ["200.pt", "400.pt", "metadata.json"]
+    ck.prune()
+    assert {"100.pt", "100.rank1.pt", "200.pt", "400.pt"} <= set(os.listdir(d)), "rank 1 has not written 400 yet: nothing may be pruned"
+    Checkpointer("rec_magpo", base_path=str(tmp_path), checkpoint_uid="u", rank=1, world=2).save(400, mk(400, 1))
+    ck.prune()
+    assert sorted(os.listdir(d)) == ["200.pt", "300.pt.corrupt", "400.pt", "400.rank1.pt", "metadata.json"]
     assert not [f for f in os.listdir(d) if f.endswith(".tmp")]
+    # (4b) the rank count is checked for a single process too
+    with pytest.raises(ValueError):
+        restore_learner_state(os.path.join(d, "400.pt"), "cpu", rank=0, world=1)
+    with pytest.raises(ValueError):
+        latest_valid_checkpoint(d, 0, 1)
+
+
+def test_checkpointer_never_deletes_what_it_cannot_load_and_survives_a_kill_between_the_ranks_saves(tmp_path):
+    """(1) a pre-existing checkpoint in another format (pickled numpy keys: not weights_only-loadable) survives the
+    construction of a Checkpointer in its directory, stale ``*.tmp`` files of interrupted writes are what gets cleaned;
+    (2) max_to_keep = 1, two ranks, the job is killed after rank 0 wrote timestep 200 and before rank 1 did: the complete
+    checkpoint 100 must still be there and is what a resume finds; (3) orphan rank files of pruned timesteps are collected."""
+    from magpo_amd.types import GPOLearnerState, HiddenStates, OptStates, Params, SableHiddenStates
+    from magpo_amd.utils.checkpointing import Checkpointer, latest_valid_checkpoint
+
+    def mk(v, r=0):
+        hs = HiddenStates(SableHiddenStates(*[torch.full((1, 1, 1, 2, 4, 4), float(v + r))] * 3), torch.full((1, 6, 128), float(r)))
+        return GPOLearnerState(Params({"w": torch.full((3,), float(v))}, {"k": torch.zeros(2)}),
+                               OptStates(dict(count=7, mu=torch.zeros(3), nu=torch.zeros(3)), dict(count=7, mu=torch.zeros(2), nu=torch.zeros(2))),
+                               np.array([v, 100 + r], np.uint32), {"step_count": torch.full((1, 2), r, dtype=torch.int32)},
+                               {"agents_view": torch.full((1, 2, 3, 4), float(r))}, torch.zeros(1, 2, dtype=torch.uint8), hs)
+    d = os.path.join(tmp_path, "checkpoints", "rec_magpo", "u")
+    os.makedirs(d)
+    torch.save({"learner_state": {"key": np.array([1, 2], np.uint32)}, "timestep": 50}, os.path.join(d, "50.pt"))   # r02 format
+    open(os.path.join(d, "60.pt.tmp"), "wb").write(b"partial")
+    open(os.path.join(d, "metadata.json.tmp"), "w").write("{")
+    with pytest.warns(UserWarning, match="does not load"):
+        cks = [Checkpointer("rec_magpo", base_path=str(tmp_path), max_to_keep=1, checkpoint_uid="u", rank=r, world=2) for r in range(2)][:2]
+    assert os.path.exists(os.path.join(d, "50.pt.corrupt")) and not [f for f in os.listdir(d) if f.endswith(".tmp")]
+    old = torch.load(os.path.join(d, "50.pt.corrupt"), weights_only=False)
+    assert old["timestep"] == 50
+    for r in (0, 1):
+        cks[r].save(100, mk(100, r), episode_return=1.0)
+    cks[0].prune()
+    cks[0].save(200, mk(200, 0), episode_return=2.0)      # ... and the job dies before rank 1 writes 200.rank1.pt
+    cks[0].prune()                                        # (even if rank 0 got this far)
+    assert {"100.pt", "100.rank1.pt", "200.pt"} <= set(os.listdir(d))
+    assert latest_valid_checkpoint(d, 1, 2).endswith("100.pt")
+    # relaunch; this time both ranks get through timestep 300, and 300 (better return) replaces 100; the half-written 200 goes too
+    cks = [Checkpointer("rec_magpo", base_path=str(tmp_path), max_to_keep=1, checkpoint_uid="u", rank=r, world=2) for r in range(2)]
+    open(os.path.join(d, "10.rank1.pt"), "wb").write(b"orphan of a pruned timestep")
+    for r in (1, 0):
+        cks[r].save(300, mk(300, r), episode_return=3.0)
+    cks[0].prune()
+    assert sorted(f for f in os.listdir(d) if f.endswith(".pt")) == ["300.pt", "300.rank1.pt"]
+    # a checkpoint that is NOT the best is itself the victim: its rank files go with it, nothing is orphaned
+    for r in (0, 1):
+        cks[r].save(400, mk(400, r), episode_return=0.5)
+    cks[0].prune()
+    assert sorted(f for f in os.listdir(d) if f.endswith(".pt")) == ["300.pt", "300.rank1.pt"]
 
 
 def test_tuning_defaults_and_environment_switches():

@@ -124,13 +124,17 @@ def test_rware_learner_parity(E, nh, nb):
     # gradient sits at the fp32 noise floor of its tensor (|g| ~ 1e-5 x the largest, where the gradient check above allows 100 % relative
     # error) moves by a different fraction of lr on the two sides: with the three-block net 2 of the 16 384 elements of enc.block2.retn.w_k
     # differ by 0.3 lr, everything else by < 0.02 lr (scripts/debug/rware_update_err.py; mechanism: profiles/r03_step2_sensitivity_fp64.txt).
-    # Bound: every element within ONE Adam step (lr), and at most 0.1 % of a tensor's elements beyond 3e-5.
+    # Bound: 3e-5 flat (as for CoordSum) for the one-block nets; ONLY the three-block net, and there only the retention projections of
+    # its last encoder block (the stiff direction of DESIGN 2b), may hold elements within ONE Adam step (lr), at most 0.1 % of a tensor.
     lr = 2.5e-4
     for net, ref in ((dl.guider, ol.gp), (dl.actor, ol.ap)):
         for n, v in net.named.items():
             d = (v.detach().cpu().double().reshape(-1) - ref[n].reshape(v.shape).double().reshape(-1)).abs()
-            assert d.max().item() <= lr, f"param {n}: max err {d.max().item():.3e}"
-            assert int((d > 3e-5).sum()) <= max(0, d.numel() // 1000), f"param {n}: {int((d > 3e-5).sum())} of {d.numel()} elements beyond 3e-5"
+            if nb == 3 and net is dl.guider and n.startswith("enc.block2.retn."):
+                assert d.max().item() <= lr, f"param {n}: max err {d.max().item():.3e}"
+                assert int((d > 3e-5).sum()) <= max(0, d.numel() // 1000), f"param {n}: {int((d > 3e-5).sum())} of {d.numel()} elements beyond 3e-5"
+            else:
+                assert d.max().item() <= 3e-5, f"param {n}: max err {d.max().item():.3e}"
 
 
 def test_rware_evaluator_and_entry_point(tmp_path):
