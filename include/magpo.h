@@ -202,9 +202,14 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
  *   xa kin1 y1 c cpe y2 xo xope hp hn logits ([N] rows) | u1 u2 ([N*A] rows) | prev [N][A] i32 | action [N][A] i32, logp, value [N][A] |
  *   ptab [N][K + 2][64] scratch (n_head = 1: block-0 self-retention candidate table);
  * blk_ptrs_host[21 * n_block]: qkvg_t wo_t ln1 ln2 gn_g gn_b | qkvg1_t wo1_t dln1 gn1_g gn1_b | q2_t kvg2_t wo2_t dln2 dln3 gn2_g gn2_b |
- *   scratch qkvg1 [N*A][256], q2 [N*A][64], kvg2 [N*A][256] (rows [k | v | - | q2 (kappa S)]).   (*_t = transposed weights as produced by magpo_transpose_pad) */
+ *   scratch qkvg1 [N*A][256], q2 [N*A][64], kvg2 [N*A][256] (rows [k | v | - | q2 (kappa S)]).
+ *   *_t = the transposed weights of magpo_transpose_pad in the FRAGMENT-MAJOR layout of magpo_act_weight_layout (below): a wave streams
+ *   its weight fragments from L2 for every token, and one fragment load must be 1 KB contiguous for that stream to run at the L1 rate. */
 int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs_host,
                     int nptrs, const void* const* blk_ptrs_host, int nblk_ptrs, magpo_stream_t stream);
+/* Wf[g][gk][lane = m + 16 kq][c] = Wt[16 g + m][16 gk + 4 kq + c] for a transposed weight Wt [nrows][64] (nrows a multiple of 16):
+ * the weight operand layout of magpo_sable_act.  Rebuilt by the host after every parameter update (SableGuider.build_act_weights). */
+int magpo_act_weight_layout(const float* Wt, float* Wf, int nrows, magpo_stream_t stream);
 /* Envs per wave (4, 8 or 16) of the launch magpo_sable_act makes for N envs of A agents; forced = dims_host[11] (0 = chosen by size).
  * The kernel instance is k_sable_act<envs per wave, A <= 4 ? 4 : 8, (n_head == 1 && A <= 4) ? 1 : 0>.  Returns -1 for an invalid `forced`.
  * Shape limits of magpo_sable_act: 1 <= A <= 8, n_block <= 4, n_head in {1, 2, 4}, K <= 31 (the candidate pre-pass holds K + 2 <= 48 rows). */

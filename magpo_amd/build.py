@@ -19,18 +19,25 @@ def _newer(src, dst):
     return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
-def build(force: bool = False, verbose: bool = False, out: str = OUT, extra_flags=(), build_dir: str = BUILD) -> str:
+def build(force: bool = False, verbose: bool = False, out: str = OUT, extra_flags=(), build_dir: str = BUILD, only: str = "") -> str:
     """``out`` / ``extra_flags`` / ``build_dir``: experiment builds (debug timers, A/B macros) next to the product library, e.g.
-    ``python -m magpo_amd.build --out exp_libs/prof.so --flags=-DMAGPO_ACT_PROF`` (scripts pick them up through MAGPO_LIB)."""
+    ``python -m magpo_amd.build --out exp_libs/prof.so --flags=-DMAGPO_ACT_PROF`` (scripts pick them up through MAGPO_LIB).
+    ``only`` (experiment builds): comma-separated source-name prefixes that are compiled with the extra flags; every other object is
+    taken from the product build directory as it is (``--only act_fused``: 4 translation units instead of 19)."""
     os.makedirs(build_dir, exist_ok=True)
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.hpp"))
     objs, jobs = [], []
+    pref = tuple(p for p in only.split(",") if p)
     for s in srcs:
-        o = os.path.join(build_dir, os.path.basename(s)[:-4] + ".o")
+        name = os.path.basename(s)[:-4]
+        if pref and not name.startswith(pref):
+            objs.append(os.path.join(BUILD, name + ".o"))   # the product build's object
+            continue
+        o = os.path.join(build_dir, name + ".o")
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
+        if force or pref or _newer(s, o) or any(_newer(h, o) for h in hdrs):
             jobs.append([HIPCC, *FLAGS, *extra_flags, "-c", s, "-o", o])
 
     def run(cmd):
@@ -53,6 +60,7 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--out", default=OUT)
     ap.add_argument("--flags", default="")
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
     bd = BUILD if a.out == OUT else os.path.join(BUILD, "exp_" + os.path.basename(a.out).replace(".so", ""))
-    print(build(force=a.force, verbose=True, out=a.out, extra_flags=a.flags.split(), build_dir=bd))
+    print(build(force=a.force, verbose=True, out=a.out, extra_flags=a.flags.split(), build_dir=bd, only=a.only))

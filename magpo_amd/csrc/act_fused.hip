@@ -25,6 +25,21 @@ extern "C" int magpo_sable_act_envs_per_wave(int N, int A, int forced) {
   return N >= 16384 ? 16 : (N >= 4096 ? 8 : 4);
 }
 
+// Fragment-major copy of a transposed weight for the acting kernel (fm_rows.hpp: wfrag<true>):
+//   Wf[g][gk][lane = m + 16 kq][c] = Wt[16 g + m][16 gk + 4 kq + c],   g < nrows / 16, gk / kq / c < 4, m < 16
+__global__ void k_act_weight_layout(const float* __restrict__ Wt, float* __restrict__ Wf, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = i >> 10, r = i & 1023, gk = r >> 8, lane = (r & 255) >> 2, c = r & 3, m = lane & 15, kq = lane >> 4;
+  Wf[i] = Wt[(16 * g + m) * 64 + 16 * gk + 4 * kq + c];
+}
+extern "C" int magpo_act_weight_layout(const float* Wt, float* Wf, int nrows, hipStream_t st) {
+  if (nrows <= 0 || (nrows & 15)) { set_error("magpo_act_weight_layout: nrows must be a positive multiple of 16"); return MAGPO_EINVAL; }
+  const int n = nrows * 64;
+  hipLaunchKernelGGL(k_act_weight_layout, dim3((n + 255) / 256), dim3(256), 0, st, Wt, Wf, n);
+  return check_launch("magpo_act_weight_layout");
+}
+
 // Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
 //   dims_host[14] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride, envs per wave, pending, flush}; kappa_host[4];
 //   keys_host [A][2] or NULL (then ptrs[3] = device key table);  ptrs_host[49] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
@@ -77,8 +92,8 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
 
 #ifdef MAGPO_ACT_PROF
 extern "C" int magpo_debug_act_prof(unsigned long long* out_host, int reset) {
-  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_act_prof), sizeof(unsigned long long) * 16) != hipSuccess) return MAGPO_ELAUNCH;
-  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_act_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(magpo::g_act_prof), sizeof(unsigned long long) * 32) != hipSuccess) return MAGPO_ELAUNCH;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(magpo::g_act_prof), z, sizeof(z)) != hipSuccess) return MAGPO_ELAUNCH; }
   return MAGPO_OK;
 }
 #endif

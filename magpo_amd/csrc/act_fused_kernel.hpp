@@ -84,7 +84,7 @@ struct ActArgs {
 };
 
 #ifdef MAGPO_ACT_PROF
-__device__ unsigned long long g_act_prof[16];
+__device__ unsigned long long g_act_prof[32];
 #define RT_DECL() unsigned long long rt_acc[5] = {0, 0, 0, 0, 0}; unsigned long long rt_last = clock64();
 #define RT(k) do { unsigned long long t_ = clock64(); rt_acc[k] += t_ - rt_last; rt_last = t_; } while (0)
 #define RT_FLUSH() do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&g_act_prof[8 + k_], rt_acc[k_]); } } while (0)
@@ -396,7 +396,10 @@ __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* 
 // hist (NA > 4 only): the k | v history rows of this env (token t at hist + t * 256, v at + 64) are then streamed through two row
 // pairs (one in use, one in flight) instead of being held for all NA - 1 earlier agents at once: 14 rows = 224 VGPRs for 8-agent
 // teams, which the register file does not have beside the state buffers (249 values went to scratch).
-template <int NH, int NA, bool STREAM = (NA > 4)>
+#ifndef MAGPO_ACT_STREAM4
+#define MAGPO_ACT_STREAM4 0   // 1: the k | v history rows of the earlier agents are streamed for teams of <= 4 agents too (register relief)
+#endif
+template <int NH, int NA, bool STREAM = (NA > 4 || MAGPO_ACT_STREAM4)>
 __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const Row& kc, const Row& vc, const Row& gc, const Row& p2,
                                          const Row (&hk)[NA - 1], const Row (&hv)[NA - 1], int i, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, int kq, const float* __restrict__ hist = nullptr) {
@@ -464,8 +467,10 @@ __device__ __forceinline__ Row cross_ret(const ActArgs& a, const Row& q, const R
   return u;
 }
 
-// Optional in-kernel stage timing (debug builds only: -DMAGPO_ACT_PROF): wall-clock ticks (100 MHz) per stage class
-// [0 dense/rows, 1 retention, 2 sampling, 3 encoder total] summed over every 64th wave.
+// Optional in-kernel stage timing (debug builds only: -DMAGPO_ACT_PROF): wall-clock ticks (100 MHz) per stage, summed over every 64th wave:
+// 0 encoder embedding + q|k|v|g GEMM, 1 encoder state pass, 2 encoder W_o / norms / value head / q2, 4 decoder pre-pass: candidate table,
+// 19 decoder pre-pass: cross-retention states, 5 decoder: action embedding + q|k|v|g GEMM + self-retention terms, 6 W_o1 + norm + k|v|g GEMM +
+// cross-retention terms, 7 W_o2 + norms + head, 16 sampling, 17 / 18 per-agent state pass of blocks > 0 (8..12: sub-stages of the state passes).
 #ifdef MAGPO_ACT_PROF
 #define PROF(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { unsigned long long t_ = wall_clock64(); \
   atomicAdd(&g_act_prof[k], t_ - t_last); t_last = t_; } } while (0)
@@ -497,8 +502,14 @@ constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
 #define MAGPO_ACT_NBUF_CAND 2
 #endif
 
+#ifndef MAGPO_ACT_STAGGER
+#define MAGPO_ACT_STAGGER 1   // 1: half of the workgroups run the candidate pre-pass ahead of the encoder (see cand_early)
+#endif
+#ifndef MAGPO_ACT_WPE
+#define MAGPO_ACT_WPE 1   // waves per SIMD the register allocation aims at (A/B hook)
+#endif
 template <int EPW, int NA, int NH>
-__global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
+__global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* TQ = smem;                  // [EPW][QP]  this iteration's [q|k|v|g] rows, one per env
   float* HK = TQ + EPW * QP;         // [A][QP]    staged token rows of the env being processed
@@ -526,35 +537,86 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
   float4 pS[16];
   if (MAGPO_ACT_PRIME) prime_state(pS, a.S_enc + (long)env0 * 4096, lane);
 
+  // candidate path of the block-0 self-retention: one head (the state tile is the whole 64 x 64 matrix)
+  const bool cand = nh_ == 1;
+  // The candidate pre-pass (block-0 self-retention states: a third of the launch's state traffic) depends on the previous launch's pending
+  // rows and on parameters only -- not on this step's encoder.  All waves start together and walk the same phases, so the chip alternates
+  // between phases in which every wave streams states (HBM-bound, ~5 TB/s) and dense phases in which none does.  STAGGER: every other
+  // group of 8 workgroups runs the candidate pre-pass FIRST, so that one half of the waves streams while the other half computes.
+  const bool cand_early = cand && !a.value_only && MAGPO_ACT_STAGGER && ((blockIdx.x >> 3) & 1);
+  auto cand_pass = [&]() __attribute__((always_inline)) {
+    const ActBlk& B = a.blk[0];
+    float4 pS1[16];   // the first self-retention state of the candidate pass
+      // candidate query rows q_c = x_c W_q (tile row = candidate) and the positional query rows pe W_q of this wave's envs
+    const Row qpe = dense64<true>(pe, B.qkvg1_t, nullptr, m, kq);
+    row_store(PEQ + env * 64, kq, qpe);
+    lsync();
+    const int ntile = (a.K + 2 + 15) >> 4;
+#define CAND_ROWS(MT_)                                                                                                        \
+    {                                                                                                                        \
+      prime_state_perm(pS1, a.S_d1 + (long)env0 * 4096, lane);                                                               \
+      Row xq[MT_];                                                                                                           \
+      _Pragma("unroll") for (int mt = 0; mt < MT_; ++mt) {                                                                   \
+        const int c = min(16 * mt + env, a.K);                                                                               \
+        xq[mt] = dense64<true>(row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq), B.qkvg1_t, nullptr, m, kq); \
+      }                                                                                                                      \
+      self_prepass_cand<NA, MT_, (EPW == 16 ? MAGPO_ACT_NBUF_CAND : 2)>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask, pS1);                                 \
+    }
+    if (ntile == 1) CAND_ROWS(1) else if (ntile == 2) CAND_ROWS(2) else CAND_ROWS(3)
+#undef CAND_ROWS
+  };
+  if (cand_early) { cand_pass(); wsync(); PROF(4); }
+
   // ---------------- encoder over the A tokens of the step (act_encoder_fn, encode.py:58-84)
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
-    for (int t = 0; t < A; ++t) {
-      const long row = ge * A + t;
-      Row x;
-      if (b == 0) {   // x = rms(gelu(rmsnorm_F(obs) * s_obs @ W_obs)) * s_encln   (sable_network.py:93-101,126,132)
-        const float* o = a.obs + row * a.ldo;
-        float ms = 0.f;
-        for (int f = 0; f < a.F; ++f) ms += o[f] * o[f];
-        const float rstd = rsqrtf(ms / (float)a.F + EPSN);
-        Row z;
+    // the A tokens of the step go through every layer TOGETHER, four at a time: each weight fragment is fetched once for the four
+    // rows (wgemm_multi) -- the wave streams its weights from L2, and that stream, not the MFMAs, is what the dense phases wait for
+    for (int t0 = 0; t0 < A; t0 += 4) {
+      const int nt = min(4, A - t0);
+      Row kin[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) z.v[j] = 0.f;
-        for (int f = 0; f < a.F; ++f) {
-          const float of = o[f] * rstd * a.s_obs[f];
-          const Row w = row_load(a.W_obs + f * AE, kq);
+      for (int tt = 0; tt < 4; ++tt) {
+        const long row = ge * A + min(t0 + tt, A - 1);   // rows past the team shadow its last token (nothing of them is stored)
+        Row x;
+        if (b == 0) {   // x = rms(gelu(rmsnorm_F(obs) * s_obs @ W_obs)) * s_encln   (sable_network.py:93-101,126,132)
+          // rmsnorm_F(obs) * s_obs @ W_obs = rstd * sum_f (o_f s_f) W_obs[f]: one pass over the features, four at a time with their loads
+          // issued together (a run-time loop of dependent scalar loads costs one memory round trip per feature on a lone wave)
+          const float* o = a.obs + row * a.ldo;
+          float ms = 0.f;
+          Row z;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) z.v[j] += of * w.v[j];
+          for (int j = 0; j < 16; ++j) z.v[j] = 0.f;
+          for (int f0 = 0; f0 < a.F; f0 += 4) {
+            float ov[4], sv[4];
+            Row w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int fi = min(f0 + u, a.F - 1);
+              ov[u] = o[fi]; sv[u] = a.s_obs[fi];
+              w[u] = row_load(a.W_obs + fi * AE, kq);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float oq = f0 + u < a.F ? ov[u] : 0.f;
+              ms += oq * oq;
+              const float c = oq * sv[u];
+#pragma unroll
+              for (int j = 0; j < 16; ++j) z.v[j] += c * w[u].v[j];
+            }
+          }
+          const float rstd = rsqrtf(ms / (float)a.F + EPSN);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) z.v[j] *= rstd;
+          x = row_rms(row_gelu(z), a.s_encln, kq);
+        } else {        // x = ln(rep of the previous block) (shared self.ln, sable_network.py:150)
+          x = row_rms(row_load(a.rep + row * AE, kq), a.s_encln, kq);
         }
-        x = row_rms(row_gelu(z), a.s_encln, kq);
-      } else {        // x = ln(rep of the previous block) (shared self.ln, sable_network.py:150)
-        x = row_rms(row_load(a.rep + row * AE, kq), a.s_encln, kq);
+        if (valid && tt < nt) row_store(a.xn + row * AE, kq, x);
+        kin[tt] = row_add(x, pe);
       }
-      if (valid) row_store(a.xn + row * AE, kq, x);
-      const Row kin = row_add(x, pe);
-      float* qrow = a.qkvg + row * 256;
-      wgemm<16>(kin, B.qkvg_t, m, kq, [&](int g, f32x4 acc) {
-        if (valid) st4g(qrow + 16 * g + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));
+      wgemm_multi<16, 4, true>(kin, nt, B.qkvg_t, m, kq, [&](int tt, int g, f32x4 acc) {
+        if (valid && tt < nt) st4g(a.qkvg + (ge * A + t0 + tt) * 256 + 16 * g + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));
       });
     }
     wsync();
@@ -565,36 +627,54 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
     if (MAGPO_ACT_PRIME && b == nb - 1 && !a.value_only) prime_state(pS, a.S_d2 + (long)env0 * 4096, lane);
     wsync();
     PROF(1);
-    for (int t = 0; t < A; ++t) {
-      const long row = ge * A + t;
-      const Row y = dense64(row_load(a.u + row * AE, kq), B.wo_t, nullptr, m, kq);
-      const Row x = row_load(a.xn + row * AE, kq);
-      const Row rep = row_rms(row_rms(row_add(x, y), B.ln1, kq), B.ln2, kq);
-      if (valid) row_store(a.rep + row * AE, kq, rep);
-      if (b == nb - 1) {
-        const Row hv = row_rms(row_gelu(dense64(rep, a.vh0_t, a.vh0_b, m, kq)), a.vh_s, kq);
-        const Row w = row_load(a.vh_w, kq);
-        Row hw;
+    for (int t0 = 0; t0 < A; t0 += 4) {
+      const int nt = min(4, A - t0);
+      Row rep[4];
+      {
+        Row uu[4], y[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) hw.v[j] = hv.v[j] * w.v[j];
-        const float val = row_sum(hw) + a.vh_b1[0];
-        if (valid && kq == 0) a.value[row] = val;
+        for (int tt = 0; tt < 4; ++tt) uu[tt] = row_load(a.u + (ge * A + min(t0 + tt, A - 1)) * AE, kq);
+        dense64_multi<4, true>(uu, nt, y, B.wo_t, nullptr, m, kq);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const long row = ge * A + min(t0 + tt, A - 1);
+          const Row x = row_load(a.xn + row * AE, kq);
+          rep[tt] = row_rms(row_rms(row_add(x, y[tt]), B.ln1, kq), B.ln2, kq);
+          if (valid && tt < nt) row_store(a.rep + row * AE, kq, rep[tt]);
+        }
+      }
+      if (b == nb - 1) {
+        {
+          Row hv[4];
+          dense64_multi<4, true>(rep, nt, hv, a.vh0_t, a.vh0_b, m, kq);
+          const Row w = row_load(a.vh_w, kq);
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            const Row h = row_rms(row_gelu(hv[tt]), a.vh_s, kq);
+            Row hw;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hw.v[j] = h.v[j] * w.v[j];
+            const float val = row_sum(hw) + a.vh_b1[0];
+            if (valid && kq == 0 && tt < nt) a.value[ge * A + t0 + tt] = val;
+          }
+        }
         if (!a.value_only) {
-          const Row reppe = row_add(rep, pe);
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) rep[tt] = row_add(rep[tt], pe);   // reppe
           for (int db = 0; db < nb; ++db) {
-            const Row q2 = dense64(reppe, a.blk[db].q2_t, nullptr, m, kq);
-            if (valid) row_store(a.blk[db].q2 + row * AE, kq, q2);
+            float* q2o = a.blk[db].q2;
+            wgemm_multi<4, 4, true>(rep, nt, a.blk[db].q2_t, m, kq, [&](int tt, int g, f32x4 acc) {
+              if (valid && tt < nt) st4g(q2o + (ge * A + t0 + tt) * AE + 16 * g + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));
+            });
           }
         }
       }
     }
     wsync();
-    PROF(0);
+    PROF(2);
   }
   PROF(3);
   constexpr int NBF = EPW == 16 ? ACT_NBUF16 : 2;
-  // candidate path of the block-0 self-retention: one head (the state tile is the whole 64 x 64 matrix)
-  const bool cand = nh_ == 1;
   // flush: S <- kappa S + sum_a k_a^T v_a with the rows in the scratch (this launch's, or the pending ones of the previous launch)
   auto flush_states = [&]() {
     wsync();
@@ -613,39 +693,27 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
   // zeroing), written back, and gives from registers what the decoder needs from kappa S
   for (int b = 0; b < nb; ++b) {
     const ActBlk& B = a.blk[b];
-    float4 pS1[16];   // block 0, one head: the first self-retention state of the candidate pass
     if (b == 0) ret_pass<4, NA, (EPW == 16 ? MAGPO_ACT_NBUF_PRE : 2), NH, MAGPO_ACT_PRIME != 0>(TQ, HK, U, a.S_d2, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
                                                B.q2, AE, a.pending, pS);
     else ret_pass<4, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, B.kvg2 + 192, 256, B.gn2_g, B.gn2_b, 1, dmask,
                                   B.q2, AE, a.pending);
+    PROF(19);
     if (b == 0 && cand) {
-      // candidate query rows q_c = x_c W_q (tile row = candidate) and the positional query rows pe W_q of this wave's envs
-      const Row qpe = dense64(pe, B.qkvg1_t, nullptr, m, kq);
-      row_store(PEQ + env * 64, kq, qpe);
-      lsync();
-      const int ntile = (a.K + 2 + 15) >> 4;
-#define CAND_ROWS(MT_)                                                                                                        \
-      {                                                                                                                        \
-        prime_state_perm(pS1, a.S_d1 + (long)env0 * 4096, lane);                                                               \
-        Row xq[MT_];                                                                                                           \
-        _Pragma("unroll") for (int mt = 0; mt < MT_; ++mt) {                                                                   \
-          const int c = min(16 * mt + env, a.K);                                                                               \
-          xq[mt] = dense64(row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq), B.qkvg1_t, nullptr, m, kq); \
-        }                                                                                                                      \
-        self_prepass_cand<NA, MT_, (EPW == 16 ? MAGPO_ACT_NBUF_CAND : 2)>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask, pS1);                                 \
-      }
-      if (ntile == 1) CAND_ROWS(1) else if (ntile == 2) CAND_ROWS(2) else CAND_ROWS(3)
-#undef CAND_ROWS
+      if (!cand_early) cand_pass();
     } else {
       ret_pass<5, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 1, dmask,
                                nullptr, 0, a.pending);
     }
   }
   wsync();
-  PROF(1);
+  PROF(4);
 
   // ---------------- autoregressive decoder (decode.py:111-153): token i of every env
   int prev = 0;   // 0 = start token, action + 1 afterwards
+  // Weight fragments are requested one layer AHEAD of their use (wload / wgemm_pre, fm_rows.hpp): the first fragments of a layer fly
+  // while the previous layer's MFMAs and row math run; those of the next agent's first layer while this agent is being sampled.
+  // (Requesting a layer's first weight fragments one layer ahead -- wload / wgemm_pre, fm_rows.hpp -- was built and measured in round 4:
+  // the kernel sits at its 512 registers, every 64 more end in scratch, and all variants were slower: 549 - 577 us against 537.)
   for (int i = 0; i < A; ++i) {
     const long row = ge * A + i;
     Row xo;
@@ -663,7 +731,7 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
         const Row kin = row_add(xin, pe);
         Row q1, k1, v1, g1;
         float* hrow = B.qkvg1 + row * 256;
-        wgemm<16>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
+        wgemm<16, true>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             if (g < 4) q1.v[4 * g + c] = acc[c];
@@ -674,15 +742,15 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
           if (valid && g >= 4 && g < 12) st4g(hrow + 16 * g + 4 * kq, make_float4(acc[0], acc[1], acc[2], acc[3]));   // k, v: history / pending rows
         });
         const Row u1 = cross_ret<NH, NA, true>(a, q1, k1, v1, g1, row_add(pc, pp), hk1, hv1, i, B.gn1_g, B.gn1_b, kq, B.qkvg1 + ge * A * 256 + 64);
-        PROF(0);
-        const Row y1 = dense64(u1, B.wo1_t, nullptr, m, kq);
+        PROF(5);
+        const Row y1 = dense64<true>(u1, B.wo1_t, nullptr, m, kq);
         cpe = row_add(row_rms(row_add(xin, y1), B.dln1, kq), pe);
       } else {
         if (valid) row_store(XS + env * UP, kq, xin);
         {
           const Row kin = row_add(xin, pe);
           float* hrow = B.qkvg1 + row * 256;
-          wgemm<16>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
+          wgemm<16, true>(kin, B.qkvg1_t, m, kq, [&](int g, f32x4 acc) {
             const float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
             if (valid) {
               *reinterpret_cast<float4*>(TQ + env * QP + 16 * g + 4 * kq) = v4;
@@ -691,12 +759,12 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
           });
         }
         wsync();
-        PROF(0);
+        PROF(17);
         // the state in memory is the one that entered this step (pre-pass): no zeroing, never written here
         ret_pass<1, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, i, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 0, 0ull);
         wsync();
-        PROF(1);
-        const Row y1 = dense64(row_load(U + le * UP, kq), B.wo1_t, nullptr, m, kq);
+        PROF(18);
+        const Row y1 = dense64<true>(row_load(U + le * UP, kq), B.wo1_t, nullptr, m, kq);
         cpe = row_add(row_rms(row_add(row_load(XS + le * UP, kq), y1), B.dln1, kq), pe);
       }
       {
@@ -706,13 +774,13 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
         Row hk2[NA - 1], hv2[NA - 1];
 #pragma unroll
         for (int t = 0; t < NA - 1; ++t) {
-          if (NA <= 4 && t < i) { hk2[t] = row_load(B.kvg2 + (ge * A + t) * 256, kq); hv2[t] = row_load(B.kvg2 + (ge * A + t) * 256 + 64, kq); }
+          if (NA <= 4 && !MAGPO_ACT_STREAM4 && t < i) { hk2[t] = row_load(B.kvg2 + (ge * A + t) * 256, kq); hv2[t] = row_load(B.kvg2 + (ge * A + t) * 256 + 64, kq); }
         }
         const Row p2 = row_load(B.kvg2 + row * 256 + 192, kq);
         const Row q2 = row_load(B.q2 + row * AE, kq);
         Row k2, v2, g2;
         float* hrow = B.kvg2 + row * 256;
-        wgemm<12>(cpe, B.kvg2_t, m, kq, [&](int g, f32x4 acc) {
+        wgemm<12, true>(cpe, B.kvg2_t, m, kq, [&](int g, f32x4 acc) {
           const float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -723,20 +791,20 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
           if (valid && g < 8) st4g(hrow + 16 * g + 4 * kq, v4);   // k, v of this token: history for the later agents / the state update
         });
         const Row u2 = cross_ret<NH, NA>(a, q2, k2, v2, g2, p2, hk2, hv2, i, B.gn2_g, B.gn2_b, kq, B.kvg2 + ge * A * 256);
-        PROF(0);
-        const Row y2 = dense64(u2, B.wo2_t, nullptr, m, kq);
+        PROF(6);
+        const Row y2 = dense64<true>(u2, B.wo2_t, nullptr, m, kq);
         const Row repi = row_load(a.rep + row * AE, kq);
         xo = row_rms(row_rms(row_add(repi, y2), B.dln2, kq), B.dln3, kq);
       }
     }
     // head (sable_network.py:296-319) and sampling
-    const Row hn = row_rms(row_gelu(dense64(xo, a.h0_t, a.h0_b, m, kq)), a.h_s, kq);
+    const Row hn = row_rms(row_gelu(dense64<true>(xo, a.h0_t, a.h0_b, m, kq)), a.h_s, kq);
     Row lg;
-    wgemm<4>(hn, a.h1_t, m, kq, [&](int g, f32x4 acc) {
+    wgemm<4, true>(hn, a.h1_t, m, kq, [&](int g, f32x4 acc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int n = 16 * g + 4 * kq + r; lg.v[4 * g + r] = acc[r] + (n < a.K ? a.h1_b[n] : 0.f); }
     });
-    PROF(0);
+    PROF(7);
     const uint32_t k0 = a.keys_dev ? a.keys_dev[2 * i] : a.keys[i][0], k1 = a.keys_dev ? a.keys_dev[2 * i + 1] : a.keys[i][1];
     const unsigned char* mk = a.mask ? a.mask + (ge * A + i) * a.K : nullptr;
     float xv[16];
@@ -767,7 +835,11 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
         const uint32_t bits = random_bits32(k0, k1, (uint32_t)(ge * a.K + n));
         const float f = __uint_as_float((bits >> 9) | 0x3f800000u) - 1.0f;
         const float uu = fmaxf(1.17549435e-38f, f + 1.17549435e-38f);
+#ifdef MAGPO_X_FASTGUMBEL   // timing experiment: hardware fp32 logs (NOT the oracle's correctly rounded value)
+        const float gmb = -__logf(-__logf(uu));
+#else
         const float gmb = (float)(-log(-log((double)uu)));
+#endif
         const float vv = gmb + lp;
         if (vv > best || (vv == best && n < arg)) { best = vv; arg = n; best_lp = lp; }
       }
@@ -780,7 +852,7 @@ __global__ __launch_bounds__(64, 1) void k_sable_act(ActArgs a) {
     }
     if (valid && kq == 0) { a.action[row] = arg; a.logp[row] = best_lp; }
     prev = arg + 1;
-    PROF(2);
+    PROF(16);
   }
   if (a.flush) flush_states();   // stand-alone step (or last step of a rollout without a value launch): settle the decoder states now
 }

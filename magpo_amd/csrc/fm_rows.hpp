@@ -92,7 +92,12 @@ __device__ __forceinline__ Row row_add(const Row& a, const Row& b) {
   for (int j = 0; j < 16; ++j) r.v[j] = a.v[j] + b.v[j];
   return r;
 }
+// Timing experiments only (results are WRONG with them; scripts/debug/act_ab2.sh): -DMAGPO_X_NOROWMATH makes RMSNorm / GELU pass-through,
+// -DMAGPO_X_NOW replaces the weight-fragment loads of the dense layers by constants, -DMAGPO_X_NOMFMA drops their MFMAs.
 __device__ __forceinline__ Row row_rms(const Row& x, const float* scale, int kq) {
+#ifdef MAGPO_X_NOROWMATH
+  return x;
+#endif
   Row q;
 #pragma unroll
   for (int j = 0; j < 16; ++j) q.v[j] = x.v[j] * x.v[j];
@@ -106,6 +111,9 @@ __device__ __forceinline__ Row row_rms(const Row& x, const float* scale, int kq)
 // GELU (tanh form) on the hardware exp / rcp units: the fused kernels run one or two waves per SIMD and are VALU-issue bound,
 // libm's tanhf is ~40 instructions per element (abs. error of the fast form ~1e-7, far inside the fp32 parity tolerance)
 __device__ __forceinline__ Row row_gelu(const Row& x) {
+#ifdef MAGPO_X_NOROWMATH
+  return x;
+#endif
   Row r;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -116,40 +124,135 @@ __device__ __forceinline__ Row row_gelu(const Row& x) {
 }
 
 // ---- dense layer, transposed on 16x16x4 fp32 MFMA: out(g, acc) receives features 16 g + 4 kq + (0..3) of every env ------
-template <int NG, class OUT>
-__device__ __forceinline__ void wgemm(const Row& x, const float* __restrict__ Wt, int m, int kq, OUT&& out) {
-  constexpr int PD = NG < 4 ? NG : 4;
+#ifdef MAGPO_X_NOW
+#define WLD(p) make_float4(1e-3f, -2e-3f, 3e-3f, -1e-3f)
+#else
+#define WLD(p) ld4g(p)
+#endif
+#ifdef MAGPO_X_NOMFMA
+#define WMFMA(a, b, c) f32x4{c[0] + (a) * (b), c[1], c[2], c[3]}
+#else
+#define WMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
+// Weight operand layouts: the transposed copy Wt [n][64] of magpo_transpose_pad (FRAG = false: lane (m, kq) reads 16 bytes of row 16 g + m,
+// i.e. one instruction touches 16 rows x 64 B), or the FRAGMENT-MAJOR copy of the acting kernel (FRAG = true, SableGuider.build_act_weights):
+//   Wf[g][gk][lane = m + 16 kq][4] = Wt[16 g + m][16 gk + 4 kq .. + 3]
+// so that one instruction reads 1 KB contiguous (8 full cache lines instead of 16 half lines) from base + 16 * lane.  A wave that streams
+// its weights from L2 for every token (the acting kernel: 1.15 MB per wave and launch) is bound by those requests, not by the MFMAs.
+template <bool FRAG>
+__device__ __forceinline__ float4 wfrag(const float* __restrict__ Wt, int g, int gk, int m, int kq) {
+  if (FRAG) return WLD(Wt + g * 1024 + gk * 256 + 4 * (m + 16 * kq));
+  return WLD(Wt + (long)(16 * g + m) * AE + 16 * gk + 4 * kq);
+}
+#ifndef MAGPO_WGEMM_PD
+#define MAGPO_WGEMM_PD 4
+#endif
+// The first fragments of a layer can be requested AHEAD of the code that produces the layer's input (wload<NG>() before the row math of the
+// previous layer, wgemm_pre<NG>() after it): a wave that runs alone on its SIMD otherwise sits out one L2 round trip at the top of every
+// dense layer -- ~45 of them per acting step.
+struct WPre { float4 w[MAGPO_WGEMM_PD][4]; };
+template <int NG, bool FRAG>
+__device__ __forceinline__ WPre wload(const float* __restrict__ Wt, int m, int kq) {
+  constexpr int PD = NG < MAGPO_WGEMM_PD ? NG : MAGPO_WGEMM_PD;
+  WPre r;
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) r.w[p][gk] = wfrag<FRAG>(Wt, p, gk, m, kq);
+  return r;
+}
+template <int NG, bool FRAG = false, class OUT = void>
+__device__ __forceinline__ void wgemm_pre(const Row& x, const float* __restrict__ Wt, const WPre& pre, int m, int kq, OUT&& out) {
+  constexpr int PD = NG < MAGPO_WGEMM_PD ? NG : MAGPO_WGEMM_PD;   // weight fragments in flight ahead of the MFMAs (column groups)
   float4 w[PD][4];
 #pragma unroll
   for (int p = 0; p < PD; ++p)
 #pragma unroll
-    for (int gk = 0; gk < 4; ++gk) w[p][gk] = ld4g(Wt + (long)(16 * p + m) * AE + 16 * gk + 4 * kq);
+    for (int gk = 0; gk < 4; ++gk) w[p][gk] = pre.w[p][gk];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].x, x.v[4 * gk], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].y, x.v[4 * gk + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].z, x.v[4 * gk + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g % PD][gk].w, x.v[4 * gk + 3], acc, 0, 0, 0);
+      acc = WMFMA(w[g % PD][gk].x, x.v[4 * gk], acc);
+      acc = WMFMA(w[g % PD][gk].y, x.v[4 * gk + 1], acc);
+      acc = WMFMA(w[g % PD][gk].z, x.v[4 * gk + 2], acc);
+      acc = WMFMA(w[g % PD][gk].w, x.v[4 * gk + 3], acc);
     }
     if (g + PD < NG) {
 #pragma unroll
-      for (int gk = 0; gk < 4; ++gk) w[g % PD][gk] = ld4g(Wt + (long)(16 * (g + PD) + m) * AE + 16 * gk + 4 * kq);
+      for (int gk = 0; gk < 4; ++gk) w[g % PD][gk] = wfrag<FRAG>(Wt, g + PD, gk, m, kq);
     }
     out(g, acc);
   }
 }
+template <int NG, bool FRAG = false, class OUT = void>
+__device__ __forceinline__ void wgemm(const Row& x, const float* __restrict__ Wt, int m, int kq, OUT&& out) {
+  const WPre pre = wload<NG, FRAG>(Wt, m, kq);
+  wgemm_pre<NG, FRAG>(x, Wt, pre, m, kq, out);
+}
+// The same layer for NT rows at once (the A tokens of an env step, all known up front in the encoder): every weight fragment is fetched
+// ONCE and multiplied into NT accumulators -- a quarter of the weight traffic of NT separate calls.  nt (uniform) <= NT rows are live.
+template <int NG, int NT, bool FRAG = false, class OUT = void>
+__device__ __forceinline__ void wgemm_multi(const Row (&x)[NT], int nt, const float* __restrict__ Wt, int m, int kq, OUT&& out) {
+  constexpr int PD = NG < 2 ? NG : 2;
+  float4 w[PD][4];
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) w[p][gk] = wfrag<FRAG>(Wt, p, gk, m, kq);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+#pragma unroll
+        for (int gk = 0; gk < 4; ++gk) {
+          acc[t] = WMFMA(w[g % PD][gk].x, x[t].v[4 * gk], acc[t]);
+          acc[t] = WMFMA(w[g % PD][gk].y, x[t].v[4 * gk + 1], acc[t]);
+          acc[t] = WMFMA(w[g % PD][gk].z, x[t].v[4 * gk + 2], acc[t]);
+          acc[t] = WMFMA(w[g % PD][gk].w, x[t].v[4 * gk + 3], acc[t]);
+        }
+      }
+    }
+    if (g + PD < NG) {
+#pragma unroll
+      for (int gk = 0; gk < 4; ++gk) w[g % PD][gk] = wfrag<FRAG>(Wt, g + PD, gk, m, kq);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out(t, g, acc[t]);
+  }
+}
 // 64 -> 64 layer into registers (+ optional bias)
+template <bool FRAG = false>
 __device__ __forceinline__ Row dense64(const Row& x, const float* __restrict__ Wt, const float* __restrict__ bias, int m, int kq) {
   Row y;
-  wgemm<4>(x, Wt, m, kq, [&](int g, f32x4 acc) {
+  wgemm<4, FRAG>(x, Wt, m, kq, [&](int g, f32x4 acc) {
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) b = ld4g(bias + 16 * g + 4 * kq);
     y.v[4 * g] = acc[0] + b.x; y.v[4 * g + 1] = acc[1] + b.y; y.v[4 * g + 2] = acc[2] + b.z; y.v[4 * g + 3] = acc[3] + b.w;
   });
   return y;
+}
+template <bool FRAG = false>
+__device__ __forceinline__ Row dense64_pre(const Row& x, const float* __restrict__ Wt, const WPre& pre, const float* __restrict__ bias, int m, int kq) {
+  Row y;
+  wgemm_pre<4, FRAG>(x, Wt, pre, m, kq, [&](int g, f32x4 acc) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = ld4g(bias + 16 * g + 4 * kq);
+    y.v[4 * g] = acc[0] + b.x; y.v[4 * g + 1] = acc[1] + b.y; y.v[4 * g + 2] = acc[2] + b.z; y.v[4 * g + 3] = acc[3] + b.w;
+  });
+  return y;
+}
+template <int NT, bool FRAG = false>
+__device__ __forceinline__ void dense64_multi(const Row (&x)[NT], int nt, Row (&y)[NT], const float* __restrict__ Wt, const float* __restrict__ bias, int m, int kq) {
+  wgemm_multi<4, NT, FRAG>(x, nt, Wt, m, kq, [&](int t, int g, f32x4 acc) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = ld4g(bias + 16 * g + 4 * kq);
+    y[t].v[4 * g] = acc[0] + b.x; y[t].v[4 * g + 1] = acc[1] + b.y; y[t].v[4 * g + 2] = acc[2] + b.z; y[t].v[4 * g + 3] = acc[3] + b.w;
+  });
 }
 
 }  // namespace magpo

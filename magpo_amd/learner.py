@@ -462,6 +462,8 @@ class MagpoLearner:
         main = torch.cuda.current_stream()
         side = self._actor_stream if self.overlap_actor_step else None
         fused = self.fused_act
+        if fused:   # fragment-major weight copies of the acting kernel from the current parameters (a node of the captured graph as well)
+            self.guider.build_act_weights()
         gtag = str(self.groups.index(g))
         act = (lambda *a, **k: self.guider.act_fused(*a, tag=gtag, **k)) if fused else self.guider.act
 

@@ -107,6 +107,8 @@ class SableGuider:
                 self.L.call("magpo_pe_table", pe_l, max_pos, self.EL, self._st())
                 self.pe.copy_(self.emb.expand_rows(pe_l))
         self.wt: Dict[str, torch.Tensor] = {}
+        self.wa: Dict[str, torch.Tensor] = {}   # fragment-major copies for the fused acting kernel (build_act_weights)
+        self._act_w_dirty = True
         self.b = _Bufs(device)
         self._act_tabs: Dict[tuple, tuple] = {}
         self._seg_tabs: Dict[tuple, tuple] = {}
@@ -182,6 +184,28 @@ class SableGuider:
                         if key not in self.wt:
                             self.wt[key] = torch.empty(E, 2 * E, device=self.dev)
                         self.wt[key].copy_(W[:, half * 2 * E:(half + 1) * 2 * E])
+        self._act_w_dirty = True   # the acting kernel's fragment-major copies are rebuilt before the next acting step (build_act_weights)
+
+    def _act_weight_names(self):
+        names = ["vh0", "h0", "h1"]
+        for b in range(self.nb):
+            names += [f"qkvg{b}", f"wo{b}", f"qkvg1{b}", f"wo1{b}", f"q2{b}", f"kvg2{b}", f"wo2{b}"]
+        return names
+
+    def build_act_weights(self):
+        """Fragment-major copies of the transposed weights for the fused acting kernel (csrc/fm_rows.hpp: wfrag<true>):
+        Wf[g][gk][lane = m + 16 kq][4] = Wt[16 g + m][16 gk + 4 kq .. + 3], so that a wave's weight-fragment load is 1 KB contiguous.
+        In-place copies into persistent buffers (static pointers: safe inside a HIP-graph capture); the rollout calls this at its start
+        (MagpoLearner._rollout_body), a stand-alone ``act_fused`` when the parameters changed since the last build."""
+        if self.E != 64:
+            return
+        for name in self._act_weight_names():
+            t = self.wt[name]
+            d = self.wa.get(name)
+            if d is None:
+                d = self.wa[name] = torch.empty_like(t)
+            self.L.call("magpo_act_weight_layout", t, d, t.shape[0], self._st())
+        self._act_w_dirty = False
 
     def lin(self, X, ldx, Wt, bias, Y, ldy, R, KIN, NOUT, act=0, Ypre=None):
         self.L.call("magpo_linear", X, ldx, Wt, bias, Y, ldy, Ypre, R, KIN, NOUT, act, self.tuning.linear_variant, self._st())
@@ -446,14 +470,19 @@ class SableGuider:
                      None if kdev is None else kdev.data_ptr(), s_enc.data_ptr(), s_d1.data_ptr(), s_d2.data_ptr(),
                      None if action_out is None else action_out.data_ptr(), None if logp_out is None else logp_out.data_ptr(),
                      value_out.data_ptr(), None if done is None else done.data_ptr())
+        if self._act_w_dirty and not torch.cuda.is_current_stream_capturing():
+            self.build_act_weights()   # (a captured rollout rebuilds them itself, as graph nodes: MagpoLearner._rollout_body)
         tabs = self._act_tabs.get(cache_key)
         if tabs is None:
+            if not self.wa:
+                self.build_act_weights()
+            wa = self.wa
             g = lambda n, w=E, rows=R: b.get(f"f{tag}_" + n, (rows, w))   # scratch per caller tag (env groups may act concurrently)
             ptr = lambda t: 0 if t is None else t.data_ptr()
             glob = [obs, pos, mask, kdev,
                     v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], v["enc.ln.scale"], v["dec.act.kernel"], v["dec.ln.scale"],
-                    self.wt["vh0"], v["enc.head.dense0.bias"], v["enc.head.norm.scale"], v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
-                    self.wt["h0"], v["dec.head.dense0.bias"], v["dec.head.norm.scale"], self.wt["h1"], v["dec.head.dense1.bias"],
+                    wa["vh0"], v["enc.head.dense0.bias"], v["enc.head.norm.scale"], v["enc.head.dense1.kernel"], v["enc.head.dense1.bias"],
+                    wa["h0"], v["dec.head.dense0.bias"], v["dec.head.norm.scale"], wa["h1"], v["dec.head.dense1.bias"],
                     self.pe, s_enc, s_d1, s_d2,
                     g("xn"), done, g("qkvg", 4 * E), g("u"), g("y"), g("rep"), g("reppe"), g("hv"),
                     g("xa", E, N), g("kin1", E, N), g("y1", E, N), g("c", E, N), g("cpe", E, N), g("y2", E, N), g("xo", E, N),
@@ -463,9 +492,9 @@ class SableGuider:
             blk = []
             for k in range(nb):
                 e, d = f"enc.block{k}.", f"dec.block{k}."
-                blk += [self.wt[f"qkvg{k}"], self.wt[f"wo{k}"], v[e + "ln1.scale"], v[e + "ln2.scale"], v[e + "retn.gn.scale"], v[e + "retn.gn.bias"],
-                        self.wt[f"qkvg1{k}"], self.wt[f"wo1{k}"], v[d + "ln1.scale"], v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"],
-                        self.wt[f"q2{k}"], self.wt[f"kvg2{k}"], self.wt[f"wo2{k}"], v[d + "ln2.scale"], v[d + "ln3.scale"],
+                blk += [wa[f"qkvg{k}"], wa[f"wo{k}"], v[e + "ln1.scale"], v[e + "ln2.scale"], v[e + "retn.gn.scale"], v[e + "retn.gn.bias"],
+                        wa[f"qkvg1{k}"], wa[f"wo1{k}"], v[d + "ln1.scale"], v[d + "retn1.gn.scale"], v[d + "retn1.gn.bias"],
+                        wa[f"q2{k}"], wa[f"kvg2{k}"], wa[f"wo2{k}"], v[d + "ln2.scale"], v[d + "ln3.scale"],
                         v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
                         g(f"qkvg1_{k}", 4 * E), g(f"q2_{k}"), g(f"kvg2_{k}", 4 * E)]   # kvg2 rows: [k | v | - | P2] (ld 256)
             tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld, self.tuning.act_envs_per_wave,
