@@ -47,7 +47,8 @@ class KernelTimer:
             if R < self.min_rows:
                 return None
             if a[6] is None or a[10] == 4:   # no pre-activation copy (act 4: the slot carries the mask): shared-tile kernel
-                key = f"k_linear_lds<{KIN},{4 if ((NOUT + 31) // 32) % 4 == 0 else 2}>"
+                nw = 4 if ((NOUT + 31) // 32) % 4 == 0 else 2
+                key = f"k_linear_lds<{KIN}, {nw}, {'true' if (a[11] & 4 and nw == 4 and KIN in (128, 192)) else 'false'}>"
             else:
                 key = f"k_linear_w<{KIN}>"
             return key, 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
@@ -57,11 +58,11 @@ class KernelTimer:
                 return None
             full = R >= 64 * 256 and ((KIN, NOUT) == (128, 384) or (R % 64 == 0 and (KIN, NOUT) in ((128, 128), (64, 256))))
             if R >= 64 * 256 and R % 64 == 0 and (KIN, NOUT) in ((64, 192), (128, 128)):
-                key = f"k_wgrad_full_g<{KIN // 64},{3 if NOUT == 192 else 2}>"
+                key = f"k_wgrad_full_g<{KIN // 64}, {3 if NOUT == 192 else 2}>"
             elif full and R % 64 == 0:
-                key = f"k_wgrad_full_x<{KIN // 32},{NOUT // 128},{0 if (KIN, NOUT) == (64, 256) else 4}>"
+                key = f"k_wgrad_full_x<{KIN // 32}, {NOUT // 128}, {0 if (KIN, NOUT) == (64, 256) else 4}, false>"
             elif full:
-                key = f"k_wgrad_full<{KIN // 32},{NOUT // 128}>"
+                key = f"k_wgrad_full<{KIN // 32}, {NOUT // 128}>"
             else:
                 key = "k_wgrad<2>" if NOUT >= 128 else "k_wgrad<1>"
             return key, 4.0 * R * (KIN + NOUT), 2.0 * R * KIN * NOUT
@@ -78,7 +79,13 @@ class KernelTimer:
             # executed MACs per 32-token chunk: fwd QK^T 32x32x64 + QS 32x64x64 + PV 32x64x32 + state 64x64x32; bwd P, dP 2 x 32x32x64,
             # dQ / dK / dV 3 x (32x64x32 + 32x64x64), G 64x64x32
             macs = 393216 if fwd else 851968
-            return ("k_ret32_fwd" if fwd else "k_ret32_bwd"), byts, 2.0 * macs * nseq * nch
+            # <FAST (every chunk full), ROWS (q | k | v rows read through the block-0 class table)>: the instance retention.hip launches
+            fast = (32 % A == 0) and T % (32 // A) == 0 and int(a[18] if fwd else a[21]) == 64 and nch <= 32
+            rows_t = (a[19] if fwd else a[22]) is not None
+            if rows_t:   # the q | k | v rows of the table are L2-resident: only r out (fwd) / the gradient rows (bwd) and the states are HBM bytes
+                byts = 4.0 * rows * 64 * (1 if fwd else 4) + 4.0 * nseq * nch * 4096
+            tf = lambda b: "true" if b else "false"
+            return (f"k_ret32_fwd<{tf(fast)}, {tf(rows_t)}>" if fwd else f"k_ret32_bwd<{tf(fast)}, {tf(rows_t)}>"), byts, 2.0 * macs * nseq * nch
         if name == "magpo_retention_recurrent":
             nenv, ntok, wr = a[10], a[11], a[14]
             return "k_ret_recurrent", 4.0 * nenv * ((2 if wr else 1) * 4096 + 4 * ntok * 64), 4.0 * nenv * ntok * 4096 + 2.0 * nenv * 4096
@@ -87,14 +94,49 @@ class KernelTimer:
             if T == 1:
                 return None
             rows = nseq * T * A
-            return "k_gru_scan_fwd<true,0>", 4.0 * rows * (384 + 128 + 512 + 128), 2.0 * rows * 128 * 384
+            # HBM bytes: gates [R, 512] + h [R, 128] + h_prev [R, 128] written; the input projection xi is read through the class table
+            # (L2-resident rows, not HBM) when a class list is given, from [R, 384] otherwise
+            xi_b = 0 if a[12] is not None else 384
+            key = "k_gru_scan_fwd_bf3<true, 3>" if a[13] == 2 else ("k_gru_scan_fwd_bf<true>" if a[13] == 1 else "k_gru_scan_fwd<true, 0, 64>")
+            return key, 4.0 * rows * (xi_b + 128 + 512 + 128), 2.0 * rows * 128 * 384
         if name == "magpo_gru_scan_bwd":
             nseq, T, A = a[7], a[8], a[9]
             rows = nseq * T * A
-            return "k_gru_scan_bwd<true>", 4.0 * rows * (512 + 128 + 128 + 512), 2.0 * rows * 384 * 128
+            return "k_gru_scan_bwd<true, 64>", 4.0 * rows * (512 + 128 + 128 + 512), 2.0 * rows * 384 * 128
+        if name == "magpo_gru_carry":   # the rollout's actor carry as one scan over the time-major trajectory (xi from the class table)
+            nenv, T, A = a[6], a[7], a[8]
+            rows = nenv * T * A
+            return "k_gru_scan_fwd<true, 1, 64>", 4.0 * rows * ((0 if a[9] is not None else 384) + 1) + 8.0 * nenv * A * 128, 2.0 * rows * 128 * 384
+        if name == "magpo_seg_post":
+            import ctypes
+            d = (ctypes.c_int * 6).from_address(a[0])
+            tail, K, nq2 = d[0], d[1], d[5]
+            R = a[1]
+            if R < self.min_rows:
+                return None
+            pt = (ctypes.c_uint64 * a[3]).from_address(a[2])
+            tab = pt[a[3] - 1] != 0          # rows index given: gate / residual rows come from the L2-resident class table, not from HBM
+            # HBM row streams of 256 B: r in, gate + residual in (unless table rows), u + o (+ ope) out, then the tail's outputs
+            streams = 1 + (0 if tab else 2) + 2 + {0: 0.0, 1: 1.0 + nq2 + 1.0 / 64, 2: 1.0 + 3.0, 3: 1.0 + 1.0 + K / 64.0}[tail]
+            dense = {0: 1, 1: 2 + nq2, 2: 4, 3: 2 + K / 64.0}[tail]
+            return f"k_seg_post<{tail}>", 256.0 * R * streams, 2.0 * R * 64 * 64 * dense
+        if name == "magpo_class_sum":   # bit-stable per-class row sums: every row of X [R, W] read once (classtab.hip)
+            R, W = a[2].numel(), a[5]
+            if R < self.min_rows:
+                return None
+            return "k_class_sum", 4.0 * R * W + 8.0 * R, 1.0 * R * W
+        if name == "magpo_headmid_bwd":
+            R, E = a[13], a[14]
+            if R < self.min_rows:
+                return None
+            return f"k_headmid_bwd<{E}>", 4.0 * R * E * 3, 30.0 * R * E
         if name == "magpo_seg_bwd":
+            import ctypes
             R = a[0]
-            return "k_seg_bwd", 4.0 * R * 64 * 9, 2.0 * R * 64 * 64
+            pt = (ctypes.c_uint64 * a[4]).from_address(a[3])
+            tab = pt[19] != 0   # rows index given: the gate / residual rows of block 0 come from the L2-resident class table
+            # HBM row streams of 256 B: a, y (recomputed from u: no), d0..d2 in, r, gate in (unless table rows), dsum, dr, dgp out
+            return "k_seg_bwd<true>", 256.0 * R * (7 if tab else 9), 2.0 * R * 64 * 64 * 2
         if name == "magpo_sable_act":
             import ctypes
             d = (ctypes.c_int * 10).from_address(a[0])
@@ -104,7 +146,10 @@ class KernelTimer:
             # the three retention states read + written once per env step = 2 * 3 * nb * nh * hs^2 * 4 B per env
             # (98 304 B at E = 64, one block, one head).  Everything else the launch touches (obs, weights, outputs) is < 1 %.
             state = 4.0 * nb * nh * hs * hs
-            return f"k_sable_act<{A}>", 6.0 * state * N, N * A * (46.0 * 64 * 64 + 12.0 * 64 * 64 / nh)
+            d14 = (ctypes.c_int * 14).from_address(a[0])
+            from magpo_amd._lib import lib as _lib
+            epw = _lib().call("magpo_sable_act_envs_per_wave", int(N), int(A), int(d14[11]))   # the instance the library launches (act_fused.hip)
+            return f"k_sable_act<{epw}, {4 if A <= 4 else 8}, {1 if (nh == 1 and A <= 4) else 0}>", 6.0 * state * N, N * A * (46.0 * 64 * 64 + 12.0 * 64 * 64 / nh)
         if name == "magpo_coordsum_step":   # ~0.5 KB per env-step (record row + targets + obs / reward / metrics out)
             N, A, TL = a[9], a[10], a[12]
             return "k_coordsum_step", float(N) * (4.0 * TL + 4.0 * A * (A + 2) + 64.0), 0.0
@@ -119,14 +164,19 @@ class KernelTimer:
             return "k_magpo_loss", 4.0 * R * (4 * K + 8), 60.0 * R * K
         return None
 
-    only = None   # restrict timing to these entry points (set-up pass for the acting kernel)
+    only = None       # restrict timing to these entry points
+    all_calls = False  # time EVERY entry point (those without a cost model as "other: <entry point>"): the eager set-up step only --
+    #                    an event pair around each of the ~700 small launches of an update step would cost the timed region ~0.5 %
 
     def begin(self, name, args):
         if not self.enabled or torch.cuda.is_current_stream_capturing() or (self.only is not None and name not in self.only):
             return None
         m = self._model(name, args)
         if m is None:
-            return None
+            if not self.all_calls or name in ("magpo_sable_act_envs_per_wave", "magpo_class_sum_slots", "magpo_row_grid", "magpo_seg_bwd_grid",
+                                              "magpo_retention_num_chunks", "magpo_obsnorm_grid", "magpo_wgrad_workspace_floats", "magpo_abi_version"):
+                return None
+            m = (f"other: {name}", 0.0, 0.0)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -187,7 +237,7 @@ class KernelTimer:
         return roof, table
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
+def cpu_baseline():
     """The CPU oracle (a torch-CPU port of the reference loop; the reference's own JAX path cannot run here:
     jax / flax / jumanji are not installed) timed on this box's host cores on a bounded sample of the same
     workload: CoordSum-4ag, same network sizes, rollout_length=128, 4 epochs x 2 minibatches, 256 envs (SURVEY 8(d) asks for
@@ -206,17 +256,15 @@ def cpu_baseline(seconds_budget: float = 12.0):
     ol = olearn.OracleLearner(ocs.CoordSumSpec(A, K, 100, 60), N, olearn.SystemCfg(), onets.SableCfg(A, K, A + 1),
                               onets.init_guider_params(1, 64, A + 1, K), onets.init_actor_params(2, A + 1, 128, K))
     ol.setup(oprng.split(oprng.prng_key(42), 4)[0])
-    t0 = time.time()
-    steps = 0
-    while True:
+    times = []
+    for _ in range(3):   # three full update steps, the MEDIAN step reported (~10 s each on the GPU box's 16-core share)
+        t0 = time.time()
         ol.update_step()
-        steps += 1
-        if time.time() - t0 > seconds_budget or steps >= 3:
-            break
-    dt = time.time() - t0
-    return dict(value=round(steps * N * 128 / dt, 1), unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{steps} full update step(s) of CoordSum-4ag at num_envs={N} (rollout 128, 4 epochs x 2 minibatches), "
-                       f"torch-CPU fp32 oracle, {cores} threads, {dt:.1f}s")
+        times.append(time.time() - t0)
+    med = sorted(times)[1]
+    return dict(value=round(N * 128 / med, 1), unit="env-steps/s", cores=cores, kind="port",
+                sample=f"median of 3 full update steps of CoordSum-4ag at num_envs={N} (rollout 128, 4 epochs x 2 minibatches), "
+                       f"torch-CPU fp32 oracle, {cores} threads, {' / '.join(f'{t:.1f}' for t in times)} s per step")
 
 
 def launch_ranks(n: int) -> int:
@@ -269,6 +317,7 @@ def main():
     ap.add_argument("--ppo-epochs", type=int, default=0, help="0 = the reference default 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the fp32-MFMA / dense-first-layers variant measurements after the timed region")
     ap.add_argument("--overlap", action="store_true", help="run actor / weight-gradient kernels on side streams (experiment: -1 %% with the current kernels, which fill the chip; kernel timings then include contention)")
     ap.add_argument("--gru-split-bf16", type=int, default=2, choices=[0, 1, 2],
                     help="recurrent GEMMs of the GRU training scans: 2 (default) = forward scan on bf16 MFMA with operands split in three pieces (24 mantissa "
@@ -369,18 +418,20 @@ def main():
     timer.attach_traffic = args.workload == "coordsum-4ag" and N == 16384  # the PMC passes were taken on that workload
     timing = not args.no_kernel_timing and rank == 0
     act_keys = ()
-    if timing and learner.fused_act and env_cfg.num_agents <= 8:
-        # The acting kernel runs inside the rollout's HIP graph, where per-launch events cannot be recorded: time it on one
-        # EAGER rollout here (same kernel, same shapes, same data distribution), still outside the timed region.  Every rank
-        # runs this extra update step so that the replicas stay in lock-step.
-        lib().timer, timer.enabled, timer.only = timer, True, ("magpo_sable_act", "magpo_coordsum_step", "magpo_lbf_step", "magpo_rware_step")
+    eager = KernelTimer(min_rows=1 << 16)
+    if timing:
+        # One EAGER update step, still outside the timed region, with an event pair around EVERY C-ABI launch: (a) the acting and env kernels
+        # run inside the rollout's HIP graph in the timed region, where per-launch events cannot be recorded (same kernels, shapes and data
+        # distribution here); (b) the ~700 small launches per step without a cost model ("other: <entry point>") are timed here only, so
+        # that the kernel table accounts for the whole step without costing the timed region an event pair per small launch.
+        # Every rank runs this extra update step so that the replicas stay in lock-step.
+        lib().timer, eager.enabled, eager.all_calls = eager, True, True
     learner.use_graph = False
     learner.update_step(grad_sync)
     learner.use_graph = True
     if timing:
-        timer.collect()
-        act_keys = tuple(timer.rec)
-        timer.only = None
+        eager.collect()
+        eager.enabled = False
     roll_events = []
     if timing:
         lib().timer, timer.enabled = timer, True
@@ -391,15 +442,32 @@ def main():
             e0.record(); orig_rollout(); e1.record()
             roll_events.append((e0, e1))
         learner.rollout = timed_rollout
+    # exposed gradient-exchange time per rank: events on the compute stream around the one all-reduce of a minibatch (the stream waits
+    # for the collective before the optimiser kernel runs)
+    ar_events = []
+    sync = grad_sync
+    if grad_sync is not None:
+        def sync(l):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = grad_sync(l); e1.record()
+            ar_events.append((e0, e1))
+            return r
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        learner.update_step(grad_sync)
+        learner.update_step(sync)
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     lib().timer = None
     elapsed = reduce_max(elapsed)
+    ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(1, args.steps) if ar_events else 0.0
+    ar_all = None
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        t[rank] = ar_ms
+        dist.all_reduce(t)
+        ar_all = [round(float(x), 3) for x in t.tolist()]
     if args.check_replicas and world > 1:
         cs = float(learner.guider.P.flat.double().sum().item() + learner.actor.P.flat.double().abs().sum().item())
         assert reduce_max(cs) == -reduce_max(-cs), "parameters diverged across ranks"
@@ -407,7 +475,16 @@ def main():
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     if rank == 0:
         timer.collect()
+        # kernels that the timed region could not time (inside the rollout graph) or did not (no cost model): from the eager step
+        act_keys = tuple(k for k in eager.rec if k not in timer.rec)
+        for k in act_keys:
+            timer.rec[k] = eager.rec[k]
         roof, table = timer.dominant(args.steps, act_keys)
+        if table:
+            for k, row in table.items():
+                row["timed_in"] = "eager set-up step" if k in act_keys else "timed region"
+                if k.startswith("other: "):
+                    row["gbs"] = row["tflops"] = None
         rollout_ms = round(sum(e0.elapsed_time(e1) for e0, e1 in roll_events) / max(1, len(roll_events)), 2) if roll_events else None
         env_steps = world * N * sysc.rollout_length * args.steps
         if isinstance(env_cfg, RwareConfig):
@@ -447,7 +524,45 @@ def main():
             "rollout_graph_ms_per_step": rollout_ms,
             "hbm_resident_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),   # peak of torch's allocator on rank 0 (all buffers of the path)
             "kernel_table": table,
+            # share of the step the table accounts for (launches through the C ABI; torch's own sort / searchsorted / copies are not in it)
+            "kernel_table_ms_per_step": None if not table else round(sum(r["ms_per_step"] for r in table.values()), 2),
+            "allreduce_wait_ms_per_step": ar_all,   # per rank, exposed on the compute stream (None for one rank)
         }
+        if table:
+            out["kernel_table_coverage"] = round(out["kernel_table_ms_per_step"] / out["ms_per_step"], 3)
+        if world == 1 and not args.no_variants:
+            # The same workload under the two switches that separate the headline from "plain": measured in this run, on this box, right
+            # after the timed region (2 untimed + 3 timed update steps each).  fp32_mfma = exact fp32 MFMA everywhere (no bf16 x3 operand
+            # splits); dense_first_layers = the first layers of both networks evaluated on every token row instead of on the distinct
+            # (agent, target, step) rows (an exact algebraic rewrite that only CoordSum's finite observation alphabet allows).
+            def variant(setup):
+                try:
+                    setup()
+                    for g in learner.groups:   # the rollout graph holds the kernels of the previous mode
+                        g.graph, g.warmed, g.graph_failed = None, False, False
+                    for _ in range(3):
+                        learner.update_step(grad_sync)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        learner.update_step(grad_sync)
+                    torch.cuda.synchronize()
+                    return round((time.perf_counter() - t1) / 3 * 1e3, 2)
+                except Exception as e:   # a variant must never take the headline line down
+                    return f"failed: {e!r}"
+            variants = {}
+            split0, lv0, alv0 = tuning.gru_split_bf16, tuning.linear_variant, tuning.actor_linear_variant
+            if split0 or (lv0 | alv0) & 4:
+                def fp32():
+                    tuning.gru_split_bf16 = 0; tuning.linear_variant &= ~4; tuning.actor_linear_variant &= ~4
+                variants["fp32_mfma_ms_per_step"] = variant(fp32)
+                tuning.gru_split_bf16, tuning.linear_variant, tuning.actor_linear_variant = split0, lv0, alv0
+            if learner.class_tables:
+                def dense():
+                    learner.class_tables = False
+                variants["dense_first_layers_ms_per_step"] = variant(dense)
+                learner.class_tables = True
+            out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle baseline ...")
             out["cpu_baseline"] = cpu_baseline()

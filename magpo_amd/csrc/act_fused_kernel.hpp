@@ -121,6 +121,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
                                          const float4* __restrict__ primed = nullptr) {
   const int lane = threadIdx.x, c4 = 4 * (lane & 15), rg = lane >> 4;
   const int A = a.A, nh = NH ? NH : a.nh, hs = NH ? AE / NH : a.hs, gs = NH ? AE / (NH * NH) : a.gs;   // NH = 0: run-time head count
+  // (the team size as a compile-time constant -- token loops without uniform branches -- was measured in round 4: 484.6 vs 486.6 us, nothing)
   // MODE 0 (encoder): all A tokens staged as [q|k|v|g] rows, state update + write, gated output -> global uout
   // MODE 1 (decoder self-retention, agent i): tokens a < i staged (k|v), token i from TQ, output u_i -> LDS U, state written at the last agent
   // MODE 2 (cross-retention pre-pass): q rows of all A agents staged, RAW q_a (kappa S) -> global uout, state untouched

@@ -262,9 +262,12 @@ class MagpoLearner:
     def __init__(self, env_cfg, num_envs: int, sys: SystemConfig, device, *, net_seed: Optional[int] = 0,
                  decay_scaling_factor: float = 0.8, use_pe: bool = True, wgrad_groups: int = 512, num_groups: int = 1,
                  n_block: int = 1, n_head: int = 1, embed_dim: int = 64, tuning=None, guider: Optional[SableGuider] = None,
-                 actor: Optional[GruActor] = None, optims=None):
+                 actor: Optional[GruActor] = None, optims=None, apply_fns=None, update_fns=None):
         """``guider`` / ``actor`` / ``optims`` = (guider ClipAdam, actor ClipAdam): networks and optimisers built by the caller
-        (rec_magpo.learner_setup hands them to get_learner_fn as its apply / update functions); by default the learner builds its own."""
+        (rec_magpo.learner_setup hands them to get_learner_fn as its apply / update functions); by default the learner builds its own.
+        ``apply_fns`` = (sable_action_select_fn, sable_apply_fn, actor_apply_fn), ``update_fns`` = (sable_update_fn, actor_update_fn)
+        (rec_magpo.py:99-100): the callables the loop CALLS for acting, the two training forwards and the two optimiser steps --
+        by default the bound methods of the objects above; get_learner_fn passes on what it was given (thin adaptors included)."""
         from .tuning import Tuning
         self.tuning = tuning if tuning is not None else (guider.tuning if guider is not None else Tuning.from_env())   # ONE object shared by both networks (tuning.py)
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
@@ -300,6 +303,9 @@ class MagpoLearner:
         self.guider, self.actor = guider, actor
         self.g_opt, self.a_opt = optims if optims is not None else (ClipAdam(guider, sys), ClipAdam(actor, sys))
         assert self.g_opt.net is guider and self.a_opt.net is actor
+        self.sable_action_select_fn, self.sable_apply_fn, self.actor_apply_fn = apply_fns if apply_fns is not None else \
+            (guider.get_actions, guider.apply, actor.apply)
+        self.sable_update_fn, self.actor_update_fn = update_fns if update_fns is not None else (self.g_opt.update, self.a_opt.update)
         self.loss_out = self.grad_all[gn + an:gn + an + 9]
         self.nt = self.guider.ntile
         self.groups: List[EnvGroup] = [EnvGroup(env_cfg, num_envs, self.T, device, self.nb, self.nt) for _ in range(num_groups)]
@@ -465,7 +471,7 @@ class MagpoLearner:
         if fused:   # fragment-major weight copies of the acting kernel from the current parameters (a node of the captured graph as well)
             self.guider.build_act_weights()
         gtag = str(self.groups.index(g))
-        act = (lambda *a, **k: self.guider.act_fused(*a, tag=gtag, **k)) if fused else self.guider.act
+        act = (lambda *a, **k: self.sable_action_select_fn(*a, tag=gtag, **k)) if fused else self.guider.act
 
         def zero_done(done):
             for k in range(self.nb):
@@ -641,12 +647,12 @@ class MagpoLearner:
         if side is not None:
             side.wait_stream(main)  # minibatch gather (and the previous optimiser step) are complete for the actor
             with torch.cuda.stream(side):
-                a_logits = self.actor.seq_fwd(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
-        g_logits, value = self.guider.train_fwd(m["obs"], m["prev"], m["pos"], m["done"], self._prev_hs, hidx, nseq, T, classes=gcl)
+                a_logits = self.actor_apply_fn(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
+        g_logits, value = self.sable_apply_fn(m["obs"], m["prev"], m["pos"], m["done"], self._prev_hs, hidx, nseq, T, classes=gcl)
         if side is not None:
             main.wait_stream(side)
         else:
-            a_logits = self.actor.seq_fwd(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
+            a_logits = self.actor_apply_fn(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
         st = self._st()
         if U == 1:
             if adv_stats is None:
@@ -678,8 +684,8 @@ class MagpoLearner:
 
     def apply_grads(self, grad_scale: float = 1.0):
         """optax clip_by_global_norm + adam + apply_updates on both flat buffers (rec_magpo.py:412-420): the two update functions."""
-        self.g_opt.update(grad_scale, self.ws64, self.gnorm[0:1])
-        self.last_lr = self.a_opt.update(grad_scale, self.ws64, self.gnorm[1:2])
+        self.sable_update_fn(grad_scale, self.ws64, self.gnorm[0:1])
+        self.last_lr = self.actor_update_fn(grad_scale, self.ws64, self.gnorm[1:2])
 
     # ------------------------------------------------------------------ update (rec_magpo.py:214-487)
     def update(self, grad_sync: Optional[Callable[["MagpoLearner"], float]] = None) -> torch.Tensor:

@@ -112,6 +112,26 @@ def load_learner_state(learner: MagpoLearner, state: GPOLearnerState) -> None:
         grp.key = np.array(state.key, dtype=np.uint32).copy()
 
 
+def _owner(fn, cls, method: str, what: str):
+    """The object whose device buffers ``fn`` acts on: ``fn`` must be the bound method ``cls.<method>`` or a thin adaptor around it
+    (``functools.partial(...).func`` / ``functools.wraps(...).__wrapped__`` chains are followed)."""
+    f, seen = fn, 0
+    while not hasattr(f, "__self__") and seen < 8:
+        f = getattr(f, "__wrapped__", None) or getattr(f, "func", None)
+        seen += 1
+        if f is None:
+            break
+    obj = getattr(f, "__self__", None)
+    names = {method} | ({"act_fused"} if method == "get_actions" else {"train_fwd", "seq_fwd"} if method == "apply" else set())
+    if not isinstance(obj, cls) or getattr(f, "__name__", None) not in names:
+        raise TypeError(
+            f"get_learner_fn: {what} must be the bound method {cls.__name__}.{method} of a network / optimiser object (or a functools.wraps / "
+            f"functools.partial adaptor around it), got {fn!r}.  Unlike the reference's pure functions of parameter pytrees, the HIP path keeps "
+            "parameters, activations and optimiser moments in device buffers owned by these objects and pairs each forward with a "
+            "hand-written backward, so a free function cannot stand in for them.")
+    return obj
+
+
 def get_learner_fn(env, apply_fns, update_fn, config):
     """Returns ``learn(learner_state) -> ExperimentOutput``: ``config.system.num_updates_per_eval`` update steps
     (rec_magpo.py:91-530).  Same contract as the reference:
@@ -119,23 +139,30 @@ def get_learner_fn(env, apply_fns, update_fn, config):
         apply_fns = (sable_action_select_fn, sable_apply_fn, actor_apply_fn)     rec_magpo.py:99   (execution / training / training)
         update_fn = (sable_update_fn, actor_update_fn)                           rec_magpo.py:100  (the two optimisers' update functions)
 
-    In the reference these are pure functions of parameter pytrees; here they are the bound methods of the objects that own the HIP
-    kernels' device buffers -- ``SableGuider.get_actions`` / ``SableGuider.apply`` / ``GruActor.apply`` and ``ClipAdam.update`` -- so the
-    networks and optimiser states they act on are reached through them (``fn.__self__``), and the learner loop (rollout, GAE, shuffles,
-    both losses, gradient mean over groups / ranks) is composed around them.  ``env``: the MarlEnv whose batched kernels the rollout steps.
+    In the reference these are pure functions of parameter pytrees.  Here the parameters, activations and optimiser moments live in device
+    buffers OWNED by objects (``SableGuider``, ``GruActor``, ``ClipAdam``), and a hand-written backward pairs every training forward, so
+    the five callables must be methods of such objects: ``SableGuider.get_actions`` / ``SableGuider.apply`` / ``GruActor.apply`` and
+    ``ClipAdam.update``, either the bound methods themselves or thin adaptors around them that expose the method as ``__wrapped__``
+    (``functools.wraps``) or ``func`` (``functools.partial``).  The loop CALLS exactly the callables it is given (rollout ->
+    ``sable_action_select_fn``, minibatch forward -> ``sable_apply_fn`` / ``actor_apply_fn``, optimiser step -> the update functions) and
+    reaches the owners' buffers / backward passes through them; anything else raises a ``TypeError`` that says so (``_owner``).
+    ``env``: the MarlEnv whose batched kernels the rollout steps.
 
     State in, state out: the learner's device buffers are a cache of the last state it produced.  When ``learner_state``
     is that state (the normal host loop, rec_magpo.py:754,792) nothing is copied; any other state (an older one, a restored
     checkpoint) is loaded into the buffers first, so ``learn`` is a function of its argument."""
     sable_action_select_fn, sable_apply_fn, actor_apply_fn = apply_fns
     sable_update_fn, actor_update_fn = update_fn
-    guider, actor = sable_apply_fn.__self__, actor_apply_fn.__self__
-    if sable_action_select_fn.__self__ is not guider:
+    guider = _owner(sable_apply_fn, SableGuider, "apply", "apply_fns[1] (sable_apply_fn)")
+    actor = _owner(actor_apply_fn, GruActor, "apply", "apply_fns[2] (actor_apply_fn)")
+    if _owner(sable_action_select_fn, SableGuider, "get_actions", "apply_fns[0] (sable_action_select_fn)") is not guider:
         raise ValueError("the execution and the training function must belong to one Sable network")
-    g_opt, a_opt = sable_update_fn.__self__, actor_update_fn.__self__
+    g_opt = _owner(sable_update_fn, ClipAdam, "update", "update_fn[0] (sable_update_fn)")
+    a_opt = _owner(actor_update_fn, ClipAdam, "update", "update_fn[1] (actor_update_fn)")
     rank, world = mdist.rank_world()
     U = int(config.system.update_batch_size)
-    learner = MagpoLearner(env.cfg, int(config.arch.num_envs), g_opt.sys, guider.dev, num_groups=U, guider=guider, actor=actor, optims=(g_opt, a_opt))
+    learner = MagpoLearner(env.cfg, int(config.arch.num_envs), g_opt.sys, guider.dev, num_groups=U, guider=guider, actor=actor, optims=(g_opt, a_opt),
+                           apply_fns=tuple(apply_fns), update_fns=tuple(update_fn))
     grad_sync = mdist.make_grad_sync(world)   # the pmean over ("batch", "device") of rec_magpo.py:395-409: one all-reduce of the flat buffer
 
     def learner_fn(learner_state: GPOLearnerState) -> ExperimentOutput:

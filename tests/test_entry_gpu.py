@@ -182,3 +182,62 @@ def test_lr_decay_uses_the_num_updates_check_total_timesteps_derives(tmp_path):
     base = float(cfg.system.actor_lr)
     want = [base * (1.0 - (i // per_update) / updates) for i in range(len(lrs))]
     assert np.allclose(lrs, want, rtol=1e-12, atol=0) and min(lrs) > 0 and abs(lrs[-1] - base / updates) < 1e-12
+
+
+def test_get_learner_fn_calls_the_functions_it_is_given_and_rejects_foreign_callables():
+    """rec_magpo.py:91-100: get_learner_fn(env, (sable_action_select_fn, sable_apply_fn, actor_apply_fn), (sable_update_fn, actor_update_fn),
+    config).  Here the five callables must be (adaptors around) methods of the objects that own the device buffers: (1) thin adaptors
+    are accepted and are what the loop CALLS (rollout, both training forwards, both optimiser steps), with the same result as the bound
+    methods; (2) a free function raises a TypeError that states the requirement."""
+    import functools
+    from magpo_amd.actor import GruActor
+    from magpo_amd.config import compose
+    from magpo_amd.learner import host_split, prng_key
+    from magpo_amd.optim import ClipAdam
+    from magpo_amd.sable import SableGuider
+    from magpo_amd.systems.gpo.anakin import rec_magpo
+    from magpo_amd.utils import make_env as environments
+    cfg = compose("rec_magpo", ["env=coordsum", "env/scenario=3x10-30", "arch.num_envs=6", "system.total_timesteps=~", "system.num_updates=2",
+                                "system.rollout_length=8", "system.ppo_epochs=2", "env.kwargs.time_limit=5"])
+    cfg.system.num_updates_per_eval = 1
+    env, _ = environments.make(cfg)
+    sysc = rec_magpo._system_config(cfg)
+    key = host_split(prng_key(3), 4)[0]
+
+    def build(adapt):
+        g = SableGuider(env.cfg.num_agents, env.cfg.num_actions, env.cfg.obs_dim, "cuda", max_pos=env.cfg.time_limit + 1, seed=5)
+        a = GruActor(env.cfg.num_agents, env.cfg.num_actions, env.cfg.obs_dim, "cuda", seed=6, tuning=g.tuning)
+        go, ao = ClipAdam(g, sysc), ClipAdam(a, sysc)
+        fns = [g.get_actions, g.apply, a.apply, go.update, ao.update]
+        calls = [0] * 5
+        if adapt:
+            def wrap(i, f):
+                @functools.wraps(f)
+                def w(*args, **kw):
+                    calls[i] += 1
+                    return f(*args, **kw)
+                return w
+            fns = [wrap(i, f) for i, f in enumerate(fns)]
+            fns[3] = functools.partial(fns[3])   # a partial around a wrapper around the bound method
+        learn = rec_magpo.get_learner_fn(env, tuple(fns[:3]), tuple(fns[3:]), cfg)
+        learn.learner.setup(key)
+        learn.learner._live_state = rec_magpo._snapshot_state(learn.learner)
+        out = learn(learn.learner._live_state)
+        return out, calls
+
+    plain, _ = build(False)
+    adapted, calls = build(True)
+    T, P, M = 8, 2, int(cfg.system.num_minibatches)
+    assert calls[0] == T + 1, "the rollout must call the execution function it was given (T steps + the bootstrap value)"
+    assert calls[1] == P * M and calls[2] == P * M and calls[4] == P * M, calls
+    for k, v in plain.learner_state.params.guider_params.items():
+        assert torch.equal(v, adapted.learner_state.params.guider_params[k]), k
+    g = SableGuider(env.cfg.num_agents, env.cfg.num_actions, env.cfg.obs_dim, "cuda", max_pos=env.cfg.time_limit + 1, seed=5)
+    a = GruActor(env.cfg.num_agents, env.cfg.num_actions, env.cfg.obs_dim, "cuda", seed=6, tuning=g.tuning)
+    go, ao = ClipAdam(g, sysc), ClipAdam(a, sysc)
+    with pytest.raises(TypeError, match="bound method SableGuider.apply"):
+        rec_magpo.get_learner_fn(env, (g.get_actions, lambda *x, **k: None, a.apply), (go.update, ao.update), cfg)
+    with pytest.raises(TypeError, match="bound method ClipAdam.update"):
+        rec_magpo.get_learner_fn(env, (g.get_actions, g.apply, a.apply), (print, ao.update), cfg)
+    with pytest.raises(TypeError, match="GruActor.apply"):
+        rec_magpo.get_learner_fn(env, (g.get_actions, g.apply, g.apply), (go.update, ao.update), cfg)
