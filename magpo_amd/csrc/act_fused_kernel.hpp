@@ -206,7 +206,9 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
       RT(1);
       // episode ended on the previous step: the carried state is zero (rec_magpo.py:164-169)
       // (pre-pass: the state in memory already carries the zeroing of ITS step; this step's zeroing follows the pending update)
-      const float decay = (!PRE && ((dmask >> e) & 1ull)) ? 0.f : a.kappa[h];
+      // Pre-pass without pending rows (first launch of a rollout, stand-alone step): memory already holds the carried state itself, so
+      // there is nothing to bring up to date -- decaying it here would decay it twice (found in round 4: the seam of consecutive rollouts)
+      const float decay = PRE ? (apply_pending ? a.kappa[h] : 1.0f) : (((dmask >> e) & 1ull) ? 0.f : a.kappa[h]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r].x *= decay; s[r].y *= decay; s[r].z *= decay; s[r].w *= decay; }
 #pragma unroll
@@ -329,8 +331,9 @@ __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* 
       for (int t = 0; t < NA; ++t)
         if (t < A && lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[jb][t];
       lsync();
+      const float kin = a.pending ? kappa : 1.0f;   // no pending rows: memory holds the carried state itself (see ret_pass)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { s[j].x *= kappa; s[j].y *= kappa; s[j].z *= kappa; s[j].w *= kappa; }
+      for (int j = 0; j < 16; ++j) { s[j].x *= kin; s[j].y *= kin; s[j].z *= kin; s[j].w *= kin; }
       if (a.pending) {
 #pragma unroll
         for (int t = 0; t < NA; ++t) {

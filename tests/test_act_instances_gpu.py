@@ -116,6 +116,53 @@ def test_forced_instance_against_the_oracle(epw, A, K, TL, maxval, N, T, nb, nh)
     assert dl.groups[0].graph is not None and not dl.groups[0].graph_failed
 
 
+@pytest.mark.parametrize("epw", [4, 8, 16])
+@pytest.mark.parametrize("A,K,N,nb,nh", [(4, 20, 21, 1, 1), (3, 10, 18, 2, 1), (5, 15, 9, 1, 2), (8, 15, 10, 2, 1)])
+def test_carried_decoder_states_across_rollout_seams(epw, A, K, N, nb, nh):
+    """NO episode ends inside or between the rollouts (time limit 100 > 4 x 6 steps), so every rollout starts from non-zero decoder states
+    that nothing resets: the first launch of a rollout has no pending rows and must take the carried states as they are (round 4 found
+    them decayed twice there -- invisible wherever an episode end zeroes the states before they are compared).  Fused instance against
+    the oracle AND the kernel-by-kernel path over four rollouts (the third and fourth as HIP-graph capture / replay)."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
+    T, TL, maxval = 6, 100, 3 * K
+    gp = onets.init_guider_params(1, 64, A + 1, K, nb=nb, nh=nh)
+    for n in gp:   # larger output projections: the decoder states must matter for the logits (at init W_o ~ 1 / 64 hides them)
+        if n.endswith("w_o"):
+            gp[n] = gp[n] * 8.0
+    ap = onets.init_actor_params(2, A + 1, 128, K)
+    ol = olearn.OracleLearner(ocs.CoordSumSpec(A, K, TL, maxval), N, olearn.SystemCfg(rollout_length=T, ppo_epochs=1, num_minibatches=1),
+                              onets.SableCfg(A, K, A + 1, embed_dim=64, n_block=nb, n_head=nh), gp, ap)
+    key = oprng.split(oprng.prng_key(29), 4)[0]
+    ol.setup(key)
+    dls = []
+    for fused in (True, False):
+        dl = MagpoLearner(CoordSumConfig(A, K, TL, maxval), N, SystemConfig(rollout_length=T, ppo_epochs=1, num_minibatches=1), DEV,
+                          net_seed=None, wgrad_groups=4, n_block=nb, n_head=nh, tuning=_tuning(epw))
+        dl.fused_act, dl.use_graph = fused, fused
+        dl.guider.load_named(gp)
+        dl.actor.load_named(ap)
+        dl.setup(key)
+        dls.append(dl)
+    hs = 64 // nh
+    for it in range(4):
+        om = ol.rollout()
+        assert not om["is_terminal_step"].any()
+        for dl in dls:
+            dl.rollout()
+        f, c = dls
+        what = f"{_instance(N, A, nh, epw)} rollout {it}"
+        assert np.array_equal(f.traj["action"].cpu().numpy(), ol.traj["action"].numpy()), f"{what}: sampled actions differ from the oracle"
+        assert torch.equal(f.traj["action"], c.traj["action"])
+        close(f.traj["log_prob"], ol.traj["log_prob"], 1e-4, 2e-6, f"{what}: log_prob")
+        for d, d2, o in zip(f.sable_hs, c.sable_hs, ol.sable_hs):
+            assert float(o.abs().max()) > 1e-2
+            close(d[:, :, :, :hs, :hs], o.permute(2, 1, 0, 3, 4), 1e-4, 2e-6, f"{what}: carried state vs the oracle")
+            close(d, d2, 3e-5, 1e-6, f"{what}: carried state vs the kernel composition")
+        for dl in dls:
+            dl._carry_over()
+    assert dls[0].groups[0].graph is not None and not dls[0].groups[0].graph_failed
+
+
 FULL = [(16384, 4, 20, 1, 1), (4096, 4, 20, 1, 1), (8192, 4, 5, 1, 1), (16384, 8, 15, 2, 1), (16384, 2, 6, 1, 1), (4096, 8, 15, 2, 1)]
 
 
