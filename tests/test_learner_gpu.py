@@ -330,3 +330,60 @@ def test_linear_lr_decay_matches_oracle():
         for n, v in dl.guider.named.items():
             close(v, ol.gp[n].reshape(v.shape), 0, 6e-5 * (s + 1), f"guider param {n} (update {s + 1})")
     assert ol._lr(4) == pytest.approx(1e-3 * 2 / 3) and ol._lr(3) == 1e-3
+
+
+@pytest.mark.parametrize("E,nh,nb", [(64, 1, 1), (128, 2, 2)])
+def test_dense_bf16_triples_whole_minibatch_gradient_error_vs_fp64(E, nh, nb):
+    """Acceptance test for the dense layers on bf16 MFMA with three-piece operand splits (Tuning.linear_variant bit 2; VERDICT r3 item 3 i):
+    the gradient of a WHOLE minibatch (rollout of 128 steps, both networks, both losses) against the oracle evaluated in fp64 on the same
+    trajectory and parameters.  Measured (round 4): fp32 MFMA 1.043e-7 / bf16 x3 1.047e-7 for the default net, 8.19e-8 / 8.84e-8 for an
+    embed-128 / 2-head / 2-block net -- both at fp32 rounding level, the triples NOT more accurate (six of the nine partial products), so
+    the question "is it as good as fp32 MFMA" is answered "to within 8 %", not "yes".  With the unexplained -3.0 +- 1.3 of the ten-seed
+    learning check (profiles/r03_sweep_return_at_10M.md) that settles it: the dense-layer triples stay OPT-IN (MAGPO_LINEAR_BF3=1, ~1 % of
+    the headline step), this test pins their accuracy at <= 1.10 x the fp32-MFMA gradient error."""
+    from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
+    from magpo_amd.tuning import Tuning
+    A, K, TL, maxval, N, T = 4, 20, 100, 60, 16, 128
+    spec = ocs.CoordSumSpec(A, K, TL, maxval)
+    scfg = onets.SableCfg(A, K, A + 1, embed_dim=E, n_block=nb, n_head=nh)
+    osys = olearn.SystemCfg(rollout_length=T, ppo_epochs=1, num_minibatches=1)
+    gp = onets.init_guider_params(1, E, A + 1, K, nb=nb, nh=nh)
+    ap = onets.init_actor_params(2, A + 1, 128, K)
+    ol = olearn.OracleLearner(spec, N, osys, scfg, gp, ap)
+    key = oprng.split(oprng.prng_key(7), 4)[0]
+    ol.setup(key)
+    ol.rollout()
+    ol.rollout()   # second rollout: non-zero rollout-start states
+    ks = oprng.split(ol.key, 4)
+    bp, apm = oprng.permutation(ks[1], N), oprng.permutation(ks[2], A)
+    mb = ol.make_minibatches(bp, apm)[0]
+    to64 = lambda x: x.double() if torch.is_tensor(x) and x.is_floating_point() else (tuple(to64(y) for y in x) if isinstance(x, tuple) else x)
+    ol64 = olearn.OracleLearner(spec, N, osys, scfg, gp, ap, dtype=torch.float64)
+    gg, ag, _, _ = ol64.minibatch_grads({k: to64(v) for k, v in mb.items()})
+    errs = {}
+    for name, variant in (("fp32_mfma", 0), ("bf16x3", 4)):
+        t = Tuning()
+        t.linear_variant = t.actor_linear_variant = variant
+        dl = MagpoLearner(CoordSumConfig(A, K, TL, maxval), N, SystemConfig(rollout_length=T, ppo_epochs=1, num_minibatches=1), DEV,
+                          net_seed=None, wgrad_groups=8, n_block=nb, n_head=nh, embed_dim=E, tuning=t)
+        dl.guider.load_named(gp); dl.actor.load_named(ap)
+        dl.setup(key)
+        dl.rollout(); dl._carry_over(); dl.rollout()
+        assert np.array_equal(dl.traj["action"].cpu().numpy(), ol.traj["action"].numpy())
+        dl.minibatch_grads(dl._permutation(ks[1], N), dl._permutation(ks[2], A))
+        num = den = 0.0
+        worst = ("", 0.0)
+        for net, ref in ((dl.guider, gg), (dl.actor, ag)):
+            for n, g in net.named_grads.items():
+                r = ref[n].reshape(g.shape)
+                d = float((g.detach().cpu().double() - r).pow(2).sum())
+                num += d; den += float(r.pow(2).sum())
+                rel = (d / max(float(r.pow(2).sum()), 1e-30)) ** 0.5
+                if rel > worst[1]:
+                    worst = (n, rel)
+        errs[name] = (num / den) ** 0.5
+        print(f"[{E}-{nh}-{nb}] {name}: relative gradient error vs fp64 {errs[name]:.3e} (worst tensor {worst[0]}: {worst[1]:.3e})")
+        del dl
+        torch.cuda.empty_cache()
+    assert errs["fp32_mfma"] < 1e-4, errs
+    assert errs["bf16x3"] <= 1.10 * errs["fp32_mfma"] + 1e-9, f"bf16 x3 dense layers are less accurate than fp32 MFMA: {errs}"
