@@ -506,6 +506,13 @@ constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
 #define MAGPO_ACT_NBUF_CAND 2
 #endif
 
+#ifndef MAGPO_ACT_STAGGER_MOD
+#define MAGPO_ACT_STAGGER_MOD 2
+#define MAGPO_ACT_STAGGER_EARLY 1
+#endif
+#ifndef MAGPO_ACT_STAGGER_SHIFT
+#define MAGPO_ACT_STAGGER_SHIFT 3   // workgroups alternate between the two phase orders in groups of 2^shift
+#endif
 #ifndef MAGPO_ACT_STAGGER
 #define MAGPO_ACT_STAGGER 1   // 1: half of the workgroups run the candidate pre-pass ahead of the encoder (see cand_early)
 #endif
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
   // rows and on parameters only -- not on this step's encoder.  All waves start together and walk the same phases, so the chip alternates
   // between phases in which every wave streams states (HBM-bound, ~5 TB/s) and dense phases in which none does.  STAGGER: every other
   // group of 8 workgroups runs the candidate pre-pass FIRST, so that one half of the waves streams while the other half computes.
-  const bool cand_early = cand && !a.value_only && MAGPO_ACT_STAGGER && ((blockIdx.x >> 3) & 1);
+  const bool cand_early = cand && !a.value_only && MAGPO_ACT_STAGGER && (int)((blockIdx.x >> MAGPO_ACT_STAGGER_SHIFT) % MAGPO_ACT_STAGGER_MOD) < MAGPO_ACT_STAGGER_EARLY;
   auto cand_pass = [&]() __attribute__((always_inline)) {
     const ActBlk& B = a.blk[0];
     float4 pS1[16];   // the first self-retention state of the candidate pass
