@@ -34,6 +34,8 @@ int magpo_threefry_split(const uint32_t* key, uint32_t* out, long num, magpo_str
 int magpo_threefry_random_bits(const uint32_t* key, uint32_t* out, long num, magpo_stream_t stream);
 int magpo_key_split_host(const uint32_t* key_host, int num, uint32_t* out_host);
 int magpo_random_bits_host(const uint32_t* key_host, int num, uint32_t* out_host);
+/* jax.random.fold_in(key, data) on the host (flax's per-parameter init keys: rec_magpo.py:598-604,623 via magpo_amd/params.py) */
+int magpo_key_fold_in_host(const uint32_t* key_host, uint32_t data, uint32_t* out_host);
 
 /* ---- K1 CoordSum env + wrappers (coordsum/env.py:55-139, wrappers/{matrax,observation,auto_reset_wrapper,episode_metrics}.py) ----
  * The step entry points of all three envs write one TimeStep (mava/types.py:45-123 MarlEnv.step): reward [N][A], discount [N][A]

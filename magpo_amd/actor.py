@@ -10,6 +10,8 @@ from __future__ import annotations
 from typing import Dict, Optional
 
 import contextlib
+
+import numpy as np
 import torch
 
 from ._lib import lib
@@ -41,7 +43,10 @@ class GruActor:
         self.gv = self.P.views(self.grads)
         self.named = actor_named_views(self.v)
         self.named_grads = actor_named_views(self.gv)
-        if seed is not None:
+        if isinstance(seed, np.ndarray):   # a PRNG key: the parameters flax creates from it (rec_magpo.py:623; params.init_actor_from_key)
+            from .params import init_actor_from_key
+            init_actor_from_key(self.named, seed)
+        elif seed is not None:
             init_actor(self.named, seed)
         self.wt: Dict[str, torch.Tensor] = {}
         self.b = _Bufs(device)

@@ -355,6 +355,11 @@ extern "C" int magpo_key_split_host(const uint32_t* key, int num, uint32_t* out)
   for (int i = 0; i < num; ++i) threefry2x32(key[0], key[1], 0u, (uint32_t)i, out[2 * i], out[2 * i + 1]);
   return MAGPO_OK;
 }
+// jax.random.fold_in(key, data) = threefry2x32(key, (0, data)) (flax derives every parameter's init key this way: params.py)
+extern "C" int magpo_key_fold_in_host(const uint32_t* key, uint32_t data, uint32_t* out) {
+  threefry2x32(key[0], key[1], 0u, data, out[0], out[1]);
+  return MAGPO_OK;
+}
 extern "C" int magpo_random_bits_host(const uint32_t* key, int num, uint32_t* out) {
   for (int i = 0; i < num; ++i) out[i] = random_bits32(key[0], key[1], (uint32_t)i);
   return MAGPO_OK;

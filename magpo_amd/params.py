@@ -13,6 +13,7 @@ import math
 from collections import OrderedDict
 from typing import Dict, Tuple
 
+import numpy as np
 import torch
 
 
@@ -283,3 +284,126 @@ def init_actor(named: Dict[str, torch.Tensor], seed: int) -> None:
                 v.copy_(_orthogonal(gen, tuple(v.shape), 0.01))
             else:
                 v.copy_(_orthogonal(gen, tuple(v.shape), math.sqrt(2.0)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Same-seed initialisation (rec_magpo.py:598-604: sable_network.init(net_key, ...); :623: actor_network.init(actor_net_key, ...)).
+# The reference's parameters are a function of (net_key, actor_net_key): flax derives one key per parameter from the 'params' key and the
+# module path, and jax's initialisers draw from it.  This restates both on the host (threefry through the C ABI's host entry points,
+# float32 numpy for the samplers, LAPACK for the QR) so that ``system.seed`` selects the same run here as there -- up to what cannot be
+# checked without JAX (the restatement is from memory; the last bits of XLA's erf_inv / QR): UNPINNED, see oracle/prng.py.
+# tests/test_oracle_prng.py compares these arrays with the oracle's restatement bit for bit and checks the distributions.
+
+def _fold_in(key: np.ndarray, data: int) -> np.ndarray:
+    from ._lib import lib
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(2, np.uint32)
+    lib().raw("magpo_key_fold_in_host")(key.ctypes.data, int(data) & 0xFFFFFFFF, out.ctypes.data)
+    return out
+
+
+def _param_key(params_key: np.ndarray, path: Tuple[str, ...], counter: int) -> np.ndarray:
+    """flax/core/scope.py: LazyRng(params_key, path + (counter,)) -> fold_in(params_key, sha1(names and integer bytes)[:4] big endian)."""
+    import hashlib
+    m = hashlib.sha1()
+    for x in tuple(path) + (int(counter),):
+        m.update(x.encode("utf-8") if isinstance(x, str) else int(x).to_bytes((int(x).bit_length() + 7) // 8, byteorder="big"))
+    return _fold_in(params_key, int.from_bytes(m.digest()[:4], byteorder="big"))
+
+
+def _uniform(key: np.ndarray, n: int, lo: np.float32, hi: np.float32) -> np.ndarray:
+    from ._lib import lib
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    bits = np.empty(n, np.uint32)
+    lib().raw("magpo_random_bits_host")(key.ctypes.data, int(n), bits.ctypes.data)
+    u = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
+    return np.maximum(lo, u * (hi - lo) + lo).astype(np.float32)
+
+
+def _erf_inv(x: np.ndarray) -> np.ndarray:
+    """float32 erf_inv: M. Giles' single-precision polynomial (central branch for -log(1 - x^2) < 5, tail branch beyond)."""
+    f = np.float32
+    w = -np.log1p(-(x * x)).astype(np.float32)
+    a = (w - f(2.5)).astype(np.float32)
+    p = f(2.81022636e-08)
+    for c in (3.43273939e-07, -3.5233877e-06, -4.39150654e-06, 0.00021858087, -0.00125372503, -0.00417768164, 0.246640727, 1.50140941):
+        p = (f(c) + p * a).astype(np.float32)
+    b = (np.sqrt(np.maximum(w, f(5.0))).astype(np.float32) - f(3.0)).astype(np.float32)
+    q = f(-0.000200214257)
+    for c in (0.000100950558, 0.00134934322, -0.00367342844, 0.00573950773, -0.0076224613, 0.00943887047, 1.00167406, 2.83297682):
+        q = (f(c) + q * b).astype(np.float32)
+    return (np.where(w < f(5.0), p, q) * x).astype(np.float32)
+
+
+def _normal(key: np.ndarray, shape) -> np.ndarray:
+    n = int(np.prod(shape))
+    u = _uniform(key, n, np.nextafter(np.float32(-1.0), np.float32(0.0)), np.float32(1.0))
+    return (np.float32(np.sqrt(2)) * _erf_inv(u)).astype(np.float32).reshape(shape)
+
+
+def _trunc_normal(key: np.ndarray, shape, lower: float = -2.0, upper: float = 2.0) -> np.ndarray:
+    f = np.float32
+    s2 = f(np.sqrt(2))
+    a, b = f(math.erf(float(f(lower) / s2))), f(math.erf(float(f(upper) / s2)))
+    out = (s2 * _erf_inv(_uniform(key, int(np.prod(shape)), a, b))).astype(np.float32)
+    return np.clip(out, np.nextafter(f(lower), f(np.inf)), np.nextafter(f(upper), f(-np.inf))).astype(np.float32).reshape(shape)
+
+
+def _orth(key: np.ndarray, shape, scale: float) -> np.ndarray:
+    rows, cols = int(shape[0]), int(shape[1])
+    a = _normal(key, (cols, rows) if rows < cols else (rows, cols))
+    q, r = np.linalg.qr(a)
+    q = (q * np.sign(np.diag(r))[None, :]).astype(np.float32)
+    return (np.float32(scale) * (q.T if rows < cols else q)).astype(np.float32)
+
+
+def init_guider_from_key(named: Dict[str, torch.Tensor], net_key: np.ndarray, E: int, n_head: int) -> None:
+    """The Sable parameters flax creates from ``net_key`` (module paths: oracle/networks.py:init_guider_params_from_key and the
+    reference lines cited there).  ``named``: the logical named views (retention projections as [n_head, E, E / n_head])."""
+    s2 = math.sqrt(2.0)
+    key = lambda path, c: _param_key(net_key, path, c)
+    hs = E // n_head
+    with torch.no_grad():
+        def put(name, arr):
+            named[name].copy_(torch.from_numpy(np.ascontiguousarray(arr)).reshape(named[name].shape))
+        for name, v in named.items():
+            v.fill_(1.0) if name.endswith("scale") else v.zero_()
+        F, K = named["enc.obs.dense.kernel"].shape[0], named["dec.head.dense1.kernel"].shape[-1]
+        put("enc.obs.dense.kernel", _orth(key(("encoder", "obs_encoder", "layers_1"), 1), (F, E), s2))
+        put("enc.head.dense0.kernel", _orth(key(("encoder", "head", "layers_0"), 1), (E, E), s2))
+        put("enc.head.dense1.kernel", _orth(key(("encoder", "head", "layers_3"), 1), (E, 1), 0.01))
+        put("dec.act.kernel", _orth(key(("decoder", "action_encoder", "layers_0"), 1), (K + 1, E), s2))
+        put("dec.head.dense0.kernel", _orth(key(("decoder", "head", "layers_0"), 1), (E, E), s2))
+        put("dec.head.dense1.kernel", _orth(key(("decoder", "head", "layers_3"), 1), (E, K), 0.01))
+        b = 0
+        while f"enc.block{b}.retn.w_g" in named:
+            for prefix, path in ((f"enc.block{b}.retn.", ("encoder", f"encoder_block_{b}", "retn")),
+                                 (f"dec.block{b}.retn1.", ("decoder", f"decoder_block_{b}", "retn1")),
+                                 (f"dec.block{b}.retn2.", ("decoder", f"decoder_block_{b}", "retn2"))):
+                put(prefix + "w_g", _normal(key(path, 1), (E, E)) * np.float32(1.0 / E))
+                put(prefix + "w_o", _normal(key(path, 2), (E, E)) * np.float32(1.0 / E))
+                for c, n in enumerate(("w_q", "w_k", "w_v"), start=1):
+                    put(prefix + n, np.stack([_normal(key(path + (f"retention_heads_{h}",), c), (E, hs)) * np.float32(1.0 / E) for h in range(n_head)]))
+            b += 1
+
+
+def init_actor_from_key(named: Dict[str, torch.Tensor], actor_net_key: np.ndarray) -> None:
+    """The RecurrentActor parameters flax creates from ``actor_net_key`` (oracle/networks.py:init_actor_params_from_key)."""
+    s2 = math.sqrt(2.0)
+    key = lambda path, c: _param_key(actor_net_key, path, c)
+    with torch.no_grad():
+        def put(name, arr):
+            named[name].copy_(torch.from_numpy(np.ascontiguousarray(arr)).reshape(named[name].shape))
+        for v in named.values():
+            v.zero_()
+        F, H = named["pre.kernel"].shape
+        K = named["head.kernel"].shape[1]
+        put("pre.kernel", _orth(key(("pre_torso", "Dense_0"), 1), (F, H), s2))
+        cell = ("ScannedRNN_0", "GRUCell_0")
+        std = np.float32(np.sqrt(np.float32(1.0) / np.float32(H))) / np.float32(0.87962566103423978)
+        for g in ("ir", "iz", "in"):
+            put(f"gru.{g}.kernel", _trunc_normal(key(cell + (g,), 1), (H, H)) * std)
+        for g in ("hr", "hz", "hn"):
+            put(f"gru.{g}.kernel", _orth(key(cell + (g,), 1), (H, H), 1.0))
+        put("post.kernel", _orth(key(("post_torso", "Dense_0"), 1), (H, H), s2))
+        put("head.kernel", _orth(key(("action_head", "Dense_0"), 1), (H, K), 0.01))

@@ -95,7 +95,10 @@ class SableGuider:
         self.gv = self.PD.views(self.grads_D)
         self.named = guider_named_views(self.P.views(), self.EL, self.nh)
         self.named_grads = guider_named_views(self.P.views(self.grads), self.EL, self.nh)
-        if seed is not None:
+        if isinstance(seed, np.ndarray):   # a PRNG key: the parameters flax creates from it (rec_magpo.py:598-604; params.init_guider_from_key)
+            from .params import init_guider_from_key
+            init_guider_from_key(self.named, seed, self.EL, self.nh)
+        elif seed is not None:
             init_guider(self.named, seed, self.EL)
         self.npos = max_pos
         self.pe = torch.zeros(max_pos, E, device=device)

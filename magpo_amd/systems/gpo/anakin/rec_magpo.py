@@ -212,11 +212,11 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
     U = int(config.system.update_batch_size)
     # networks (rec_magpo.py:559-579), optimisers (:581-589) -- objects that own their kernels' device buffers
     cfg, sysc = env.cfg, _system_config(config)
-    seed = int(net_key[1]) & 0x7FFFFFFF
+    # parameters = what flax creates from net_key / actor_net_key (rec_magpo.py:598-604,623; magpo_amd/params.py, UNPINNED restatement)
     sable_network = SableGuider(cfg.num_agents, cfg.num_actions, cfg.obs_dim, device, embed_dim=int(nc.embed_dim), n_head=int(nc.n_head),
                                 n_block=int(nc.n_block), decay_scaling_factor=float(mc.decay_scaling_factor),
-                                use_pe=bool(mc.timestep_positional_encoding), max_pos=cfg.time_limit + 1, seed=seed)
-    actor_network = GruActor(cfg.num_agents, cfg.num_actions, cfg.obs_dim, device, seed=seed + 1, tuning=sable_network.tuning)
+                                use_pe=bool(mc.timestep_positional_encoding), max_pos=cfg.time_limit + 1, seed=np.asarray(net_key, np.uint32))
+    actor_network = GruActor(cfg.num_agents, cfg.num_actions, cfg.obs_dim, device, seed=np.asarray(actor_net_key, np.uint32), tuning=sable_network.tuning)
     guider_optim, actor_optim = ClipAdam(sable_network, sysc), ClipAdam(actor_network, sysc)
     # Pack apply and update functions (rec_magpo.py:624-632)
     apply_fns = (sable_network.get_actions, sable_network.apply, actor_network.apply)

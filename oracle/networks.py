@@ -497,3 +497,56 @@ def actor_apply(p, hidden, obs, done, mask):
     y = torch.relu(ys @ p["post.kernel"] + p["post.bias"])
     logits = y @ p["head.kernel"] + p["head.bias"]
     return h, masked_log_softmax(logits, mask), ys
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Same-seed initialisation: the parameters flax would create from rec_magpo.py:598-604 (sable_network.init(net_key, ...)) and :623
+# (actor_network.init(actor_net_key, ...)).  Module paths as the reference's modules name their children (sable_network.py:46-60 setup
+# attributes ln1 / ln2 / retn / ffn; :97-125 Sequential children layers_<i>; :118-125,283-291 encoder_block_<i> / decoder_block_<i>;
+# retention.py:237-262 w_g, w_o, group_norm, retention_heads_<h>; :50-64 w_q, w_k, w_v; base.py:152-195 pre_torso / ScannedRNN_0 /
+# GRUCell_0 / post_torso / action_head with auto-named Dense_0 children), per-scope parameter counters in creation order (Dense: kernel 1,
+# bias 2).  PARITY UNPINNED (oracle/prng.py: samplers and flax's key derivation are restated from memory).
+
+
+def init_guider_params_from_key(net_key: np.ndarray, E: int, F: int, K: int, nh: int = 1, nb: int = 1, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    s2 = math.sqrt(2.0)
+    key = lambda path, c: prng.flax_param_key(net_key, path, c)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    p: Dict[str, torch.Tensor] = {}
+    for name, shape in guider_param_shapes(E, F, K, nh, nb).items():   # ones / zeros first; the random tensors overwrite below
+        p[name] = torch.ones(shape, dtype=dtype) if name.endswith("scale") else torch.zeros(shape, dtype=dtype)
+    p["enc.obs.dense.kernel"] = t(prng.init_orthogonal(key(("encoder", "obs_encoder", "layers_1"), 1), (F, E), s2))
+    p["enc.head.dense0.kernel"] = t(prng.init_orthogonal(key(("encoder", "head", "layers_0"), 1), (E, E), s2))
+    p["enc.head.dense1.kernel"] = t(prng.init_orthogonal(key(("encoder", "head", "layers_3"), 1), (E, 1), 0.01))
+    p["dec.act.kernel"] = t(prng.init_orthogonal(key(("decoder", "action_encoder", "layers_0"), 1), (K + 1, E), s2))
+    p["dec.head.dense0.kernel"] = t(prng.init_orthogonal(key(("decoder", "head", "layers_0"), 1), (E, E), s2))
+    p["dec.head.dense1.kernel"] = t(prng.init_orthogonal(key(("decoder", "head", "layers_3"), 1), (E, K), 0.01))
+    hs = E // nh
+
+    def retn(prefix, path):
+        p[prefix + "w_g"] = t(prng.init_normal(key(path, 1), (E, E), 1.0 / E))
+        p[prefix + "w_o"] = t(prng.init_normal(key(path, 2), (E, E), 1.0 / E))
+        for c, n in enumerate(("w_q", "w_k", "w_v"), start=1):
+            p[prefix + n] = t(np.stack([prng.init_normal(key(path + (f"retention_heads_{h}",), c), (E, hs), 1.0 / E) for h in range(nh)]))
+
+    for b in range(nb):
+        retn(f"enc.block{b}.retn.", ("encoder", f"encoder_block_{b}", "retn"))
+        retn(f"dec.block{b}.retn1.", ("decoder", f"decoder_block_{b}", "retn1"))
+        retn(f"dec.block{b}.retn2.", ("decoder", f"decoder_block_{b}", "retn2"))
+    return p
+
+
+def init_actor_params_from_key(actor_net_key: np.ndarray, F: int, H: int, K: int, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    s2 = math.sqrt(2.0)
+    key = lambda path, c: prng.flax_param_key(actor_net_key, path, c)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    p = {name: torch.zeros(shape, dtype=dtype) for name, shape in actor_param_shapes(F, H, K).items()}
+    p["pre.kernel"] = t(prng.init_orthogonal(key(("pre_torso", "Dense_0"), 1), (F, H), s2))
+    cell = ("ScannedRNN_0", "GRUCell_0")
+    for g in ("ir", "iz", "in"):
+        p[f"gru.{g}.kernel"] = t(prng.init_lecun_normal(key(cell + (g,), 1), (H, H)))
+    for g in ("hr", "hz", "hn"):
+        p[f"gru.{g}.kernel"] = t(prng.init_orthogonal(key(cell + (g,), 1), (H, H), 1.0))
+    p["post.kernel"] = t(prng.init_orthogonal(key(("post_torso", "Dense_0"), 1), (H, H), s2))
+    p["head.kernel"] = t(prng.init_orthogonal(key(("action_head", "Dense_0"), 1), (H, K), 0.01))
+    return p

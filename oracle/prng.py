@@ -187,3 +187,92 @@ def choice(key: np.ndarray, n: int, num: int = 1, replace: bool = True, p=None) 
         g = (gumbel(key, n) + np.log(p_arr.astype(np.float64)).astype(np.float32)).astype(np.float32)
     order = np.argsort(-g.astype(np.float64), kind="stable")   # descending, equal values keep index order (lax.top_k)
     return order[:num].astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Parameter initialisation on the JAX stream (rec_magpo.py:598-604,623: sable_network.init(net_key, ...), actor_network.init(actor_net_key, ...)).
+# PARITY UNPINNED, twice over: (a) the samplers below restate jax/_src/random.py and jax/_src/nn/initializers.py from memory (normal =
+# sqrt(2) erf_inv(uniform(nextafter(-1, 0), 1)); truncated_normal; variance_scaling; orthogonal = QR of a normal draw with the sign fix)
+# and evaluate erf_inv with the single-precision polynomial of M. Giles, "Approximating the erfinv function" (the one XLA uses), in
+# numpy float32 -- XLA's own log1p / fused multiply-adds and LAPACK's QR may differ from it in the last bits; (b) the per-parameter keys
+# restate flax's scope RNG (flax/core/scope.py: LazyRng / _fold_in_static: sha1 over the module path and the per-scope make_rng counter,
+# first four digest bytes folded into the 'params' key), also from memory.  What IS pinned here: distributions (moments, orthogonality,
+# truncation bounds) and that the product's initialiser (magpo_amd/params.py) reproduces these arrays bit for bit.
+
+
+def fold_in(key: np.ndarray, data: int) -> np.ndarray:
+    """jax.random.fold_in(key, data) = threefry2x32(key, threefry_seed(uint32 data)) with seed words (0, data)."""
+    key = np.asarray(key, dtype=_U32)
+    x0, x1 = threefry2x32(key[0], key[1], _U32(0), _U32(int(data) & 0xFFFFFFFF))
+    return np.array([x0, x1], dtype=_U32)
+
+
+def flax_param_key(params_key: np.ndarray, path, counter: int) -> np.ndarray:
+    """Key flax hands to the initialiser of the ``counter``-th parameter (1-based, in creation order) of the module at ``path`` (tuple of
+    scope names below the root): LazyRng(params_key, path + (counter,)).as_jax_rng() = fold_in(params_key, first 4 bytes (big endian) of
+    sha1 over the utf-8 names and the minimal big-endian bytes of the integers)."""
+    import hashlib
+    m = hashlib.sha1()
+    for x in tuple(path) + (int(counter),):
+        if isinstance(x, str):
+            m.update(x.encode("utf-8"))
+        else:
+            m.update(int(x).to_bytes((int(x).bit_length() + 7) // 8, byteorder="big"))
+    return fold_in(params_key, int.from_bytes(m.digest()[:4], byteorder="big"))
+
+
+def erf_inv_f32(x: np.ndarray) -> np.ndarray:
+    """Single-precision erf_inv (Giles' polynomial, central branch w < 5 and tail branch), every operation rounded to float32."""
+    x = np.asarray(x, dtype=np.float32)
+    f = np.float32
+    w = -np.log1p(-(x * x)).astype(np.float32)
+    wc = (w - f(2.5)).astype(np.float32)
+    p = f(2.81022636e-08)
+    for c in (3.43273939e-07, -3.5233877e-06, -4.39150654e-06, 0.00021858087, -0.00125372503, -0.00417768164, 0.246640727, 1.50140941):
+        p = (f(c) + p * wc).astype(np.float32)
+    wt = (np.sqrt(np.maximum(w, f(5.0))).astype(np.float32) - f(3.0)).astype(np.float32)
+    q = f(-0.000200214257)
+    for c in (0.000100950558, 0.00134934322, -0.00367342844, 0.00573950773, -0.0076224613, 0.00943887047, 1.00167406, 2.83297682):
+        q = (f(c) + q * wt).astype(np.float32)
+    return (np.where(w < f(5.0), p, q) * x).astype(np.float32)
+
+
+def normal(key: np.ndarray, n: int) -> np.ndarray:
+    """jax.random.normal(key, (n,), float32): sqrt(2) * erf_inv(uniform(key, minval=nextafter(-1, 0), maxval=1))."""
+    lo = np.nextafter(np.float32(-1.0), np.float32(0.0))
+    u = bits_to_uniform(random_bits(key, n), lo, 1.0)
+    return (np.float32(np.sqrt(2)) * erf_inv_f32(u)).astype(np.float32)
+
+
+def truncated_normal(key: np.ndarray, n: int, lower: float = -2.0, upper: float = 2.0) -> np.ndarray:
+    """jax.random.truncated_normal(key, lower, upper, (n,), float32)."""
+    f = np.float32
+    s2 = f(np.sqrt(2))
+    a, b = f(math.erf(float(f(lower) / s2))), f(math.erf(float(f(upper) / s2)))
+    u = bits_to_uniform(random_bits(key, n), a, b)
+    out = (s2 * erf_inv_f32(u)).astype(np.float32)
+    return np.clip(out, np.nextafter(f(lower), f(np.inf)), np.nextafter(f(upper), f(-np.inf))).astype(np.float32)
+
+
+def init_normal(key: np.ndarray, shape, stddev: float) -> np.ndarray:
+    """nn.initializers.normal(stddev)(key, shape): random.normal * stddev (retention.py:50-64,237-246: stddev = 1 / embed_dim)."""
+    return (normal(key, int(np.prod(shape))).reshape(shape) * np.float32(stddev)).astype(np.float32)
+
+
+def init_lecun_normal(key: np.ndarray, shape) -> np.ndarray:
+    """variance_scaling(1.0, 'fan_in', 'truncated_normal') for a Dense kernel [fan_in, fan_out] (flax GRUCell's input kernels)."""
+    std = np.float32(np.sqrt(np.float32(1.0) / np.float32(shape[0]))) / np.float32(0.87962566103423978)
+    return (truncated_normal(key, int(np.prod(shape))).reshape(shape) * std).astype(np.float32)
+
+
+def init_orthogonal(key: np.ndarray, shape, scale: float = 1.0) -> np.ndarray:
+    """nn.initializers.orthogonal(scale)(key, (rows, cols)): QR of a normal (max, min) matrix, columns signed by diag(R), transposed
+    when rows < cols (sable_network.py:97-107,263-282, torsos.py:42, heads.py:53; flax GRUCell's recurrent kernels)."""
+    rows, cols = int(shape[0]), int(shape[1])
+    mshape = (cols, rows) if rows < cols else (rows, cols)
+    a = normal(key, mshape[0] * mshape[1]).reshape(mshape)
+    q, r = np.linalg.qr(a)
+    q = (q * np.sign(np.diag(r))[None, :]).astype(np.float32)
+    if rows < cols:
+        q = q.T
+    return (np.float32(scale) * q).astype(np.float32)

@@ -84,3 +84,52 @@ def test_choice_hand_worked_vector_and_branches():
     import pytest
     with pytest.raises(ValueError):
         prng.choice(k, 3, 4, False)
+
+
+def test_same_seed_initialisation_product_equals_oracle_and_has_the_reference_distributions():
+    """rec_magpo.py:598-604,623: the networks' parameters are a function of (net_key, actor_net_key).  The product's host-side initialiser
+    (magpo_amd/params.py: flax's per-parameter keys -> jax.random.normal / truncated_normal / orthogonal, restated) must give the oracle's
+    arrays (oracle/prng.py, oracle/networks.py) bit for bit, and both must have the reference's distributions: normal(1 / E) retention
+    projections, orthogonal(sqrt 2 | 0.01 | 1) dense kernels, lecun-normal GRU input kernels, ones / zeros elsewhere.  UNPINNED against
+    JAX / flax themselves (absent here)."""
+    import math
+    import torch
+    from magpo_amd.params import (FlatParams, actor_layout, actor_named_views, guider_layout, guider_named_views, init_actor_from_key,
+                                  init_guider_from_key)
+    from oracle import networks as onets
+    ks = prng.split(prng.prng_key(42), 4)
+    actor_net_key, net_key = ks[2], ks[3]
+    for E, nh, nb, F, K in ((64, 1, 1, 5, 20), (32, 4, 2, 14, 6), (128, 2, 3, 75, 5)):
+        og = onets.init_guider_params_from_key(net_key, E, F, K, nh, nb)
+        P = FlatParams(guider_layout(E, F, K, nb, nh), "cpu")
+        named = guider_named_views(P.views(), E, nh)
+        init_guider_from_key(named, net_key, E, nh)
+        assert set(named) == set(og)
+        for n, v in named.items():
+            assert np.array_equal(v.numpy().reshape(-1), og[n].numpy().reshape(-1)), f"guider {n} (E={E})"
+        wq = og["enc.block0.retn.w_q"].numpy()
+        assert abs(float(wq.std()) * E - 1.0) < 0.05 and abs(float(wq.mean())) * E < 0.05
+        for n, gain in (("enc.obs.dense.kernel", math.sqrt(2)), ("dec.head.dense0.kernel", math.sqrt(2)), ("dec.head.dense1.kernel", 0.01),
+                        ("dec.act.kernel", math.sqrt(2)), ("enc.head.dense1.kernel", 0.01)):
+            w = og[n].numpy().astype(np.float64)
+            g = w @ w.T if w.shape[0] < w.shape[1] else w.T @ w
+            assert np.abs(g - gain * gain * np.eye(g.shape[0])).max() < 1e-5 * max(1.0, gain * gain), n
+        assert float(og["enc.block0.ffn.w1"].abs().max() if "enc.block0.ffn.w1" in og else 0.0) == 0.0
+        assert all(float((v - 1).abs().max()) == 0.0 for n, v in og.items() if n.endswith("scale"))
+    F, H, K = 5, 128, 20
+    oa = onets.init_actor_params_from_key(actor_net_key, F, H, K)
+    PA = FlatParams(actor_layout(F, H, K), "cpu")
+    an = actor_named_views(PA.views())
+    init_actor_from_key(an, actor_net_key)
+    for n, v in an.items():
+        assert np.array_equal(v.numpy().reshape(-1), oa[n].numpy().reshape(-1)), f"actor {n}"
+    wi = oa["gru.ir.kernel"].numpy()
+    assert abs(float(wi.std()) * math.sqrt(H) - 1.0) < 0.03 and float(np.abs(wi).max()) <= 2.0 / math.sqrt(H) / 0.87962566103423978 + 1e-6
+    wh = oa["gru.hz.kernel"].numpy().astype(np.float64)
+    assert np.abs(wh.T @ wh - np.eye(H)).max() < 1e-5
+    assert not np.array_equal(oa["gru.hr.kernel"].numpy(), oa["gru.hz.kernel"].numpy())     # one key per parameter path
+    # the two sampler pieces that have closed forms: fold_in and Giles' erf_inv against scipy
+    from scipy.special import erfinv
+    u = np.linspace(-0.99, 0.99, 1001).astype(np.float32)
+    assert np.max(np.abs(prng.erf_inv_f32(u) - erfinv(u.astype(np.float64)))) < 2e-6
+    assert np.array_equal(prng.fold_in(net_key, 7), prng.split(net_key, 8)[7])                # both are threefry(key, (0, i))
