@@ -190,14 +190,20 @@ int magpo_zero_states_where_done(float* s0, float* s1, float* s2, const unsigned
                                  magpo_stream_t stream);
 
 /* ---- K2 fused acting step: SableNetwork.get_actions (sable_network.py:443-482; decode.py:111-153) in ONE launch ----
- * dims_host[14] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F), envs per wave (0 = by size, or 4 / 8 / 16),
- *   pending, flush}; kappa_host[4] (per head);
+ * dims_host[16] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride (>= F), envs per wave (0 = by size, or 4 / 8 / 16),
+ *   pending, flush, precand, defer}; kappa_host[4] (per head);
  * keys_host [A][2] sampling keys by value, or NULL with ptrs[3] = device key table (static arguments for graph replay);
  * Decoder states are read once and written once per step: the update S <- kappa S + sum_a k_a^T v_a of a step is DEFERRED to the next launch
  *   (the step's k | v rows stay in the scratch rows qkvg1 / kvg2, which therefore must persist between the launches of a rollout).
  *   pending = 1: the previous launch left such rows (apply them first); flush = 1: also apply this launch's rows before returning (with
  *   value_only: the pending ones), so that S_d1 / S_d2 hold the carried states again.  A stand-alone step is {pending 0, flush 1}; a rollout is
  *   {0, 0}, {1, 0} ... and ends with a launch that has flush = 1 (e.g. the bootstrap-value launch {value_only 1, pending 1, flush 1}).
+ * defer = 1 (env-step launches of a rollout; excludes flush / value_only): with one head, every other group of workgroups runs the block-0
+ *   candidate pre-pass of the NEXT step at the end of this launch (S_d1 of their envs then already holds this step's rows; their candidate
+ *   table assumes step count + 1 and no episode end); precand = 1 tells the next launch (same N, same envs per wave) that this happened: those
+ *   workgroups skip the pre-pass, zero state and table where `done` says the episode ended, and a flushing launch leaves their S_d1 alone.  A
+ *   rollout is {pending, precand, defer, flush} = {0,0,1,0}, {1,1,1,0} ... and ends with the value launch {1,1,0,1}; a stand-alone step is
+ *   {0,0,0,1}.  Purpose: these workgroups stream states while the others decode (the launch alternates HBM-bound and dense phases).
  * ptrs_host[49]: obs pos mask keys_dev | s_obs W_obs s_encln W_act s_decln | vh0_t vh0_b vh_s vh_w vh_b1 | h0_t h0_b h_s h1_t h1_b |
  *   pe | S_enc S_d1 S_d2 ([n_block][n_head][N][64][64], updated in place) | scratch xn ([N*A] rows), done [N] u8 or NULL (envs whose
  *   episode just ended: their carried states read as zero, rec_magpo.py:164-169), scratch qkvg u y rep reppe hv ([N*A] rows) |

@@ -41,7 +41,7 @@ extern "C" int magpo_act_weight_layout(const float* Wt, float* Wf, int nrows, hi
 }
 
 // Pointer tables (host arrays of device pointers) keep the boundary plain C without a shared struct layout:
-//   dims_host[14] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride, envs per wave, pending, flush}; kappa_host[4];
+//   dims_host[16] = {N, A, K, F, n_block, n_head, hs, gs, npos, value_only, obs row stride, envs per wave, pending, flush, precand, defer}; kappa_host[4];
 //   keys_host [A][2] or NULL (then ptrs[3] = device key table);  ptrs_host[49] / blk_ptrs_host[21 * n_block] in the order of the P(...) lists below.
 extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, const uint32_t* keys_host, const void* const* ptrs,
                                int nptrs, const void* const* blk_ptrs, int nblk_ptrs, hipStream_t st) {
@@ -49,13 +49,15 @@ extern "C" int magpo_sable_act(const int* dims_host, const float* kappa_host, co
   memset(&a, 0, sizeof(a));
   a.N = dims_host[0]; a.A = dims_host[1]; a.K = dims_host[2]; a.F = dims_host[3]; a.nb = dims_host[4]; a.nh = dims_host[5];
   a.hs = dims_host[6]; a.gs = dims_host[7]; a.npos = dims_host[8]; a.value_only = dims_host[9]; a.ldo = dims_host[10];
-  a.pending = dims_host[12] != 0; a.flush = dims_host[13] != 0;
+  a.pending = dims_host[12] != 0; a.flush = dims_host[13] != 0; a.precand = dims_host[14] != 0; a.defer = dims_host[15] != 0;
   if (a.N <= 0) return MAGPO_OK;
   if (a.A < 1 || a.A > MAXA || a.nb < 1 || a.nb > MAXB || a.nh < 1 || a.nh > 4 || a.K < 1 || a.K > 31 || a.F < 1 || a.hs * a.nh != AE ||
       a.gs < 4 || a.gs > a.hs || (a.gs & (a.gs - 1)) || a.npos < 1 || a.ldo < a.F) {
     set_error("magpo_sable_act: unsupported shape (1 <= A <= 8, n_block <= 4, n_head in {1,2,4}, K <= 31)");
     return MAGPO_EINVAL;
   }
+  if (a.defer && (a.flush || a.value_only)) { set_error("magpo_sable_act: defer (candidate pass of the next step at the end of the launch) excludes flush / value_only"); return MAGPO_EINVAL; }
+  if (a.precand && !a.pending) { set_error("magpo_sable_act: precand needs pending (the previous launch of the rollout left rows)"); return MAGPO_EINVAL; }
   if (nptrs != 49 || nblk_ptrs != 21 * a.nb) { set_error("magpo_sable_act: pointer table size mismatch"); return MAGPO_EINVAL; }
   for (int i = 0; i < 4; ++i) a.kappa[i] = kappa_host[i];
   if (keys_host) for (int i = 0; i < a.A; ++i) { a.keys[i][0] = keys_host[2 * i]; a.keys[i][1] = keys_host[2 * i + 1]; }

@@ -69,6 +69,10 @@ struct ActArgs {
   // (blk[].qkvg1 / blk[].kvg2) have not been added to S_d1 / S_d2 yet; flush = add this launch's (or, for a value-only launch, the
   // pending) rows before returning, so that the states in memory are the true carried states again.
   int pending, flush;
+  // Deferred candidate pass (block 0, one head): defer = the deferring waves run the candidate pre-pass of the NEXT step at the end of this
+  // launch (rows of this step applied, positional row of step count + 1, no episode-end zeroing yet); precand = the previous launch did
+  // that, so those waves find S_d1 up to date and their candidate table built (envs whose episode ended in between are fixed up).
+  int precand, defer;
   float* ptab;              // [N][K + 2][64] block-0 self-retention: q_c (kappa S) for every candidate previous action c, row K + 1 = the positional part
   const float* obs; const int* pos; const unsigned char* mask; const uint32_t* keys_dev; uint32_t keys[16][2];
   const float *s_obs, *W_obs, *s_encln, *W_act, *s_decln;
@@ -297,7 +301,7 @@ __device__ __forceinline__ void ret_pass(float* TQ, float* HK, float* U, float* 
 template <int NA, int MT, int NB>
 __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* __restrict__ S0, const ActArgs& a, int env0, int nvalid,
                                                   const float* __restrict__ pend, const Row (&xq)[MT], unsigned long long dmask,
-                                                  const float4* __restrict__ primed) {
+                                                  const float4* __restrict__ primed, bool apply_pending) {
   const int lane = threadIdx.x, n16 = lane & 15, c4 = 4 * n16, kq = lane >> 4, A = a.A;
   const float kappa = a.kappa[0];
   const int pe_row = a.K + 1, pe_mt = pe_row >> 4, pe_m = pe_row & 15;
@@ -331,10 +335,10 @@ __device__ __forceinline__ void self_prepass_cand(float* HK, float* PEQ, float* 
       for (int t = 0; t < NA; ++t)
         if (t < A && lane < 32) *reinterpret_cast<float4*>(HK + t * QP + 64 + 4 * lane) = hreg[jb][t];
       lsync();
-      const float kin = a.pending ? kappa : 1.0f;   // no pending rows: memory holds the carried state itself (see ret_pass)
+      const float kin = apply_pending ? kappa : 1.0f;   // no pending rows: memory holds the carried state itself (see ret_pass)
 #pragma unroll
       for (int j = 0; j < 16; ++j) { s[j].x *= kin; s[j].y *= kin; s[j].z *= kin; s[j].w *= kin; }
-      if (a.pending) {
+      if (apply_pending) {
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
           if (t < A) {
@@ -506,6 +510,9 @@ constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
 #define MAGPO_ACT_NBUF_CAND 2
 #endif
 
+#ifndef MAGPO_ACT_DEFER
+#define MAGPO_ACT_DEFER 1   // 1: the non-EARLY waves run the candidate pre-pass of the next step at the end of the launch (see defer_wave)
+#endif
 #ifndef MAGPO_ACT_STAGGER_MOD
 #define MAGPO_ACT_STAGGER_MOD 2
 #define MAGPO_ACT_STAGGER_EARLY 1
@@ -514,7 +521,7 @@ constexpr int ACT_NBUF16 = MAGPO_ACT_NBUF16;
 #define MAGPO_ACT_STAGGER_SHIFT 3   // workgroups alternate between the two phase orders in groups of 2^shift
 #endif
 #ifndef MAGPO_ACT_STAGGER
-#define MAGPO_ACT_STAGGER 1   // 1: half of the workgroups run the candidate pre-pass ahead of the encoder (see cand_early)
+#define MAGPO_ACT_STAGGER 1   // 1: the workgroups alternate between two phase orders (see stag / defer_wave in k_sable_act)
 #endif
 #ifndef MAGPO_ACT_WPE
 #define MAGPO_ACT_WPE 1   // waves per SIMD the register allocation aims at (A/B hook)
@@ -552,14 +559,19 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
   const bool cand = nh_ == 1;
   // The candidate pre-pass (block-0 self-retention states: a third of the launch's state traffic) depends on the previous launch's pending
   // rows and on parameters only -- not on this step's encoder.  All waves start together and walk the same phases, so the chip alternates
-  // between phases in which every wave streams states (HBM-bound, ~5 TB/s) and dense phases in which none does.  STAGGER: every other
-  // group of 8 workgroups runs the candidate pre-pass FIRST, so that one half of the waves streams while the other half computes.
-  const bool cand_early = cand && !a.value_only && MAGPO_ACT_STAGGER && (int)((blockIdx.x >> MAGPO_ACT_STAGGER_SHIFT) % MAGPO_ACT_STAGGER_MOD) < MAGPO_ACT_STAGGER_EARLY;
-  auto cand_pass = [&]() __attribute__((always_inline)) {
+  // between phases in which every wave streams states (HBM-bound, ~5 TB/s) and dense phases in which none does.  Two roles, alternating
+  // in groups of 8 workgroups (STAGGER):
+  //   EARLY waves run the candidate pre-pass FIRST, ahead of the encoder;
+  //   DEFERRING waves run it LAST, for the NEXT step (a.defer): after the decoder the step's k | v rows are known, the next step count is
+  //     this one + 1 unless the episode ends, and an ended episode means a zero state and a zero table -- fixed up by the next launch
+  //     (a.precand) from its `done` flags.  They stream states while the EARLY waves decode, and decode while those stream.
+  const bool stag = MAGPO_ACT_STAGGER && (int)((blockIdx.x >> MAGPO_ACT_STAGGER_SHIFT) % MAGPO_ACT_STAGGER_MOD) < MAGPO_ACT_STAGGER_EARLY;
+  const bool defer_wave = cand && MAGPO_ACT_DEFER && MAGPO_ACT_STAGGER && !stag;
+  auto cand_pass = [&](const Row& pe_q, unsigned long long dm, bool apply) __attribute__((always_inline)) {
     const ActBlk& B = a.blk[0];
     float4 pS1[16];   // the first self-retention state of the candidate pass
-      // candidate query rows q_c = x_c W_q (tile row = candidate) and the positional query rows pe W_q of this wave's envs
-    const Row qpe = dense64<true>(pe, B.qkvg1_t, nullptr, m, kq);
+    // candidate query rows q_c = x_c W_q (tile row = candidate) and the positional query rows pe W_q of this wave's envs
+    const Row qpe = dense64<true>(pe_q, B.qkvg1_t, nullptr, m, kq);
     row_store(PEQ + env * 64, kq, qpe);
     lsync();
     const int ntile = (a.K + 2 + 15) >> 4;
@@ -571,12 +583,25 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
         const int c = min(16 * mt + env, a.K);                                                                               \
         xq[mt] = dense64<true>(row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq), B.qkvg1_t, nullptr, m, kq); \
       }                                                                                                                      \
-      self_prepass_cand<NA, MT_, (EPW == 16 ? MAGPO_ACT_NBUF_CAND : 2)>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dmask, pS1);                                 \
+      self_prepass_cand<NA, MT_, (EPW == 16 ? MAGPO_ACT_NBUF_CAND : 2)>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dm, pS1, apply);              \
     }
     if (ntile == 1) CAND_ROWS(1) else if (ntile == 2) CAND_ROWS(2) else CAND_ROWS(3)
 #undef CAND_ROWS
   };
-  if (cand_early) { cand_pass(); wsync(); PROF(4); }
+  if (cand && !a.value_only) {
+    if (!(defer_wave && a.precand)) {   // EARLY waves; DEFERRING waves on the first launch of a rollout / a stand-alone step
+      cand_pass(pe, dmask, a.pending != 0);
+      wsync();
+    } else if (dmask) {                 // the previous launch built state and table for "episode goes on": where it ended, the state is zero
+      for (int e = 0; e < nvalid; ++e) {
+        if (!((dmask >> e) & 1ull)) continue;
+        float* Se = a.S_d1 + (long)(env0 + e) * 4096;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st4nt(Se + r * 256 + 4 * lane, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+    }
+    PROF(4);
+  }
 
   // ---------------- encoder over the A tokens of the step (act_encoder_fn, encode.py:58-84)
   for (int b = 0; b < nb; ++b) {
@@ -687,16 +712,17 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
   PROF(3);
   constexpr int NBF = EPW == 16 ? ACT_NBUF16 : 2;
   // flush: S <- kappa S + sum_a k_a^T v_a with the rows in the scratch (this launch's, or the pending ones of the previous launch)
-  auto flush_states = [&]() {
+  auto flush_states = [&](bool d1_block0_done) {
     wsync();
     for (int b = 0; b < nb; ++b) {
       const ActBlk& B = a.blk[b];
-      ret_pass<3, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 1, 0ull);
+      if (!(b == 0 && d1_block0_done))
+        ret_pass<3, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 1, 0ull);
       ret_pass<3, NA, NBF, NH>(TQ, HK, U, a.S_d2 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.kvg2, 256, 0, nullptr, 0, B.gn2_g, B.gn2_b, 1, 0ull);
     }
   };
   if (a.value_only) {   // uniform: bootstrap value only (rec_magpo.py:202-208); the last launch of a rollout also settles the decoder states
-    if (a.flush && a.pending) flush_states();
+    if (a.flush && a.pending) flush_states(defer_wave && a.precand);   // (the deferring waves' S_d1 already holds the last step's rows)
     return;
   }
 
@@ -710,7 +736,7 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
                                   B.q2, AE, a.pending);
     PROF(19);
     if (b == 0 && cand) {
-      if (!cand_early) cand_pass();
+      // (the candidate pre-pass of block 0 ran ahead of the encoder, or at the end of the previous launch)
     } else {
       ret_pass<5, NA, NBF, NH>(TQ, HK, U, a.S_d1 + (long)b * nh_ * NS, NS, a, env0, nvalid, 0, B.qkvg1, 256, 64, nullptr, 0, B.gn1_g, B.gn1_b, 1, dmask,
                                nullptr, 0, a.pending);
@@ -737,7 +763,12 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
       if (b == 0 && cand) {
         // self-retention from the candidate table: r = P[prev] + P[pe] + sum_{a <= i} (q . k_a) v_a, everything in registers
         const float* pt = a.ptab + ge * (long)(a.K + 2) * 64;
-        const Row pc = row_load(pt + (long)prev * 64, kq), pp = row_load(pt + (long)(a.K + 1) * 64, kq);
+        Row pc = row_load(pt + (long)prev * 64, kq), pp = row_load(pt + (long)(a.K + 1) * 64, kq);
+        if (defer_wave && a.precand) {   // table built before the env step: an episode that ended since has a zero state, hence zero rows
+          const float keepf = ((dmask >> le) & 1ull) ? 0.f : 1.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { pc.v[j] *= keepf; pp.v[j] *= keepf; }
+        }
         Row hk1[NA - 1], hv1[NA - 1];   // (unused: the history rows of the earlier agents are streamed, two row pairs at a time)
         const Row kin = row_add(xin, pe);
         Row q1, k1, v1, g1;
@@ -865,7 +896,12 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
     prev = arg + 1;
     PROF(16);
   }
-  if (a.flush) flush_states();   // stand-alone step (or last step of a rollout without a value launch): settle the decoder states now
+  if (defer_wave && a.defer) {   // the candidate pre-pass of the NEXT step (never together with flush: the rows would be applied twice)
+    wsync();                     // this step's k | v rows are read back by other lanes
+    const int pn = min(p_ + 1, a.npos - 1);
+    const Row pe_n = row_load(a.pe + (long)pn * AE, kq);
+    cand_pass(pe_n, 0ull, true);
+  } else if (a.flush) flush_states(false);   // stand-alone step (or last step of a rollout without a value launch): settle the decoder states now
 }
 
 }  // namespace magpo

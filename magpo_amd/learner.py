@@ -494,7 +494,7 @@ class MagpoLearner:
             if fused:   # states of envs whose episode just ended read as zero inside the kernel (rec_magpo.py:164-169); the decoder-state
                 # update of a step is deferred to the next launch (each state read + written once per step, csrc/act_fused.hip)
                 act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], done=done_prev, mask=mk,
-                    pending=t > 0, flush=False)
+                    pending=t > 0, flush=False, precand=t > 0, defer=True)
             else:
                 act(obs, pos, g.sable_hs, skeys[t], tr["action"][t], tr["log_prob"][t], tr["value"][t], mask=mk)
             g.env.step(tr["action"][t], tr["reward"][t], tr["done"][t + 1], tr["obs"][t + 1], tr["step_count"][t + 1],
@@ -517,7 +517,7 @@ class MagpoLearner:
             g.policy_h[0].copy_(g.policy_h[1])
             g.cur = 0
         if fused:   # bootstrap value (encoder states of just-ended episodes read as zero) + the last step's pending decoder-state update
-            act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True, done=tr["done"][T], pending=True, flush=True)
+            act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True, done=tr["done"][T], pending=True, flush=True, precand=True)
             zero_done(tr["done"][T])
         else:
             act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)

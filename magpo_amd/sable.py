@@ -446,7 +446,7 @@ class SableGuider:
                    k0, k1, kdev, action_out[:, i:], A, logp_out[:, i:], A, prev[:, i + 1:] if i + 1 < A else None, A, None, 0, N, K, st)
 
     def act_fused(self, obs, pos, states, sample_keys, action_out, logp_out, value_out, mask=None, value_only=False, done=None, tag="",
-                  pending=False, flush=True):
+                  pending=False, flush=True, precand=False, defer=False):
         """Same contract as :meth:`act`, ONE launch per env step (csrc/act_fused_kernel.hpp: k_sable_act): a wave carries 4 - 16 envs
         through encoder, the A decoder iterations and the sampling.  states [n_block, n_head, N, 64, 64].  ``done`` [N] u8
         (optional): envs whose episode ended on the previous step -- their carried states are read as zero
@@ -454,7 +454,9 @@ class SableGuider:
         ``pending`` / ``flush``: the kernel defers a step's decoder-state update to the next launch so that every state is read and
         written once per step (include/magpo.h).  The defaults {False, True} are a stand-alone step (states settled on return); a
         rollout passes pending = (t > 0), flush = False and ends with a launch that has flush = True (the bootstrap-value launch).
-        The scratch rows that carry the pending k | v rows belong to ``tag``."""
+        The scratch rows that carry the pending k | v rows belong to ``tag``.
+        ``defer`` / ``precand`` (include/magpo.h): inside a rollout half of the workgroups run the block-0 candidate pre-pass of the NEXT
+        step at the end of the launch (defer) and skip it in the next one (precand), so that they stream states while the others decode."""
         A, K, F, nb, nh = self.A, self.K, self.F, self.nb, self.nh
         if A > 8 and self.wide:
             raise NotImplementedError("wide observations (obs_dim > 32) with more than 8 agents")
@@ -469,7 +471,7 @@ class SableGuider:
         v, b = self.v, self.b
         s_enc, s_d1, s_d2 = states   # value_only (bootstrap value, rec_magpo.py:202-208): the kernel writes no state
         kdev = sample_keys if torch.is_tensor(sample_keys) else None
-        cache_key = (N, bool(value_only), bool(pending), bool(flush), self.tuning.act_envs_per_wave, obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
+        cache_key = (N, bool(value_only), bool(pending), bool(flush), bool(precand), bool(defer), self.tuning.act_envs_per_wave, obs.data_ptr(), pos.data_ptr(), None if mask is None else mask.data_ptr(),
                      None if kdev is None else kdev.data_ptr(), s_enc.data_ptr(), s_d1.data_ptr(), s_d2.data_ptr(),
                      None if action_out is None else action_out.data_ptr(), None if logp_out is None else logp_out.data_ptr(),
                      value_out.data_ptr(), None if done is None else done.data_ptr())
@@ -501,7 +503,7 @@ class SableGuider:
                         v[d + "retn2.gn.scale"], v[d + "retn2.gn.bias"],
                         g(f"qkvg1_{k}", 4 * E), g(f"q2_{k}"), g(f"kvg2_{k}", 4 * E)]   # kvg2 rows: [k | v | - | P2] (ld 256)
             tabs = (np.array([N, A, K, F, nb, nh, self.hs, self.gs, self.npos, 1 if value_only else 0, self.Fld, self.tuning.act_envs_per_wave,
-                              1 if pending else 0, 1 if flush else 0], dtype=np.int32),
+                              1 if pending else 0, 1 if flush else 0, 1 if precand else 0, 1 if defer else 0], dtype=np.int32),
                     np.array((self.kappas + [0.0] * 4)[:4], dtype=np.float32),
                     np.array([ptr(t) for t in glob], dtype=np.uint64), np.array([ptr(t) for t in blk], dtype=np.uint64))
             if len(self._act_tabs) > 4096:

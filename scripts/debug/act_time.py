@@ -17,9 +17,9 @@ l.use_graph = False
 l.setup(host_split(prng_key(1), 4)[0])
 g = l.groups[0]; tr = g.traj
 l._rollout_keys(g)
-def call(pending=True):
+def call(pending=True):   # rollout mode: pending rows of the previous launch, deferred candidate pass (precand / defer), no flush
     l.guider.act_fused(tr["obs"][0], tr["step_count"][0], g.sable_hs, g.skeys_host[0], tr["action"][0], tr["log_prob"][0], tr["value"][0],
-                       done=tr["done"][0], pending=pending, flush=False)
+                       done=tr["done"][0], pending=pending, flush=False, precand=pending, defer=True)
 call(False)
 for _ in range(3): call()
 torch.cuda.synchronize()
