@@ -362,6 +362,8 @@ class MagpoLearner:
         this process's first group.  Reset keys are rows 1.. of split(key, n_groups*N + 1) laid out row-major
         over (group, env); ONE step key is shared by every group (rec_magpo.py:660-671)."""
         N = self.N
+        if group < 0 or group + len(self.groups) > n_groups:   # (a short key table would send the env-reset kernel out of bounds)
+            raise ValueError(f"setup: this learner holds {len(self.groups)} env group(s) starting at group {group}, but the job has n_groups={n_groups}")
         total = n_groups * N + 1
         kd = torch.from_numpy(np.ascontiguousarray(key, np.uint32).view(np.int32)).to(self.dev)
         allk = torch.empty(total, 2, dtype=torch.int32, device=self.dev)

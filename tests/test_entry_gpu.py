@@ -220,15 +220,15 @@ def test_get_learner_fn_calls_the_functions_it_is_given_and_rejects_foreign_call
             fns = [wrap(i, f) for i, f in enumerate(fns)]
             fns[3] = functools.partial(fns[3])   # a partial around a wrapper around the bound method
         learn = rec_magpo.get_learner_fn(env, tuple(fns[:3]), tuple(fns[3:]), cfg)
-        learn.learner.setup(key)
+        learn.learner.setup(key, n_groups=len(learn.learner.groups))   # update_batch_size = 2 groups (configs/system/gpo/rec_magpo.yaml)
         learn.learner._live_state = rec_magpo._snapshot_state(learn.learner)
         out = learn(learn.learner._live_state)
         return out, calls
 
     plain, _ = build(False)
     adapted, calls = build(True)
-    T, P, M = 8, 2, int(cfg.system.num_minibatches)
-    assert calls[0] == T + 1, "the rollout must call the execution function it was given (T steps + the bootstrap value)"
+    T, P, M, U = 8, 2, int(cfg.system.num_minibatches), int(cfg.system.update_batch_size)
+    assert calls[0] == U * (T + 1), "the rollout of every env group must call the execution function it was given (T steps + the bootstrap value)"
     assert calls[1] == P * M and calls[2] == P * M and calls[4] == P * M, calls
     for k, v in plain.learner_state.params.guider_params.items():
         assert torch.equal(v, adapted.learner_state.params.guider_params[k]), k

@@ -343,7 +343,7 @@ def test_dense_bf16_triples_whole_minibatch_gradient_error_vs_fp64(E, nh, nb):
     the headline step), this test pins their accuracy at <= 1.10 x the fp32-MFMA gradient error."""
     from magpo_amd.learner import CoordSumConfig, MagpoLearner, SystemConfig
     from magpo_amd.tuning import Tuning
-    A, K, TL, maxval, N, T = 4, 20, 100, 60, 16, 128
+    A, K, TL, maxval, N, T = 4, 20, 100, 60, 8, 128
     spec = ocs.CoordSumSpec(A, K, TL, maxval)
     scfg = onets.SableCfg(A, K, A + 1, embed_dim=E, n_block=nb, n_head=nh)
     osys = olearn.SystemCfg(rollout_length=T, ppo_epochs=1, num_minibatches=1)
