@@ -27,7 +27,7 @@ import torch
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 PEAK_F32_MFMA_TF = 157.3   # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_f32)
-PMC_FILE = "r03_pmc_hbm_traffic.json"   # offline PMC passes (scripts/pmc_kernels.py + scripts/pmc_collect.py)
+PMC_FILE = "r04_pmc_hbm_traffic.json"   # offline PMC passes (scripts/pmc_kernels.py + scripts/pmc_collect.py)
 
 
 class KernelTimer:
