@@ -24,7 +24,7 @@ H = 128
 
 class GruActor:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, hidden: int = 128, wgrad_groups: int = 512,
-                 seed: Optional[int] = None, grads: Optional[torch.Tensor] = None, tuning: Optional[Tuning] = None):
+                 seed: Optional[int] = None, grads: Optional[torch.Tensor] = None, tuning: Optional[Tuning] = None, obs_ld: Optional[int] = None):
         self.tuning = tuning if tuning is not None else Tuning.from_env()   # per-call kernel knobs (tuning.py); the library keeps none
         if hidden != 128:
             raise NotImplementedError("gfx950 GRU kernels: hidden_state_dim = 128 only")
@@ -32,7 +32,11 @@ class GruActor:
             raise NotImplementedError("obs_dim <= 128 and action_dim <= 32 required")
         self.A, self.K, self.F = n_agents, action_dim, obs_dim
         self.wide = obs_dim > 32            # wide observations: rows padded to 128, pre-torso on the MFMA dense kernel (csrc/wideobs.hip)
-        self.Fld = 128 if self.wide else obs_dim
+        self.Fld = 128 if self.wide else obs_dim      # floats between observation rows
+        if obs_ld is not None and int(obs_ld) != self.Fld:   # rows wider than the features read (system.add_agent_id: False, learner.net_obs)
+            if self.wide or int(obs_ld) < obs_dim:
+                raise ValueError(f"obs_ld={obs_ld} with obs_dim={obs_dim}: a separate row stride is supported for narrow observations only")
+            self.Fld = int(obs_ld)
         self.dev = device
         self.L = lib()
         self.G = wgrad_groups
@@ -113,7 +117,7 @@ class GruActor:
         if self.wide:
             self.lin(obs, 128, self.wt["pre"], self.v["pre.bias"], emb, H, R, 128, H, act=1)
         else:
-            self.L.call("magpo_small_linear", obs, self.F, self.F, self.v["pre.kernel"], self.v["pre.bias"], emb, H, H, R, 1, self._st())
+            self.L.call("magpo_small_linear", obs, self.Fld, self.F, self.v["pre.kernel"], self.v["pre.bias"], emb, H, H, R, 1, self._st())
 
     def _groups(self, R):
         """Row slabs of a split weight gradient: no more than one per 256 rows (small minibatches: fewer partials to reduce)."""
@@ -258,7 +262,7 @@ class GruActor:
         self.lin(dxi, ldx, wi_t, None, demb, H, R, 3 * H, H)
         grid = L.call("magpo_row_grid", R)
         sw = b.get("g_slabw", (grid, 33 * H))
-        L.call("magpo_small_relu_wgrad", obs, F, F, emb, demb, sw, R, st)
+        L.call("magpo_small_relu_wgrad", obs, self.Fld, F, emb, demb, sw, R, st)
         L.call("magpo_reduce_slabs", sw, gv["pre.kernel"], grid, F * H, 33 * H, 1.0, 0, st)
         L.call("magpo_reduce_slabs", sw[:, 32 * H:], gv["pre.bias"], grid, H, 33 * H, 1.0, 0, st)
         if self.overlap_wgrad and self.wgrad_stream is not None:

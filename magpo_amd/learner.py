@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -57,6 +57,7 @@ class CoordSumConfig:
     num_actions: int
     time_limit: int = 100
     maxval: Optional[int] = None
+    add_agent_id: bool = True  # system.add_agent_id (AgentIDWrapper, make_env.py:90-104): False = the networks read the rows behind the one-hot id
     has_mask = False          # action_mask is all-True (matrax.py:117-134): never stored
     class_tables = True       # observations take few distinct values: first-layer class tables apply (csrc/classtab.hip)
 
@@ -79,6 +80,7 @@ class LbfConfig:
     max_agent_level: int = 2
     force_coop: bool = True
     time_limit: int = 100
+    add_agent_id: bool = True
     has_mask = True
     class_tables = False
     num_actions = 6
@@ -86,6 +88,19 @@ class LbfConfig:
     @property
     def obs_dim(self) -> int:   # vector observation 3 (num_food + num_agents) + one-hot agent id
         return 3 * (self.num_food + self.num_agents) + self.num_agents
+
+
+def net_obs(cfg) -> Tuple[int, int]:
+    """(features the networks read, column offset of the first one inside an observation row).  The env kernels always write
+    [one-hot agent id | features] rows (AgentIDWrapper, observation.py:42-54); with ``system.add_agent_id: False`` (make_env.py:90-104: the
+    wrapper is not applied) the networks are built for the features alone and every consumer gets the row pointer advanced by num_agents
+    floats with the row stride unchanged.  Narrow observations only (the 128-float padded rows of wide observations are read with
+    16-byte vector loads that a column offset would misalign)."""
+    if getattr(cfg, "add_agent_id", True):
+        return cfg.obs_dim, 0
+    if cfg.obs_dim > 32:
+        raise NotImplementedError("system.add_agent_id=False with wide observations (obs_dim > 32: Robot Warehouse)")
+    return cfg.obs_dim - cfg.num_agents, cfg.num_agents
 
 
 def host_split(key: np.ndarray, num: int = 2) -> np.ndarray:
@@ -272,9 +287,9 @@ class MagpoLearner:
         self.tuning = tuning if tuning is not None else (guider.tuning if guider is not None else Tuning.from_env())   # ONE object shared by both networks (tuning.py)
         self.env_cfg, self.N, self.sys, self.dev = env_cfg, num_envs, sys, device
         A, K = env_cfg.num_agents, env_cfg.num_actions
-        F = env_cfg.obs_dim  # with the AgentIDWrapper's one-hot id (observation.py:42-54), add_agent_id: True
+        F, self.obs_off = net_obs(env_cfg)   # what the networks read: the whole row with the AgentIDWrapper's one-hot id, or the part behind it
         self.A, self.K, self.F, self.T = A, K, F, sys.rollout_length
-        self.Fld = obs_row_stride(F)
+        self.Fld = obs_row_stride(env_cfg.obs_dim)   # floats between rows as the env kernels write them
         if num_envs % sys.num_minibatches:
             raise ValueError("num_envs must be divisible by num_minibatches")
         self.L = lib()
@@ -292,14 +307,17 @@ class MagpoLearner:
         if guider is None:
             guider = SableGuider(A, K, F, device, decay_scaling_factor=decay_scaling_factor, use_pe=use_pe,
                                  max_pos=env_cfg.time_limit + 1, wgrad_groups=wgrad_groups, n_block=self.nb, n_head=self.nh, embed_dim=int(embed_dim),
-                                 seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn], tuning=self.tuning)
+                                 seed=None if net_seed is None else net_seed, grads=self.grad_all[:gn], tuning=self.tuning, obs_ld=self.Fld)
         else:
             guider.bind_grads(self.grad_all[:gn])
         if actor is None:
             actor = GruActor(A, K, F, device, wgrad_groups=wgrad_groups, seed=None if net_seed is None else net_seed + 1,
-                             grads=self.grad_all[gn:gn + an], tuning=self.tuning)
+                             grads=self.grad_all[gn:gn + an], tuning=self.tuning, obs_ld=self.Fld)
         else:
             actor.bind_grads(self.grad_all[gn:gn + an])
+        if guider.F != F or actor.F != F or guider.Fld != self.Fld or actor.Fld != self.Fld:
+            raise ValueError(f"networks built for {guider.F} / {actor.F} observation features with row stride {guider.Fld} / {actor.Fld}, "
+                             f"the env provides {F} with row stride {self.Fld}")
         self.guider, self.actor = guider, actor
         self.g_opt, self.a_opt = optims if optims is not None else (ClipAdam(guider, sys), ClipAdam(actor, sys))
         assert self.g_opt.net is guider and self.a_opt.net is actor
@@ -327,7 +345,8 @@ class MagpoLearner:
         # layers in front of the GRU / of the first retention run on the distinct rows only.  MAGPO_CLASS_TABLES=0 = dense path.
         import os
         # (the tables are read in place by the 64-wide fused kernels: a 128-wide net takes the dense first layers)
-        self.class_tables = env_cfg.class_tables and os.environ.get("MAGPO_CLASS_TABLES", "1") != "0" and int(embed_dim) <= 64
+        # (... and need the one-hot id in the network input: the class rows are [id | target])
+        self.class_tables = env_cfg.class_tables and os.environ.get("MAGPO_CLASS_TABLES", "1") != "0" and int(embed_dim) <= 64 and self.obs_off == 0
         self._cls = None
         # the actor's forward / backward run on a second HIP stream next to the guider's (independent until the loss)
         self.overlap_actor = False  # opt-in (bench.py --overlap): ~3 %, but per-kernel timings then include contention
@@ -355,6 +374,10 @@ class MagpoLearner:
 
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
+
+    def _net_view(self, obs: torch.Tensor) -> torch.Tensor:
+        """The part of the observation rows the networks read (net_obs): same rows, same stride, pointer behind the one-hot id."""
+        return obs if self.obs_off == 0 else obs[..., self.obs_off:]
 
     # ------------------------------------------------------------------ setup (rec_magpo.py:642-660)
     def setup(self, key: np.ndarray, n_groups: int = 1, group: int = 0):
@@ -481,7 +504,7 @@ class MagpoLearner:
                     L.call("magpo_zero_states_where_done", g.sable_hs[0][k][h], g.sable_hs[1][k][h], g.sable_hs[2][k][h], done, N, st)
 
         for t in range(T):
-            obs, pos, done_prev = tr["obs"][t], tr["step_count"][t], tr["done"][t]
+            obs, pos, done_prev = self._net_view(tr["obs"][t]), tr["step_count"][t], tr["done"][t]
             if not self.batched_actor_carry:
                 # the actor's hidden-state carry is a pure function of (obs, done); per step it can run on a side stream
                 h_in, h_out = g.policy_h[g.cur], g.policy_h[1 - g.cur]
@@ -513,16 +536,16 @@ class MagpoLearner:
                     g.traj_cls = torch.empty(T * N * A, dtype=torch.int32, device=self.dev)
                 L.call("magpo_coordsum_classes", tr["obs"], self.F, None, None, A, self.env_cfg.maxval, 1, g.traj_cls, None, T * N * A, st)
                 ccl = (self._class_rows()["obs_act"], g.traj_cls)
-            self.actor.carry(tr["obs"][:T], g.policy_h[g.cur], tr["done"][:T], g.policy_h[1 - g.cur], classes=ccl, tag=gtag)
+            self.actor.carry(self._net_view(tr["obs"][:T]), g.policy_h[g.cur], tr["done"][:T], g.policy_h[1 - g.cur], classes=ccl, tag=gtag)
             g.cur = 1 - g.cur
         if g.cur != 0:  # keep the buffer roles identical from rollout to rollout (static graph arguments)
             g.policy_h[0].copy_(g.policy_h[1])
             g.cur = 0
         if fused:   # bootstrap value (encoder states of just-ended episodes read as zero) + the last step's pending decoder-state update
-            act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True, done=tr["done"][T], pending=True, flush=True, precand=True)
+            act(self._net_view(tr["obs"][T]), tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True, done=tr["done"][T], pending=True, flush=True, precand=True)
             zero_done(tr["done"][T])
         else:
-            act(tr["obs"][T], tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
+            act(self._net_view(tr["obs"][T]), tr["step_count"][T], g.sable_hs, None, None, None, g.last_val, value_only=True)
         L.call("magpo_gae", tr["reward"], tr["value"], tr["done"], g.last_val, tr["done"][T], tr["adv"], tr["targets"], T, N, A,
                self.sys.gamma, self.sys.gae_lambda, st)
 
@@ -649,12 +672,12 @@ class MagpoLearner:
         if side is not None:
             side.wait_stream(main)  # minibatch gather (and the previous optimiser step) are complete for the actor
             with torch.cuda.stream(side):
-                a_logits = self.actor_apply_fn(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
-        g_logits, value = self.sable_apply_fn(m["obs"], m["prev"], m["pos"], m["done"], self._prev_hs, hidx, nseq, T, classes=gcl)
+                a_logits = self.actor_apply_fn(self._net_view(m["obs"]), m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
+        g_logits, value = self.sable_apply_fn(self._net_view(m["obs"]), m["prev"], m["pos"], m["done"], self._prev_hs, hidx, nseq, T, classes=gcl)
         if side is not None:
             main.wait_stream(side)
         else:
-            a_logits = self.actor_apply_fn(m["obs"], m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
+            a_logits = self.actor_apply_fn(self._net_view(m["obs"]), m["done"], self._policy_h0, m["h0idx"], nseq, T, classes=acl)
         st = self._st()
         if U == 1:
             if adv_stats is None:

@@ -55,7 +55,7 @@ class SableGuider:
     def __init__(self, n_agents: int, action_dim: int, obs_dim: int, device, *, embed_dim: int = 64, n_head: int = 1,
                  n_block: int = 1, decay_scaling_factor: float = 0.8, use_pe: bool = True, max_pos: int = 101,
                  wgrad_groups: int = 512, seed: Optional[int] = None, grads: Optional[torch.Tensor] = None,
-                 tuning: Optional[Tuning] = None):
+                 tuning: Optional[Tuning] = None, obs_ld: Optional[int] = None):
         self.tuning = tuning if tuning is not None else Tuning.from_env()   # per-call kernel knobs (tuning.py); the library keeps none
         if embed_dim not in (16, 32, 64, 128) or n_head not in (1, 2, 4) or n_block < 1 or embed_dim % n_head or 64 // n_head // n_head < 4:
             raise NotImplementedError("gfx950 Sable kernels: embed_dim in {16, 32, 64, 128} (nets narrower than 64 run embedded in the 64-wide "
@@ -74,7 +74,11 @@ class SableGuider:
         # observation rows: F floats apart for small observations (row kernels), padded to 128 for wide ones (obs_dim > 32, e.g.
         # Robot Warehouse: the observation-side first layer then runs on the MFMA dense kernels, csrc/wideobs.hip)
         self.wide = obs_dim > 32
-        self.Fld = 128 if self.wide else obs_dim
+        self.Fld = 128 if self.wide else obs_dim      # floats between observation rows
+        if obs_ld is not None and int(obs_ld) != self.Fld:   # rows wider than the features read (system.add_agent_id: False, learner.net_obs)
+            if self.wide or int(obs_ld) < obs_dim:
+                raise ValueError(f"obs_ld={obs_ld} with obs_dim={obs_dim}: a separate row stride is supported for narrow observations only")
+            self.Fld = int(obs_ld)
         self.dev = device
         self.L = lib()
         self.kappas = decay_kappas(self.nh, decay_scaling_factor)
@@ -587,7 +591,7 @@ class SableGuider:
             L.call("magpo_headmid_fwd", z0, E, v["enc.ln.scale"], g("xn0"), E, None, None, None, 0, R, E, st)
             L.call("magpo_add_pe", g("xn0"), E, self.pe, pos, 1, self.npos, g("kin0"), E, R, E, st)
         else:
-            L.call("magpo_embed_fwd", 0, obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
+            L.call("magpo_embed_fwd", 0, obs, self.Fld, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], None, 0, v["enc.ln.scale"],
                    self.pe, pos, 1, self.npos, None, 0, g("xn0"), E, g("kin0"), E, R, E, st)   # z is recomputed by the backward
         for k in range(nb):
             e = f"enc.block{k}."
@@ -863,7 +867,7 @@ class SableGuider:
                 self.reduce(so, gv["enc.obs.norm.scale"], P=F, stride=128)
             else:
                 L.call("magpo_embed_bwd", 0, None, 0, dsum0, E, dkin, E, None, 0, v["enc.ln.scale"], None, 0, slab("a"), slab("w", 32 * E), F,
-                       obs, F, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, E, st)
+                       obs, self.Fld, F, v["enc.obs.norm.scale"], v["enc.obs.dense.kernel"], slab("d", 32), None, 0, R, E, st)
                 self.reduce(slab("a"), gv["enc.ln.scale"], accumulate=not first_ln)
                 self.reduce(slab("d", 32), gv["enc.obs.norm.scale"], P=F, stride=32)
                 self.reduce(slab("w", 32 * E), gv["enc.obs.dense.kernel"], P=F * E, stride=32 * E)

@@ -213,10 +213,12 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
     # networks (rec_magpo.py:559-579), optimisers (:581-589) -- objects that own their kernels' device buffers
     cfg, sysc = env.cfg, _system_config(config)
     # parameters = what flax creates from net_key / actor_net_key (rec_magpo.py:598-604,623; magpo_amd/params.py, UNPINNED restatement)
-    sable_network = SableGuider(cfg.num_agents, cfg.num_actions, cfg.obs_dim, device, embed_dim=int(nc.embed_dim), n_head=int(nc.n_head),
+    from magpo_amd.learner import obs_row_stride
+    obs_ld = obs_row_stride(cfg.obs_dim)   # floats between the rows the env kernels write; env.obs_dim = the features the networks read (add_agent_id)
+    sable_network = SableGuider(cfg.num_agents, cfg.num_actions, env.obs_dim, device, obs_ld=obs_ld, embed_dim=int(nc.embed_dim), n_head=int(nc.n_head),
                                 n_block=int(nc.n_block), decay_scaling_factor=float(mc.decay_scaling_factor),
                                 use_pe=bool(mc.timestep_positional_encoding), max_pos=cfg.time_limit + 1, seed=np.asarray(net_key, np.uint32))
-    actor_network = GruActor(cfg.num_agents, cfg.num_actions, cfg.obs_dim, device, seed=np.asarray(actor_net_key, np.uint32), tuning=sable_network.tuning)
+    actor_network = GruActor(cfg.num_agents, cfg.num_actions, env.obs_dim, device, obs_ld=obs_ld, seed=np.asarray(actor_net_key, np.uint32), tuning=sable_network.tuning)
     guider_optim, actor_optim = ClipAdam(sable_network, sysc), ClipAdam(actor_network, sysc)
     # Pack apply and update functions (rec_magpo.py:624-632)
     apply_fns = (sable_network.get_actions, sable_network.apply, actor_network.apply)
@@ -242,7 +244,8 @@ def run_experiment(_config) -> float:
     key, key_e, actor_net_key, net_key = ks[0], ks[1], ks[2], ks[3]
     learn, actor_network, learner_state = learner_setup(env, (key, actor_net_key, net_key), config, device, rank, world)
 
-    eval_actor = GruActor(env.num_agents, env.action_dim, env.obs_dim, device)
+    from magpo_amd.learner import obs_row_stride
+    eval_actor = GruActor(env.num_agents, env.action_dim, env.obs_dim, device, obs_ld=obs_row_stride(env.cfg.obs_dim))
     eval_act_fn = make_rec_eval_act_fn(eval_actor, config)
     evaluator = get_eval_fn(eval_env, eval_act_fn, config, absolute_metric=False, device=device, n_devices=n_devices)
 

@@ -74,7 +74,9 @@ class MarlEnv:
 
     @property
     def obs_dim(self) -> int:
-        return self.cfg.obs_dim
+        """Width of ``agents_view`` as the networks see it: with the AgentIDWrapper's one-hot id, or (system.add_agent_id: False) without."""
+        from ..learner import net_obs
+        return net_obs(self.cfg)[0]
 
     @property
     def unwrapped(self):
@@ -111,7 +113,9 @@ class MarlEnv:
             if getattr(st, "_ones", None) is None or st._ones.shape[0] != N:
                 st._ones = torch.ones(N, A, K, dtype=torch.uint8, device=obs.device)
             mask = st._ones
-        observation = Observation(obs[..., :F], mask, obs_step.view(N, 1).expand(N, A))
+        from ..learner import net_obs
+        off = net_obs(self.cfg)[1]     # the env kernels always write [one-hot id | features]: without the id the view starts behind it
+        observation = Observation(obs[..., off:off + F], mask, obs_step.view(N, 1).expand(N, A))
         extras = {"episode_metrics": {"episode_return": m_ret, "episode_length": m_len, "is_terminal_step": m_term.bool()}, "env_metrics": {}}
         return TimeStep(step_type, reward, discount, observation, extras)
 
@@ -165,10 +169,8 @@ def make_coordsum_env(config):
     kw.update(config.env.kwargs.to_container())  # **config.env.kwargs override the registered kwargs (make_env.py:211-213)
     add_id = bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id)
     config.system.add_agent_id = add_id
-    if not add_id:
-        raise NotImplementedError("system.add_agent_id=False is not supported by the HIP env kernel (obs = [agent id | target])")
-    cfg = CoordSumConfig(**kw)
-    return MarlEnvSpec(cfg, auto_reset=True), MarlEnvSpec(cfg, auto_reset=False)
+    cfg = CoordSumConfig(**kw, add_agent_id=add_id)   # False: the networks read the rows behind the one-hot id (learner.net_obs)
+    return MarlEnvSpec(cfg, auto_reset=True, add_agent_id=add_id), MarlEnvSpec(cfg, auto_reset=False, add_agent_id=add_id)
 
 
 def make_lbf_env(config):
@@ -182,11 +184,9 @@ def make_lbf_env(config):
         raise NotImplementedError(f"LevelBasedForaging kwargs {sorted(unknown)} are not supported (grid observations, penalties, unnormalised rewards)")
     add_id = bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id)
     config.system.add_agent_id = add_id
-    if not add_id:
-        raise NotImplementedError("system.add_agent_id=False is not supported by the HIP env kernels")
     cfg = LbfConfig(grid_size=int(tc["grid_size"]), fov=int(tc["fov"]), num_agents=int(tc["num_agents"]), num_food=int(tc["num_food"]),
                     max_agent_level=int(tc.get("max_agent_level", 2)), force_coop=bool(tc.get("force_coop", False)),
-                    time_limit=int(kw.get("time_limit", 100)))
+                    time_limit=int(kw.get("time_limit", 100)), add_agent_id=add_id)
     if cfg.obs_dim > 32:
         raise NotImplementedError("LevelBasedForaging: num_agents + 3 (num_food + num_agents) <= 32 (the LBF kernel writes unpadded observation rows)")
     G = cfg.grid_size
@@ -207,7 +207,8 @@ def make_rware_env(config):
     add_id = bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id)
     config.system.add_agent_id = add_id
     if not add_id:
-        raise NotImplementedError("system.add_agent_id=False is not supported by the HIP env kernels")
+        raise NotImplementedError("system.add_agent_id=False with Robot Warehouse: its 128-float padded observation rows are read with 16-byte "
+                                  "vector loads that the column offset behind the one-hot id would misalign (CoordSum and LBF support it)")
     cfg = RwareConfig(column_height=int(tc["column_height"]), shelf_rows=int(tc["shelf_rows"]), shelf_columns=int(tc["shelf_columns"]),
                       num_agents=int(tc["num_agents"]), sensor_range=int(tc["sensor_range"]), request_queue_size=int(tc["request_queue_size"]),
                       time_limit=int(kw.get("time_limit", 500)))

@@ -29,10 +29,11 @@ class CoordSumSpec:
         self.num_actions = int(num_actions)
         self.time_limit = int(time_limit)
         self.maxval = int(maxval) if maxval else int(num_actions)
+        self.add_agent_id = True   # system.add_agent_id (make_env.py:90-104): False = AgentIDWrapper is not applied
 
     @property
     def obs_dim(self) -> int:  # AgentIDWrapper: one-hot id + 1 feature
-        return self.num_agents + 1
+        return (self.num_agents if self.add_agent_id else 0) + 1
 
 
 REGISTRY = {  # coordsum/__init__.py:6-45
@@ -63,6 +64,8 @@ def make_obs(spec: CoordSumSpec, target_val: np.ndarray, step_count: np.ndarray)
     view = np.zeros((n, a, a + 1), np.int32)
     view[:, :, :a] = np.eye(a, dtype=np.int32)[None]
     view[:, :, a] = target_val[:, None]
+    if not getattr(spec, "add_agent_id", True):   # no AgentIDWrapper: the CoordSumWrapper's view alone (matrax.py:117-134)
+        view = view[:, :, a:]
     return dict(
         agents_view=view,
         action_mask=np.ones((n, a, spec.num_actions), bool),

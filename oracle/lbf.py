@@ -51,10 +51,11 @@ class LbfSpec:
         self.grid_size, self.fov, self.num_agents, self.num_food = int(grid_size), int(fov), int(num_agents), int(num_food)
         self.max_agent_level, self.force_coop, self.time_limit = int(max_agent_level), bool(force_coop), int(time_limit)
         self.num_actions = NUM_ACTIONS
+        self.add_agent_id = True   # system.add_agent_id (make_env.py:90-104): False = AgentIDWrapper is not applied
 
     @property
     def obs_dim(self) -> int:   # vector observation + one-hot agent id (AgentIDWrapper)
-        return 3 * (self.num_food + self.num_agents) + self.num_agents
+        return 3 * (self.num_food + self.num_agents) + (self.num_agents if self.add_agent_id else 0)
 
 
 def _generate(spec: LbfSpec, key: np.ndarray) -> Dict[str, np.ndarray]:
@@ -143,7 +144,8 @@ def make_obs(spec: LbfSpec, st: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     view, mask = _observe(spec, st)
     N, A = view.shape[0], spec.num_agents
     ids = np.broadcast_to(np.eye(A, dtype=np.float32)[None], (N, A, A))
-    return dict(agents_view=np.concatenate([ids, view.astype(np.float32)], axis=-1), action_mask=mask,
+    full = np.concatenate([ids, view.astype(np.float32)], axis=-1) if getattr(spec, "add_agent_id", True) else view.astype(np.float32)
+    return dict(agents_view=full, action_mask=mask,
                 step_count=np.repeat(st["step_count"][:, None], A, axis=1).astype(np.int32))
 
 

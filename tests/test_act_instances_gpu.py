@@ -158,6 +158,8 @@ def test_carried_decoder_states_across_rollout_seams(epw, A, K, N, nb, nh):
             assert float(o.abs().max()) > 1e-2
             close(d[:, :, :, :hs, :hs], o.permute(2, 1, 0, 3, 4), 1e-4, 2e-6, f"{what}: carried state vs the oracle")
             close(d, d2, 3e-5, 1e-6, f"{what}: carried state vs the kernel composition")
+        # the GRU actor's hidden state is carried across the seams as well (one scan per rollout from the carried state)
+        close(f.policy_h[f._cur], ol.policy_h.reshape(N * A, 128), 1e-4, 2e-6, f"{what}: policy hidden state")
         for dl in dls:
             dl._carry_over()
     assert dls[0].groups[0].graph is not None and not dls[0].groups[0].graph_failed
