@@ -16,4 +16,4 @@ int check_launch(const char* what) {
 }  // namespace magpo
 
 extern "C" const char* magpo_last_error() { return magpo::g_last_error.c_str(); }
-extern "C" int magpo_abi_version() { return 2; }   // 2: per-call tuning arguments (no setters), discount output of the env steps
+extern "C" int magpo_abi_version() { return 3; }   // 3: magpo_sable_act takes dims_host[16] (precand / defer) and fragment-major weights (magpo_act_weight_layout); 2: per-call tuning arguments (no setters), discount output of the env steps

@@ -51,7 +51,7 @@ def test_no_torch_types_and_plain_c_header():
 
 def test_host_entry_points_without_gpu(built):
     from oracle import prng
-    assert built.call("magpo_abi_version") == 2
+    assert built.call("magpo_abi_version") == 3
     # chunks of at most 32 tokens by default (csrc/retention32.hpp), 64 on request or for teams of more than 32 agents
     assert built.call("magpo_retention_num_chunks", 128, 4, 0) == 16 and built.call("magpo_retention_num_chunks", 128, 3, 32) == 13
     assert built.call("magpo_retention_num_chunks", 128, 40, 0) == 128
