@@ -80,7 +80,10 @@ def test_forced_instance_equals_kernel_composition_under_graph_replay(epw, A, K,
 
 @pytest.mark.parametrize("epw", [4, 8, 16])
 @pytest.mark.parametrize("A,K,TL,maxval,N,T,nb,nh", [(4, 20, 7, 60, 33, 12, 1, 1), (2, 10, 7, 15, 21, 12, 2, 1), (8, 15, 6, 100, 19, 10, 2, 1),
-                                                     (5, 20, 6, 80, 18, 10, 1, 2)])
+                                                     (5, 20, 6, 80, 18, 10, 1, 2),
+                                                     # every episode ends exactly ON the rollout seam (T = 2 x time limit): the bootstrap-value
+                                                     # launch flushes, the host zeroes, and the next rollout's first launch sees done for every env
+                                                     (4, 20, 5, 60, 17, 10, 1, 1)])
 def test_forced_instance_against_the_oracle(epw, A, K, TL, maxval, N, T, nb, nh):
     """Three consecutive rollouts of the forced instance (eager, captured as a HIP graph, replayed;, non-zero carried states, episode
     ends) against the oracle: sampled actions bit-exact, values / log-probs / carried retention states <= 1e-4."""
