@@ -21,8 +21,11 @@ extern "C" int magpo_sable_act_envs_per_wave(int N, int A, int forced) {
     if (forced != 4 && forced != 8 && forced != 16) { set_error("magpo_sable_act: envs per wave must be 0, 4, 8 or 16"); return -1; }
     return forced;
   }
-  if (A <= 4) return N > 4096 ? 16 : (N >= 4096 ? 8 : 4);   // (4096 envs, round 3 kernel: 290 / 270 / 328 us for 4 / 8 / 16)
-  return N >= 16384 ? 16 : (N >= 4096 ? 8 : 4);
+  // Round 4 (staggered / deferred candidate pre-pass; profiles/r04_act_kernel_launch_times.txt, us per launch for 4 / 8 / 16 envs per wave):
+  // A = 4, one block: N = 2048 -> 218 / 250 / -, 4096 -> 244 / 260 / 328, 8192 -> - / 309 / 349, 16384 -> 934 / 606 / 482; A = 8, two blocks:
+  // 4096 -> 945 / 1080 / 1439, 16384 -> - / - / 1904.  I.e. the fewest envs per wave whose waves still fit the chip's 1024 SIMDs at once.
+  (void)A;
+  return N <= 4096 ? 4 : (N <= 8192 ? 8 : 16);
 }
 
 // Fragment-major copy of a transposed weight for the acting kernel (fm_rows.hpp: wfrag<true>):

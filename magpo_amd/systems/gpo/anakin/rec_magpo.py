@@ -215,10 +215,15 @@ def learner_setup(env, keys, config, device=None, rank: int = 0, world: int = 1)
     # parameters = what flax creates from net_key / actor_net_key (rec_magpo.py:598-604,623; magpo_amd/params.py, UNPINNED restatement)
     from magpo_amd.learner import obs_row_stride
     obs_ld = obs_row_stride(cfg.obs_dim)   # floats between the rows the env kernels write; env.obs_dim = the features the networks read (add_agent_id)
+    import os
+    g_seed, a_seed = np.asarray(net_key, np.uint32), np.asarray(actor_net_key, np.uint32)
+    if os.environ.get("MAGPO_LEGACY_INIT") == "1":   # A/B only: the torch-generator initialisation of rounds 1-3 (same distributions, other draws)
+        g_seed = int(net_key[1]) & 0x7FFFFFFF
+        a_seed = g_seed + 1
     sable_network = SableGuider(cfg.num_agents, cfg.num_actions, env.obs_dim, device, obs_ld=obs_ld, embed_dim=int(nc.embed_dim), n_head=int(nc.n_head),
                                 n_block=int(nc.n_block), decay_scaling_factor=float(mc.decay_scaling_factor),
-                                use_pe=bool(mc.timestep_positional_encoding), max_pos=cfg.time_limit + 1, seed=np.asarray(net_key, np.uint32))
-    actor_network = GruActor(cfg.num_agents, cfg.num_actions, env.obs_dim, device, obs_ld=obs_ld, seed=np.asarray(actor_net_key, np.uint32), tuning=sable_network.tuning)
+                                use_pe=bool(mc.timestep_positional_encoding), max_pos=cfg.time_limit + 1, seed=g_seed)
+    actor_network = GruActor(cfg.num_agents, cfg.num_actions, env.obs_dim, device, obs_ld=obs_ld, seed=a_seed, tuning=sable_network.tuning)
     guider_optim, actor_optim = ClipAdam(sable_network, sysc), ClipAdam(actor_network, sysc)
     # Pack apply and update functions (rec_magpo.py:624-632)
     apply_fns = (sable_network.get_actions, sable_network.apply, actor_network.apply)

@@ -1,5 +1,5 @@
 """Parity of EVERY instance of the fused acting kernel k_sable_act<envs per wave, NA, NH> (csrc/act_fused_kernel.hpp), in particular
-the ones the bench shapes dispatch: 16 envs per wave above 4 096 envs, 8 at 4 096, 4 below (act_fused.hip: magpo_sable_act_envs_per_wave).
+the ones the bench shapes dispatch: 16 envs per wave above 8 192 envs, 8 up to 8 192, 4 up to 4 096 (act_fused.hip: magpo_sable_act_envs_per_wave).
 Their state-buffer depths, LDS carve-up and `nvalid` tails differ, so each is checked on its own (Weak 1):
 
 (a) forced instances on small ragged batches against the CPU oracle (sable_network.py:443-482, decode.py:111-153 restated in
@@ -172,8 +172,8 @@ FULL = [(16384, 4, 20, 1, 1), (4096, 4, 20, 1, 1), (8192, 4, 5, 1, 1), (16384, 8
 
 
 @pytest.mark.parametrize("N,A,K,nb,nh", FULL, ids=[f"{n}envs-{a}ag-{_n}" for n, a, _n in
-                                                   [(16384, 4, "k_sable_act<16,4,1>"), (4096, 4, "k_sable_act<8,4,1>"), (8192, 4, "k_sable_act<16,4,1>"),
-                                                    (16384, 8, "k_sable_act<16,8,0>"), (16384, 2, "k_sable_act<16,4,1>"), (4096, 8, "k_sable_act<8,8,0>")]])
+                                                   [(16384, 4, "k_sable_act<16,4,1>"), (4096, 4, "k_sable_act<4,4,1>"), (8192, 4, "k_sable_act<8,4,1>"),
+                                                    (16384, 8, "k_sable_act<16,8,0>"), (16384, 2, "k_sable_act<16,4,1>"), (4096, 8, "k_sable_act<4,8,0>")]])
 def test_size_dispatched_instance_equals_composition_at_bench_sizes(N, A, K, nb, nh, request):
     """BASELINE.json's env counts (16 384 CoordSum-4ag / LBF-2p, 8 192 and 4 096 per GPU for RWARE-4ag / the 32 768-env target, 8-agent
     teams of the 131 072-env config): the instance magpo_sable_act picks BY SIZE (named in the test id, checked here) runs six env
