@@ -572,18 +572,21 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
     const ActBlk& B = a.blk[0];
     float4 pS1[16];   // the first self-retention state of the candidate pass
     // candidate query rows q_c = x_c W_q (tile row = candidate) and the positional query rows pe W_q of this wave's envs
-    const Row qpe = dense64<true>(pe_q, B.qkvg1_t, nullptr, m, kq);
-    row_store(PEQ + env * 64, kq, qpe);
-    lsync();
     const int ntile = (a.K + 2 + 15) >> 4;
 #define CAND_ROWS(MT_)                                                                                                        \
     {                                                                                                                        \
       prime_state_perm(pS1, a.S_d1 + (long)env0 * 4096, lane);                                                               \
-      Row xq[MT_];                                                                                                           \
+      Row xin_[MT_ + 1], xout_[MT_ + 1];   /* the candidate tiles and the positional row: one pass over the weight fragments */ \
       _Pragma("unroll") for (int mt = 0; mt < MT_; ++mt) {                                                                   \
         const int c = min(16 * mt + env, a.K);                                                                               \
-        xq[mt] = dense64<true>(row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq), B.qkvg1_t, nullptr, m, kq); \
+        xin_[mt] = row_rms(row_gelu(row_load(a.W_act + (long)c * AE, kq)), a.s_decln, kq);                                   \
       }                                                                                                                      \
+      xin_[MT_] = pe_q;                                                                                                      \
+      dense64_multi<MT_ + 1, true>(xin_, MT_ + 1, xout_, B.qkvg1_t, nullptr, m, kq);                                         \
+      row_store(PEQ + env * 64, kq, xout_[MT_]);                                                                             \
+      lsync();                                                                                                               \
+      Row xq[MT_];                                                                                                           \
+      _Pragma("unroll") for (int mt = 0; mt < MT_; ++mt) xq[mt] = xout_[mt];                                                 \
       self_prepass_cand<NA, MT_, (EPW == 16 ? MAGPO_ACT_NBUF_CAND : 2)>(HK, PEQ, a.S_d1, a, env0, nvalid, B.qkvg1, xq, dm, pS1, apply);              \
     }
     if (ntile == 1) CAND_ROWS(1) else if (ntile == 2) CAND_ROWS(2) else CAND_ROWS(3)
@@ -843,7 +846,9 @@ __global__ __launch_bounds__(64, MAGPO_ACT_WPE) void k_sable_act(ActArgs a) {
     // head (sable_network.py:296-319) and sampling
     const Row hn = row_rms(row_gelu(dense64<true>(xo, a.h0_t, a.h0_b, m, kq)), a.h_s, kq);
     Row lg;
-    wgemm<4, true>(hn, a.h1_t, m, kq, [&](int g, f32x4 acc) {
+#pragma unroll
+    for (int j = 8; j < 16; ++j) lg.v[j] = 0.f;
+    wgemm<2, true>(hn, a.h1_t, m, kq, [&](int g, f32x4 acc) {   // K <= 31 actions: two column groups of 16 hold every logit
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int n = 16 * g + 4 * kq + r; lg.v[4 * g + r] = acc[r] + (n < a.K ? a.h1_b[n] : 0.f); }
     });
