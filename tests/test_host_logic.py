@@ -271,3 +271,17 @@ def test_tuning_defaults_and_environment_switches():
     assert o.linear_variant & 4 and o.actor_linear_variant & 4 and o.wgrad_variant & 64 and o.gru_split_bf16 == 1 and o.ret_chunk_tokens == 64
     e = Tuning.from_env({"MAGPO_LINEAR_BF3": "", "MAGPO_GRU_SPLIT_BF16": ""})                         # empty variables = unset
     assert e == Tuning()
+
+
+def test_net_obs_column_offsets_for_add_agent_id_false():
+    """system.add_agent_id (make_env.py:90-104): with the AgentIDWrapper the networks read the whole [one-hot id | features] row, without it the
+    features behind the id (same rows, pointer offset); wide observations (Robot Warehouse) refuse the offset."""
+    from magpo_amd.learner import CoordSumConfig, LbfConfig, RwareConfig, net_obs
+    assert net_obs(CoordSumConfig(4, 20)) == (5, 0) and net_obs(CoordSumConfig(4, 20, add_agent_id=False)) == (1, 4)
+    lbf = LbfConfig(8, 8, 2, 2, 2, True, 100)
+    assert net_obs(lbf) == (14, 0) and net_obs(LbfConfig(8, 8, 2, 2, 2, True, 100, add_agent_id=False)) == (12, 2)
+    rw = RwareConfig()
+    assert net_obs(rw) == (rw.obs_dim, 0)
+    rw.add_agent_id = False
+    with pytest.raises(NotImplementedError):
+        net_obs(rw)
