@@ -119,9 +119,9 @@ def test_forced_instance_against_the_oracle(epw, A, K, TL, maxval, N, T, nb, nh)
     assert dl.groups[0].graph is not None and not dl.groups[0].graph_failed
 
 
-@pytest.mark.parametrize("epw", [4, 8, 16])
-@pytest.mark.parametrize("A,K,N,nb,nh", [(4, 20, 21, 1, 1), (3, 10, 18, 2, 1), (5, 15, 9, 1, 2), (8, 15, 10, 2, 1)])
-def test_carried_decoder_states_across_rollout_seams(epw, A, K, N, nb, nh):
+@pytest.mark.parametrize("A,K,N,nb,nh,epw", [(4, 20, 21, 1, 1, 4), (4, 20, 21, 1, 1, 8), (4, 20, 21, 1, 1, 16), (3, 10, 18, 2, 1, 4), (3, 10, 18, 2, 1, 8),
+                                             (3, 10, 18, 2, 1, 16), (5, 15, 9, 1, 2, 8), (5, 15, 9, 1, 2, 16), (8, 15, 10, 2, 1, 4), (8, 15, 10, 2, 1, 16)])
+def test_carried_decoder_states_across_rollout_seams(A, K, N, nb, nh, epw):
     """NO episode ends inside or between the rollouts (time limit 100 > 4 x 6 steps), so every rollout starts from non-zero decoder states
     that nothing resets: the first launch of a rollout has no pending rows and must take the carried states as they are (round 4 found
     them decayed twice there -- invisible wherever an episode end zeroes the states before they are compared).  Fused instance against
