@@ -53,7 +53,9 @@ def close(a, b, rtol, atol, what):
                                                        (4, 20, 10, 60, 8, 16, 1, 1, 128), (3, 10, 9, 30, 6, 11, 2, 2, 128), (4, 20, 10, 60, 4, 12, 1, 4, 128),
                                                        (2, 10, 7, 15, 4, 12, 3, 1, 128)])
 def test_rollout_and_update_parity(A, K, TL, maxval, N, T, nb, nh, E):
-    ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb, nh=nh, E=E)
+    # (the T = 128 cases are about the chunk bookkeeping of a full-length rollout; they spend their time in the oracle's autograd, so one
+    # PPO epoch there -- the cumulative prev_hstates permutation across epochs, quirk B19, is covered by the short cases)
+    ol, dl = _mk(A, K, TL, maxval, N, T, nb=nb, nh=nh, E=E, P=2 if T < 100 else 1)
     assert np.array_equal(dl.env.target.cpu().numpy(), ol.env_state["target"])
     assert np.array_equal(dl.key, ol.key)
     om = ol.rollout(record_logits=True)
