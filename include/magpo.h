@@ -267,6 +267,9 @@ int magpo_sample_categorical(const float* logits, long ld, const unsigned char* 
                              uint32_t k0, uint32_t k1, const uint32_t* key_dev, int* action, long act_stride, float* logp,
                              long logp_stride, int* next_idx, long next_stride, float* lp_all, long lp_ld, int N,
                              int K, magpo_stream_t stream);
+/* GAE (multistep.py:24-68): done [T][N] with done[t] = "the observation of step t starts an episode", last_done [N] the same for step T.
+ * N * A < 8192 sequences (and T >= 16): a wavefront prefix scan over time, one wave per (env, agent) sequence (log-depth instead of T
+ * dependent steps); otherwise one thread per sequence, coalesced across sequences.  Same recurrence, fp32 summation order differs. */
 int magpo_gae(const float* reward, const float* value, const unsigned char* done, const float* last_val,
               const unsigned char* last_done, float* adv, float* targets, int T, int N, int A, float gamma,
               float lam, magpo_stream_t stream);

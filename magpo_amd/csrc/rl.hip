@@ -89,6 +89,43 @@ __global__ void k_gae(const float* __restrict__ reward, const float* __restrict_
   }
 }
 
+// ---- GAE as a wavefront prefix scan: one WAVE per (env, agent) sequence, 64 timesteps per tile, tiles from the end of the rollout.
+// Step t applies the affine map f_t(x) = delta_t + c_t x with c_t = gamma lambda (1 - done_{t+1}) to the advantage of step t + 1, so
+// adv_t = (f_t o f_{t+1} o ... o f_{T-1})(0): a reverse inclusive scan under composition, (a, b) o (a', b') = (a a', b + a b'), done in
+// log2(64) shuffle steps per tile with the tile's result carried into the one before it.  A sequence costs T / 64 x 6 dependent steps
+// instead of T, which is what matters when N * A is small (the paper's 64-env batch: 512 sequences = 512 threads of the serial kernel
+// walking 128 dependent steps); its loads are strided by N * A floats per lane, so the streaming one-thread-per-sequence kernel above stays
+// the choice for large batches (coalesced across sequences).  Same recurrence, other summation order: fp32 rounding differences only.
+__global__ __launch_bounds__(64) void k_gae_scan(const float* __restrict__ reward, const float* __restrict__ value, const unsigned char* __restrict__ done,
+                                                   const float* __restrict__ last_val, const unsigned char* __restrict__ last_done,
+                                                   float* __restrict__ adv, float* __restrict__ targets, int T, int N, int A, float gamma, float lam) {
+  const long NA = (long)N * A, i = blockIdx.x;
+  const long n = i / A;
+  const int lane = threadIdx.x;
+  float carry = 0.f;   // advantage of the first step behind the tile
+  for (int t0 = ((T - 1) / 64) * 64; t0 >= 0; t0 -= 64) {
+    const int t = t0 + lane;
+    const bool live = t < T;
+    float a = 1.f, b = 0.f, v = 0.f;   // identity map for the lanes past the end of the rollout
+    if (live) {
+      v = value[t * NA + i];
+      const bool last = t == T - 1;
+      const float next_value = last ? last_val[i] : value[(long)(t + 1) * NA + i];
+      const float nd = (last ? last_done[n] : done[(long)(t + 1) * N + n]) ? 0.f : 1.f;
+      b = reward[t * NA + i] + gamma * next_value * nd - v;
+      a = gamma * lam * nd;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {   // lane l: composition over lanes l .. min(l + 2 d - 1, 63)
+      const float a2 = __shfl_down(a, d), b2 = __shfl_down(b, d);
+      if (lane + d < 64) { b = b + a * b2; a = a * a2; }
+    }
+    const float g = b + a * carry;
+    if (live) { adv[t * NA + i] = g; targets[t * NA + i] = g + v; }
+    carry = __shfl(g, 0);
+  }
+}
+
 // ---- minibatch gather: (T,N,A,...) trajectory -> sequence-major minibatch rows --------------------
 // row = (j*T + t)*A + a'   <-   (t, env = env_idx[j], agent = agent_perm[a'])     (rec_magpo.py:441-462)
 struct GatherArgs {
@@ -379,8 +416,13 @@ extern "C" int magpo_gae(const float* reward, const float* value, const unsigned
                          const unsigned char* last_done, float* adv, float* targets, int T, int N, int A, float gamma,
                          float lam, hipStream_t st) {
   long NA = (long)N * A;
-  hipLaunchKernelGGL(k_gae, dim3((unsigned)((NA + 127) / 128)), dim3(128), 0, st, reward, value, done, last_val, last_done, adv,
-                     targets, T, N, A, gamma, lam);
+  if (NA <= 0 || T <= 0) return MAGPO_OK;
+  // few sequences: one wave per sequence, prefix scan over time (k_gae_scan); many: one thread per sequence, coalesced across sequences
+  if (NA < 8192 && T >= 16)
+    hipLaunchKernelGGL(k_gae_scan, dim3((unsigned)NA), dim3(64), 0, st, reward, value, done, last_val, last_done, adv, targets, T, N, A, gamma, lam);
+  else
+    hipLaunchKernelGGL(k_gae, dim3((unsigned)((NA + 127) / 128)), dim3(128), 0, st, reward, value, done, last_val, last_done, adv,
+                       targets, T, N, A, gamma, lam);
   return check_launch("magpo_gae");
 }
 

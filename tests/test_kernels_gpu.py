@@ -716,9 +716,11 @@ def test_coordsum_env(L, stream, A, K, TL, maxval, auto):
     assert np.array_equal(env.key.cpu().numpy().view(np.uint32), st["key"])
 
 
-def test_gae(L, stream):
+@pytest.mark.parametrize("T,N,A", [(37, 50, 4), (128, 64, 8), (200, 7, 3), (64, 5, 2), (9, 50, 4), (37, 4096, 4)])
+def test_gae(L, stream, T, N, A):
+    """multistep.py:24-68.  N * A < 8192 and T >= 16: the wavefront prefix scan over time (one wave per sequence: full tiles, a ragged last
+    tile, several tiles with a carried advantage); otherwise one thread per sequence (the last two shapes)."""
     g = torch.Generator().manual_seed(9)
-    T, N, A = 37, 50, 4
     reward, value = torch.randn(T, N, A, generator=g), torch.randn(T, N, A, generator=g)
     done_env = torch.rand(T, N, generator=g) < 0.1
     last_val = torch.randn(N, A, generator=g)
